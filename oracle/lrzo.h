@@ -1,0 +1,141 @@
+/* lrzo.h -- ORACLE (test infrastructure only, never shipped, never on the product path).
+ *
+ * CPU restatement of lrzip-next 0.14.0's compression hot path:
+ *   rzip long-range preprocessor      (reference src/rzip.c)
+ *   stream/block/chunk container      (reference src/stream.c, src/lrzip.c:write_magic)
+ *   lz4 compressibility gate          (reference src/stream.c:2325-2380 + liblz4 1.9.3 algorithm)
+ *   LZMA multithreaded BT4 match list (reference src/lzma/C/LzFindMt.c, LzFindOpt.c)
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product (lrzip-next_amd/) must never call it.
+ *
+ * Pinning: see oracle/README.md -- pinned against recorded outputs of the
+ * reference binary and against oracle/_ref/liblzma_ref.so
+ * (the reference's own LZMA sources compiled unmodified).
+ */
+#ifndef LRZO_H
+#define LRZO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int64_t i64;
+typedef uint8_t uchar;
+
+/* ---- rzip ---------------------------------------------------------- */
+
+/* reference src/rzip.c:67-82 levels[] */
+typedef struct {
+	unsigned long mb_used;
+	unsigned initial_freq;
+	unsigned max_chain_len;
+} lrzo_level;
+const lrzo_level *lrzo_rzip_level(int level);
+
+/* reference src/rzip.c:765-771 : glibc random() seed-1 sequence,
+ * hash_index[i] = (random() << 16) ^ random(), shifted operand drawn first. */
+void lrzo_hash_index(uint64_t out[256]);
+
+/* Sinks for the two rzip streams.  put0 receives stream-0 bytes (tokens),
+ * put1 receives a literal run as (offset,len) into the chunk buffer. */
+typedef struct {
+	void *ctx;
+	void (*put0)(void *ctx, const uchar *p, i64 len);
+	void (*put1)(void *ctx, i64 chunk_off, i64 len);
+} lrzo_sink;
+
+typedef struct {
+	i64 matches, match_bytes, literals, literal_bytes;
+	i64 tag_hits, tag_misses, inserts;
+	i64 lookups; /* candidate positions probed (not in reference stats) */
+	i64 hash_count;
+	uint64_t minimum_tag_mask, tag_mask;
+	i64 tag_clean_ptr;
+} lrzo_rzip_stats;
+
+/* One rzip chunk: reference src/rzip.c:586-762 hash_search.
+ * victim_round is the static of insert_hash (src/rzip.c:308), carried by the caller.
+ * crc_out = CRC-32 (IEEE) of the chunk. Emits terminator and CRC on stream 0. */
+void lrzo_rzip_chunk(const uchar *buf, i64 chunk_size, int rzip_level, int chunk_bytes,
+		     const uint64_t hash_index[256], i64 *victim_round,
+		     const lrzo_sink *sink, lrzo_rzip_stats *stats, uint32_t *crc_out);
+
+/* Optional: dump of the final hash table (for GPU resolver parity). table must
+ * hold 2*2^hash_bits u64 (offset,tag pairs) or be NULL. */
+void lrzo_rzip_chunk_table(const uchar *buf, i64 chunk_size, int rzip_level, int chunk_bytes,
+			   const uint64_t hash_index[256], i64 *victim_round,
+			   const lrzo_sink *sink, lrzo_rzip_stats *stats, uint32_t *crc_out,
+			   uint64_t *table_out);
+
+/* ---- hashes -------------------------------------------------------- */
+uint32_t lrzo_crc32(uint32_t crc, const uchar *p, size_t n);
+typedef struct { uint32_t a, b, c, d; uint64_t len; uchar buf[64]; unsigned fill; } lrzo_md5;
+void lrzo_md5_init(lrzo_md5 *m);
+void lrzo_md5_update(lrzo_md5 *m, const uchar *p, size_t n);
+void lrzo_md5_final(lrzo_md5 *m, uchar out[16]);
+
+/* ---- lz4 gate ------------------------------------------------------ */
+/* liblz4 1.9.3 LZ4_compress_default(src,dst,srcSize,dstCapacity) return value
+ * (compressed size, 0 on failure), without producing the bytes. */
+int lrzo_lz4_compress_default_size(const uchar *src, int src_size, int dst_capacity);
+/* reference src/stream.c:2325-2380 lz4_compresses: 0 = skip backend, else pct. */
+int lrzo_lz4_compresses(const uchar *s_buf, i64 s_len, int threshold);
+
+/* ---- LZMA match finder (MT BT4 semantics) -------------------------- */
+/* For block src[0..n): per position i the final (len,dist-1) pair list the
+ * encoder's ReadMatchDistances sees from MatchFinderMt_GetMatches
+ * (reference LzFindMt.c:1274-1317 after MixMatches3), for numHashBytes=4.
+ * offsets[i]..offsets[i+1] index u32 pairs[]; returns total u32 count, or -1.
+ * pairs may be NULL to only count.  dict_size = LZMA dictionary, fb = matchMaxLen,
+ * cut = cutValue. */
+i64 lrzo_lzma_mf_bt4(const uchar *src, size_t n, uint32_t dict_size, unsigned fb, unsigned cut,
+		     uint64_t *offsets /* n+1 */, uint32_t *pairs, size_t pairs_cap);
+/* hash mask the reference derives (LzFind.c:347-373,432-442) and bigHash flag */
+uint32_t lrzo_lzma_hash_mask(uint32_t dict_size, uint64_t expected_size);
+
+/* ---- container / whole-file driver --------------------------------- */
+typedef struct {
+	int compression_level;     /* -L, 1..9 (7) */
+	int rzip_level;            /* -R, 0 => = compression_level */
+	int no_compress;           /* -n */
+	int threads;               /* -p */
+	int processors;            /* host PROCESSORS as the reference would see it */
+	i64 ramsize;               /* -m * 100 MiB, or physical */
+	i64 window;                /* -w (x100 MiB), 0 = unset */
+	int lz4_test;              /* default 1 (off when -n) */
+	int threshold;             /* default 100 */
+	int nobemt;                /* --nobemt */
+	uint32_t dict_size;        /* 0 => by level */
+	int workers;               /* oracle-side worker threads for block compression (timing only) */
+	int verbose;
+} lrzo_params;
+void lrzo_params_default(lrzo_params *p);
+
+/* LzmaCompress-compatible callback (oracle/_ref or any other). */
+typedef int (*lrzo_lzma_fn)(unsigned char *dest, size_t *destLen, const unsigned char *src, size_t srcLen,
+			    unsigned char *outProps, size_t *outPropsSize, int level, unsigned dictSize,
+			    int lc, int lp, int pb, int fb, int numThreads);
+
+typedef struct {
+	i64 stream_bufsize;
+	int threads_used;
+	uint32_t dict_size;
+	i64 n_chunks, n_blocks;
+	i64 blocks_lzma, blocks_none;
+	lrzo_rzip_stats rz;
+} lrzo_file_stats;
+
+/* Compress in[0..n) into a malloc'd .lrz image (caller frees *out).
+ * Restates rzip_fd (src/rzip.c:922), open_stream_out sizing (src/stream.c:1140),
+ * compthread header/block layout (src/stream.c:1550), write_magic (src/lrzip.c:131). */
+int lrzo_compress_buffer(const lrzo_params *p, const uchar *in, i64 n, lrzo_lzma_fn lzma,
+			 uchar **out, i64 *out_len, lrzo_file_stats *fs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
