@@ -1,0 +1,135 @@
+/* lrzgpu.h -- C ABI of the MI355X-native lrzip-next compression hot path.
+ *
+ * Drop-in boundary for: rzip long-range preprocessor + lz4 compressibility gate + per-block
+ * LZMA backend of lrzip-next 0.14 (reference paths are relative to the lrzip-next tree).
+ * Plain pointers and sizes only; every function returns 0 (or a documented value) on success
+ * and a negative value on failure -- the library never calls exit().  Host pointers unless the
+ * name ends in _dev.  The HIP runtime is required: without a visible gfx950 device the compute
+ * entry points fail with LRZGPU_E_NODEVICE (there is no CPU fallback in this library).
+ */
+#ifndef LRZGPU_H
+#define LRZGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LRZGPU_E_NODEVICE (-100)
+#define LRZGPU_E_PARAM (-101)
+#define LRZGPU_E_NOMEM (-102)
+#define LRZGPU_E_HIP (-103)
+#define LRZGPU_E_IO (-104)
+#define LRZGPU_E_INTERNAL (-105)
+
+/* rzip_control.flags bits this path reads (src/include/lrzip_private.h:257-370) */
+#define LRZGPU_FLAG_NO_COMPRESS (1u << 5)  /* FLAG_NO_COMPRESS, -n */
+#define LRZGPU_FLAG_THRESHOLD (1u << 20)   /* FLAG_THRESHOLD: lz4 test on (default) */
+#define LRZGPU_FLAG_NOBEMT (1u << 27)      /* FLAG_NOBEMT */
+
+/* The fields of rzip_control (src/include/lrzip_private.h:472-581) the compress path depends on.
+ * Output depends on them exactly as in the reference (block boundaries, dictionary, thread slots:
+ * src/stream.c:1169-1331, src/util.c:103-188, src/rzip.c:999-1020). */
+typedef struct lrzgpu_control {
+	int compression_level;      /* -L, 5..9 on the GPU LZMA path (1..9 with NO_COMPRESS)          */
+	int rzip_compression_level; /* -R, 0 = same as compression_level (src/main.c:779-780)          */
+	int threads;                /* -p, before prepare_streamout_threads() adds one                 */
+	int processors;             /* PROCESSORS (sysconf) as the reference host would report         */
+	int64_t ramsize;            /* -m x 100 MiB, or physical RAM (src/lrzip.c:108)                 */
+	int64_t window;             /* -w, 0 = unset                                                   */
+	uint32_t dictSize;          /* --dictsize, 0 = by level (src/util.c:108-127)                   */
+	uint32_t flags;             /* LRZGPU_FLAG_*                                                   */
+	int threshold;              /* -T value, default 100                                           */
+	/* execution (no influence on the bytes produced) */
+	int device;                 /* HIP device ordinal                                              */
+	int host_threads;           /* host parser/range-coder threads, 0 = threads                    */
+	int gpu_slots;              /* LZMA blocks resident on the GPU at once, 0 = default            */
+	int verbose;
+	/* results */
+	int64_t st_size;            /* control->st_size                                                */
+	uint8_t hash_resblock[16];  /* MD5 of the input (control->hash_resblock)                       */
+	uint8_t lzma_properties[5]; /* control->lzma_properties                                        */
+	uint32_t dictSize_used;     /* dictionary after open_stream_out()'s reduction loop             */
+	int64_t stream_bufsize;     /* block size open_stream_out() settled on                         */
+	int threads_used;
+} lrzgpu_control;
+
+void lrzgpu_control_init(lrzgpu_control *c); /* initialise_control() defaults, src/lrzip.c:1813-1857 */
+
+/* ---- whole-file entry points ----------------------------------------------------------------- */
+
+/* void rzip_fd(rzip_control*, int fd_in, int fd_out)  -- src/include/rzip.h:12, src/rzip.c:922.
+ * Compresses fd_in chunk by chunk at the current offset of fd_out and appends the MD5. Like the
+ * reference it does not write the 21-byte magic (compress_file does, src/lrzip.c:1464-1560). */
+int lrzgpu_rzip_fd(lrzgpu_control *control, int fd_in, int fd_out);
+
+/* compress_file() for plain files: magic placeholder, rzip_fd, write_magic -- src/lrzip.c:1464. */
+int lrzgpu_compress_file(lrzgpu_control *control, int fd_in, int fd_out);
+
+/* Same container, memory to memory. in: host buffer. *out is malloc'd (caller frees with free()). */
+int lrzgpu_compress_buffer(lrzgpu_control *control, const uint8_t *in, int64_t n, uint8_t **out, int64_t *out_len);
+
+/* Same, input already resident in HBM (d_in is a device pointer on control->device). */
+int lrzgpu_compress_buffer_dev(lrzgpu_control *control, const void *d_in, int64_t n, uint8_t **out, int64_t *out_len);
+
+/* ---- rzip stage -------------------------------------------------------------------------------
+ * hash_search(), src/rzip.c:586-762: scan one chunk resident in HBM.  Emits the two rzip streams
+ * exactly as put_match/put_literal/write_sbstream would (src/rzip.c:208-265): stream 0 (tokens,
+ * terminator, CRC) into a malloc'd host buffer, stream 1 (literal bytes) into a device buffer of
+ * the caller (capacity n). victim_round carries insert_hash()'s static (src/rzip.c:308). */
+typedef struct lrzgpu_scan_stats {
+	int64_t matches, match_bytes, literals, literal_bytes, inserts, lookups, tag_hits, tag_misses;
+	int64_t hash_count, tag_clean_ptr;
+	uint64_t minimum_tag_mask, tag_mask;
+} lrzgpu_scan_stats;
+
+int lrzgpu_hash_search_dev(const void *d_chunk, int64_t chunk_size, int rzip_level, int chunk_bytes,
+			   int64_t *victim_round, uint8_t **stream0, int64_t *stream0_len,
+			   void *d_stream1, int64_t *stream1_len, uint32_t *crc32, lrzgpu_scan_stats *stats,
+			   int device);
+/* host-pointer convenience wrapper (uploads the chunk, downloads stream 1 into stream1[n]) */
+int lrzgpu_hash_search(const uint8_t *chunk, int64_t chunk_size, int rzip_level, int chunk_bytes,
+		       int64_t *victim_round, uint8_t **stream0, int64_t *stream0_len,
+		       uint8_t *stream1, int64_t *stream1_len, uint32_t *crc32, lrzgpu_scan_stats *stats,
+		       int device);
+/* init_hash_indexes(), src/rzip.c:765-771 (glibc random() seed-1 sequence, frozen) */
+void lrzgpu_hash_index(uint64_t out[256]);
+
+/* ---- lz4 gate ---------------------------------------------------------------------------------
+ * static int lz4_compresses(rzip_control*, uchar *s_buf, i64 s_len) -- src/stream.c:2325-2380.
+ * Returns 0 = leave the block uncompressed, 1..100 = percentage; <0 on error. */
+int lrzgpu_lz4_compresses(const uint8_t *s_buf, int64_t s_len, int threshold, int device);
+int lrzgpu_lz4_compresses_dev(const void *d_buf, int64_t s_len, int threshold, int device);
+/* LZ4_compress_default(src, dst, srcSize, dstCapacity) return value (liblz4 1.9.3), size only. */
+int lrzgpu_lz4_compress_default_size(const uint8_t *src, int src_size, int dst_capacity, int device);
+
+/* ---- LZMA backend -----------------------------------------------------------------------------
+ * LzmaCompress() -- src/lzma/include/LzmaLib.h:95-112, same arguments and SRes codes
+ * (0 OK, 2 MEM, 5 PARAM, 7 OUTPUT_EOF).  GPU match finder + host parser/range coder.
+ * Levels 5..9 (btMode=1, numHashBytes=4); numThreads is accepted and ignored (the output of the
+ * reference does not depend on it). */
+int lrzgpu_LzmaCompress(unsigned char *dest, size_t *destLen, const unsigned char *src, size_t srcLen,
+			unsigned char *outProps, size_t *outPropsSize, int level, unsigned dictSize,
+			int lc, int lp, int pb, int fb, int numThreads);
+
+/* The GPU half alone: per-position match lists in the order MatchFinderMt_GetMatches
+ * (src/lzma/C/LzFindMt.c:1274-1317) would return them.  counts[i] = number of u32 entries of
+ * position i; pairs = (len, dist-1) couples of position 0, 1, ... ; returns total entries or <0. */
+int64_t lrzgpu_lzma_match_lists(const uint8_t *src, size_t n, uint32_t dictSize, unsigned fb, unsigned cutValue,
+				uint8_t *counts, uint32_t *pairs, size_t pairs_cap, int device);
+
+/* The host half alone: parser + range coder fed with match lists (any producer). */
+int lrzgpu_lzma_encode_with_lists(unsigned char *dest, size_t *destLen, const unsigned char *src, size_t srcLen,
+				  const uint8_t *counts, const uint32_t *pairs, int level, unsigned dictSize,
+				  int lc, int lp, int pb, int fb);
+
+/* ---- misc ------------------------------------------------------------------------------------- */
+int lrzgpu_device_count(void);
+const char *lrzgpu_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,239 @@
+// api_backend.cpp -- C ABI entry points of the per-block backends (lz4 gate, LZMA).
+// Boundary declared in include/lrzgpu.h; each function cites the reference interface it replaces.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../../include/lrzgpu.h"
+#include "common.h"
+#include "lz4_gate.h"
+#include "lzma_enc.h"
+#include "lzma_mf.h"
+
+using namespace lrzgpu;
+
+extern "C" int lrzgpu_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess)
+		return 0;
+	return n;
+}
+
+extern "C" const char *lrzgpu_version(void) { return "lrzgpu 0.1 (gfx950; lrzip-next 0.14.0 container)"; }
+
+namespace lrzgpu {
+int select_device(int device)
+{
+	int n = lrzgpu_device_count();
+	if (n <= 0 || device < 0 || device >= n)
+		return LRZGPU_E_NODEVICE;
+	if (hipSetDevice(device) != hipSuccess)
+		return LRZGPU_E_HIP;
+	return 0;
+}
+} // namespace lrzgpu
+
+// ---- lz4 gate: src/stream.c:2325-2380 -------------------------------------------------------
+
+static int lz4_size_dev(const uint8_t *d_src, int src_size, int dst_capacity)
+{
+	Lz4Job job{d_src, src_size, dst_capacity}, *d_job = nullptr;
+	int *d_res = nullptr, res = -1;
+	if (hipMalloc(&d_job, sizeof(job)) != hipSuccess)
+		return LRZGPU_E_NOMEM;
+	if (hipMalloc(&d_res, sizeof(int)) != hipSuccess) {
+		(void)hipFree(d_job);
+		return LRZGPU_E_NOMEM;
+	}
+	int rc = 0;
+	if (hipMemcpy(d_job, &job, sizeof(job), hipMemcpyHostToDevice) != hipSuccess || lz4_sizes_device(d_job, 1, d_res, 0) != 0 ||
+	    hipMemcpy(&res, d_res, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+		rc = LRZGPU_E_HIP;
+	(void)hipFree(d_job);
+	(void)hipFree(d_res);
+	return rc ? rc : res;
+}
+
+extern "C" int lrzgpu_lz4_compresses_dev(const void *d_buf, int64_t s_len, int threshold, int device)
+{
+	int rc = select_device(device);
+	if (rc)
+		return rc;
+	if (s_len < 0)
+		return LRZGPU_E_PARAM;
+	int err = 0;
+	int v = lz4_compresses_decision(s_len, threshold, [&](int in_len, int d_len) {
+		int r = lz4_size_dev((const uint8_t *)d_buf, in_len, d_len);
+		if (r < 0) {
+			err = r;
+			return 0;
+		}
+		return r;
+	});
+	return err ? err : v;
+}
+
+extern "C" int lrzgpu_lz4_compresses(const uint8_t *s_buf, int64_t s_len, int threshold, int device)
+{
+	int rc = select_device(device);
+	if (rc)
+		return rc;
+	if (s_len < 0)
+		return LRZGPU_E_PARAM;
+	uint8_t *d = nullptr;
+	if (hipMalloc(&d, (size_t)s_len + 16) != hipSuccess)
+		return LRZGPU_E_NOMEM;
+	if (s_len && hipMemcpy(d, s_buf, (size_t)s_len, hipMemcpyHostToDevice) != hipSuccess) {
+		(void)hipFree(d);
+		return LRZGPU_E_HIP;
+	}
+	int v = lrzgpu_lz4_compresses_dev(d, s_len, threshold, device);
+	(void)hipFree(d);
+	return v;
+}
+
+extern "C" int lrzgpu_lz4_compress_default_size(const uint8_t *src, int src_size, int dst_capacity, int device)
+{
+	int rc = select_device(device);
+	if (rc)
+		return rc;
+	if (src_size < 0)
+		return 0;
+	uint8_t *d = nullptr;
+	if (hipMalloc(&d, (size_t)src_size + 16) != hipSuccess)
+		return LRZGPU_E_NOMEM;
+	if (src_size && hipMemcpy(d, src, (size_t)src_size, hipMemcpyHostToDevice) != hipSuccess) {
+		(void)hipFree(d);
+		return LRZGPU_E_HIP;
+	}
+	int v = lz4_size_dev(d, src_size, dst_capacity);
+	(void)hipFree(d);
+	return v;
+}
+
+// ---- LZMA: src/lzma/include/LzmaLib.h:95-112 --------------------------------------------------
+
+extern "C" int64_t lrzgpu_lzma_match_lists(const uint8_t *src, size_t n, uint32_t dictSize, unsigned fb, unsigned cutValue,
+					   uint8_t *counts, uint32_t *pairs, size_t pairs_cap, int device)
+{
+	int rc = select_device(device);
+	if (rc)
+		return rc;
+	MfWorkspace *w = nullptr;
+	double per_pos = n ? (double)pairs_cap / (double)n : 16.0;
+	if (per_pos < 4)
+		per_pos = 4;
+	if (mf_workspace_create(&w, n ? n : 1, per_pos) != 0) {
+		mf_workspace_destroy(w);
+		return LRZGPU_E_NOMEM;
+	}
+	uint8_t *d_src = nullptr;
+	int64_t ret = LRZGPU_E_HIP;
+	unsigned long long total = 0;
+	if (hipMalloc(&d_src, n + 16) == hipSuccess && (n == 0 || hipMemcpy(d_src, src, n, hipMemcpyHostToDevice) == hipSuccess)) {
+		int r = mf_run_device(w, d_src, n, dictSize, fb, cutValue, 0, &total);
+		if (r == 0) {
+			if (total > pairs_cap)
+				ret = LRZGPU_E_NOMEM;
+			else if ((n == 0 || hipMemcpy(counts, w->counts, n, hipMemcpyDeviceToHost) == hipSuccess) &&
+				 (total == 0 || hipMemcpy(pairs, w->pool_out, total * 4, hipMemcpyDeviceToHost) == hipSuccess))
+				ret = (int64_t)total;
+		} else
+			ret = r == -4 ? LRZGPU_E_NOMEM : LRZGPU_E_INTERNAL;
+	}
+	if (d_src)
+		(void)hipFree(d_src);
+	mf_workspace_destroy(w);
+	return ret;
+}
+
+extern "C" int lrzgpu_lzma_encode_with_lists(unsigned char *dest, size_t *destLen, const unsigned char *src, size_t srcLen,
+					     const uint8_t *counts, const uint32_t *pairs, int level, unsigned dictSize,
+					     int lc, int lp, int pb, int fb)
+{
+	LzmaParams p;
+	p.level = level;
+	p.dict_size = dictSize;
+	p.lc = lc;
+	p.lp = lp;
+	p.pb = pb;
+	p.fb = fb;
+	MatchLists ml;
+	ml.counts = counts;
+	ml.pairs = pairs;
+	size_t out_len = 0;
+	int r = lzma_encode_block(p, src, srcLen, ml, dest, *destLen, &out_len);
+	*destLen = out_len;
+	return r;
+}
+
+namespace lrzgpu {
+// LzmaEncProps_Normalize() for the arguments lrzip-next passes (LzmaEnc.c:68-108)
+int lzma_normalize(LzmaParams &p, int level, unsigned dictSize, int lc, int lp, int pb, int fb)
+{
+	if (level < 0)
+		level = 5;
+	p.level = level;
+	if (dictSize == 0)
+		dictSize = level <= 3 ? (1u << (level * 2 + 16)) : level <= 6 ? (1u << (level + 19)) : level <= 7 ? (1u << 25) : (1u << 26);
+	p.dict_size = dictSize;
+	p.lc = lc < 0 ? 3 : lc;
+	p.lp = lp < 0 ? 0 : lp;
+	p.pb = pb < 0 ? 2 : pb;
+	p.fb = fb < 0 ? (level < 7 ? 32 : 64) : fb;
+	if (p.lc > 8 || p.lp > 4 || p.pb > 4)
+		return LZ_ERROR_PARAM;
+	if (level < 5)
+		return LZ_ERROR_PARAM; // algo=0 / HC5: outside this path
+	return LZ_OK;
+}
+} // namespace lrzgpu
+
+extern "C" int lrzgpu_LzmaCompress(unsigned char *dest, size_t *destLen, const unsigned char *src, size_t srcLen,
+				   unsigned char *outProps, size_t *outPropsSize, int level, unsigned dictSize,
+				   int lc, int lp, int pb, int fb, int numThreads)
+{
+	(void)numThreads;
+	LzmaParams p;
+	int r = lzma_normalize(p, level, dictSize, lc, lp, pb, fb);
+	if (r != LZ_OK)
+		return r;
+	if (*outPropsSize < 5)
+		return LZ_ERROR_PARAM;
+	*outPropsSize = 5;
+	lzma_write_props(p, outProps);
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	if (select_device(dev))
+		return LZ_ERROR_MEM; // no SRes for "no device": the library has no CPU finder
+	std::vector<uint8_t> counts(srcLen ? srcLen : 1);
+	size_t cap = srcLen * 16 + 4096;
+	for (int attempt = 0; attempt < 3; attempt++) {
+		std::vector<uint32_t> pairs;
+		try {
+			pairs.resize(cap);
+		} catch (...) {
+			return LZ_ERROR_MEM;
+		}
+		int64_t total = lrzgpu_lzma_match_lists(src, srcLen, p.dict_size, (unsigned)p.fb, p.cut(), counts.data(), pairs.data(), cap, dev);
+		if (total == LRZGPU_E_NOMEM) {
+			cap *= 4;
+			continue;
+		}
+		if (total < 0)
+			return LZ_ERROR_MEM;
+		MatchLists ml;
+		ml.counts = counts.data();
+		ml.pairs = pairs.data();
+		size_t out_len = 0;
+		r = lzma_encode_block(p, src, srcLen, ml, dest, *destLen, &out_len);
+		*destLen = out_len;
+		return r;
+	}
+	return LZ_ERROR_MEM;
+}

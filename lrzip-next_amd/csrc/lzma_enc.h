@@ -1,0 +1,49 @@
+// lzma_enc.h -- host-side LZMA parser + range coder of the MI355X path.
+//
+// The GPU match finder (lzma_mf.hip) produces, for every position of a block, the exact
+// (len, dist-1) list the reference encoder would receive from its multithreaded BT4 finder
+// (reference src/lzma/C/LzFindMt.c:1274-1317).  This encoder consumes those lists and emits the
+// raw LZMA stream of reference src/lzma/C/LzmaEnc.c (optimal parser, algo=1) bit for bit.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace lrzgpu {
+
+// Per-position match lists for one block, in position order:
+//   counts[i]  = number of u32 entries of position i (2 per (len, dist-1) pair, lengths increasing)
+//   pairs[]    = the entries of position 0, then position 1, ...
+// The encoder walks positions monotonically, so it keeps the running offset itself.
+struct MatchLists {
+	const uint8_t *counts = nullptr; // n entries
+	const uint32_t *pairs = nullptr;
+	// Optional streaming hook: called before position `upto` is first read, so a producer that is
+	// still filling the arrays can block the consumer.  May be null.
+	void (*wait_ready)(void *ctx, size_t upto) = nullptr;
+	void *ctx = nullptr;
+};
+
+struct LzmaParams {
+	int level = 7;
+	uint32_t dict_size = 1u << 25;
+	int lc = 3, lp = 0, pb = 2;
+	int fb = 64;
+	uint32_t cut() const { return 16u + ((uint32_t)fb >> 1); } // btMode=1 (LzmaEnc.c:99)
+};
+
+enum : int { LZ_OK = 0, LZ_ERROR_MEM = 2, LZ_ERROR_PARAM = 5, LZ_ERROR_OUTPUT_EOF = 7 };
+
+// Encodes src[0..n) given its match lists. dest_cap bytes available at dest; on success
+// *dest_len is the stream size. Returns LZ_ERROR_OUTPUT_EOF when the stream does not fit
+// (reference: SeqOutStreamBuf_Write overflow, LzmaEnc.c:2971-2988, 3102-3107).
+int lzma_encode_block(const LzmaParams &prm, const uint8_t *src, size_t n, const MatchLists &ml,
+		      uint8_t *dest, size_t dest_cap, size_t *dest_len);
+
+// 5-byte LZMA properties (reference LzmaEnc_WriteProperties, LzmaEnc.c:3037-3070).
+void lzma_write_props(const LzmaParams &prm, uint8_t props[5]);
+
+// Hash mask the reference derives for a block (LzFind.c:347-373, 432-442).
+uint32_t lzma_hash_mask(uint32_t dict_size, uint64_t expected_size);
+
+} // namespace lrzgpu

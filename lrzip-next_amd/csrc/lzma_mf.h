@@ -1,0 +1,36 @@
+// lzma_mf.h -- device-side LZMA match finder (see lzma_mf.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "lzma_enc.h"
+
+namespace lrzgpu {
+
+struct MfWorkspace {
+	size_t max_n;
+	unsigned long long pool_cap; // u32 entries
+	uint32_t *key_a, *key_b, *val_a, *val_b, *spos;
+	uint32_t *prev2, *prev3;
+	uint32_t *seg_start, *seg_len, *seg_start_s, *seg_len_s;
+	uint8_t *flags;
+	uint32_t *son;
+	uint8_t *counts;      // result: entries per position
+	uint64_t *tmp_start;
+	uint64_t *offsets;    // exclusive scan of counts
+	uint32_t *pool_tmp;
+	uint32_t *pool_out;   // result: entries in position order
+	void *scalars;
+	void *cub_tmp;
+	size_t cub_bytes;
+};
+
+// pool_per_pos: u32 pool entries reserved per input byte (typical text needs ~6-10).
+int mf_workspace_create(MfWorkspace **out, size_t max_n, double pool_per_pos);
+void mf_workspace_destroy(MfWorkspace *w);
+int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict, uint32_t fb, uint32_t cut,
+		  hipStream_t s, unsigned long long *total_entries);
+
+} // namespace lrzgpu

@@ -1,0 +1,405 @@
+// lzma_mf.hip -- GPU match finder for the per-block LZMA backend (gfx950 / MI355X).
+//
+// Produces, for every position of a block, exactly the (len, dist-1) list the reference's
+// multithreaded BT4 finder hands to the parser (reference src/lzma/C/LzFindMt.c:1274-1317 after
+// MixMatches3 1031-1072; tree walk LzFindOpt.c:67-244; heads LzFindMt.c:368-394).
+//
+// MI355X-first decomposition (the reference walks positions strictly in order on one thread):
+//   * a binary tree only ever links positions that share one main-hash value, and the hash-head
+//     chain of the reference is "previous position with the same hash value".  So the block is
+//     partitioned by hash value with a stable radix sort (key = hash, value = position) and every
+//     hash bucket becomes an independent serial chain -> one GPU lane per bucket, buckets
+//     scheduled longest-first.  son[] is indexed by absolute position (8 B per input byte in HBM)
+//     instead of the reference's cyclic buffer; the `delta >= cyclicBufferSize` cut-off is kept.
+//   * the h2/h3 "most recent position with the same 2/3-byte hash" tables of the LZ thread are
+//     pure functions of the data (updated at every position), obtained with two more sorts.
+//   * records are written into a bump-allocated pool and then gathered into position order so the
+//     host parser streams them sequentially.
+// Roofline: HBM-latency/throughput bound pointer chasing, no MFMA.  Algorithmic bytes/position:
+// 1 B read + 4 B head r/w + 8 B son pair + <=48 node visits (8 B pair + compares) -- see DESIGN.md.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "lzma_mf.h"
+
+namespace lrzgpu {
+
+#define HIPCHK(x)                                                                              \
+	do {                                                                                   \
+		hipError_t e_ = (x);                                                           \
+		if (e_ != hipSuccess) {                                                        \
+			fprintf(stderr, "lrzgpu: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+			return -1;                                                             \
+		}                                                                              \
+	} while (0)
+
+__device__ __forceinline__ uint32_t crc_byte(uint32_t b)
+{
+	uint32_t r = b;
+#pragma unroll
+	for (int j = 0; j < 8; j++)
+		r = (r >> 1) ^ (0xEDB88320u & (0u - (r & 1)));
+	return r;
+}
+
+// keys for the three hash tables; which: 4 = main hash (GetHeads4 / GetHeads4b), 3 = h3, 2 = h2
+template <int WHICH>
+__global__ void __launch_bounds__(256) k_keys(const uint8_t *__restrict__ src, uint32_t n4, uint32_t mask, int big,
+					      uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t stride = gridDim.x * blockDim.x;
+	for (; i < n4; i += stride) {
+		uint32_t b0 = src[i], b1 = src[i + 1], b2 = src[i + 2], b3 = src[i + 3];
+		uint32_t c0 = crc_byte(b0);
+		uint32_t k;
+		if (WHICH == 4) {
+			if (big)
+				k = (c0 & mask) ^ (b1 | (b2 << 8) | (b3 << 16));
+			else
+				k = (c0 & mask) ^ ((crc_byte(b3) << 5) & mask) ^ (b1 | (b2 << 8));
+		} else if (WHICH == 3) {
+			k = ((c0 ^ b1) ^ (b2 << 8)) & 0xFFFF;
+		} else {
+			k = (c0 ^ b1) & 1023;
+		}
+		keys[i] = k;
+		vals[i] = i;
+	}
+}
+
+// prev[pos] = 1-based position of the previous element with the same key, 0 if none
+__global__ void __launch_bounds__(256) k_link_prev(const uint32_t *__restrict__ skey, const uint32_t *__restrict__ sval,
+						   uint32_t n4, uint32_t *__restrict__ prev)
+{
+	uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t stride = gridDim.x * blockDim.x;
+	for (; k < n4; k += stride) {
+		uint32_t p = 0;
+		if (k > 0 && skey[k] == skey[k - 1])
+			p = sval[k - 1] + 1;
+		prev[sval[k]] = p;
+	}
+}
+
+__global__ void __launch_bounds__(256) k_flag_heads(const uint32_t *__restrict__ skey, uint32_t n4, uint8_t *__restrict__ flags)
+{
+	uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t stride = gridDim.x * blockDim.x;
+	for (; k < n4; k += stride)
+		flags[k] = (k == 0 || skey[k] != skey[k - 1]) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256) k_seg_len(const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ nseg_p,
+						 uint32_t n4, uint32_t *__restrict__ seg_len)
+{
+	uint32_t nseg = *nseg_p;
+	uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t stride = gridDim.x * blockDim.x;
+	for (; s < nseg; s += stride)
+		seg_len[s] = (s + 1 < nseg ? seg_start[s + 1] : n4) - seg_start[s];
+}
+
+constexpr int kMaxRec = 128; // u32 entries per position: 2 * (2 hash pairs + cut (<= 48)) -> 100
+
+// One lane per hash bucket: replay the bucket's positions in order through the BT4 tree walk
+// (LzFindOpt.c GetMatchesSpecN_2 semantics), then the LZ-thread merge (MixMatches3).
+__global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint32_t n,
+					   const uint32_t *__restrict__ spos,
+					   const uint32_t *__restrict__ seg_len_sorted, const uint32_t *__restrict__ seg_start_sorted,
+					   const uint32_t *__restrict__ nseg_p,
+					   uint32_t *__restrict__ son,
+					   const uint32_t *__restrict__ prev2, const uint32_t *__restrict__ prev3,
+					   uint32_t dict, uint32_t fb, uint32_t cut,
+					   uint8_t *__restrict__ counts, uint64_t *__restrict__ tmp_start,
+					   uint32_t *__restrict__ pool, unsigned long long *__restrict__ cursor,
+					   unsigned long long pool_cap, int *__restrict__ err)
+{
+	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= *nseg_p)
+		return;
+	const uint32_t k0 = seg_start_sorted[g];
+	const uint32_t L = seg_len_sorted[g];
+	const uint32_t cyc_size = dict + 1;
+	uint32_t prev = 0; // 1-based position of the previous element of this bucket
+
+	for (uint32_t j = 0; j < L; j++) {
+		const uint32_t i = spos[k0 + j];
+		const uint32_t pos = i + 1;
+		const uint8_t *cur = src + i;
+		const uint32_t avail = n - i;
+		const uint32_t len_limit = avail < fb ? avail : fb;
+		const uint32_t cbs = pos < cyc_size ? pos : cyc_size;
+		uint32_t rec[kMaxRec];
+		uint32_t nrec = 0;
+		uint32_t delta = pos - prev; // prev == 0 -> delta == pos >= cbs -> empty
+
+		if (delta >= cbs) {
+			son[2 * (size_t)pos] = 0;
+			son[2 * (size_t)pos + 1] = 0;
+		} else {
+			uint32_t *ptr0 = son + 2 * (size_t)pos + 1, *ptr1 = son + 2 * (size_t)pos;
+			uint32_t len0 = 0, len1 = 0, max_len = 3, cv = cut;
+			for (;;) {
+				const uint32_t cur_match = pos - delta;
+				uint32_t *pair = son + 2 * (size_t)cur_match;
+				const uint8_t *pb = cur - delta;
+				uint32_t len = len0 < len1 ? len0 : len1;
+				const uint32_t pair0 = pair[0], pair1 = pair[1];
+				if (pb[len] == cur[len]) {
+					while (++len != len_limit)
+						if (pb[len] != cur[len])
+							break;
+					if (max_len < len) {
+						max_len = len;
+						rec[nrec++] = len;
+						rec[nrec++] = delta - 1;
+						if (len == len_limit) {
+							*ptr1 = pair0;
+							*ptr0 = pair1;
+							break;
+						}
+					}
+				}
+				uint32_t next;
+				if (pb[len] < cur[len]) {
+					*ptr1 = cur_match;
+					ptr1 = pair + 1;
+					len1 = len;
+					next = pair1;
+				} else {
+					*ptr0 = cur_match;
+					ptr0 = pair;
+					len0 = len;
+					next = pair0;
+				}
+				if (next >= cur_match) { // corrupt tree (cannot happen): stop like the reference
+					*err = 2;
+					*ptr0 = *ptr1 = 0;
+					break;
+				}
+				delta = pos - next;
+				if (--cv == 0 || delta >= cbs) {
+					*ptr0 = *ptr1 = 0;
+					break;
+				}
+			}
+		}
+		prev = pos;
+
+		// LZ-thread merge: MixMatches3 (h2/h3 candidates nearer than the first tree match)
+		uint32_t mix[4];
+		uint32_t nmix = 0;
+		{
+			const uint32_t min_pos = nrec ? pos - rec[1] : (pos > dict ? pos - dict : 1);
+			const uint32_t c2 = prev2[i], c3 = prev3[i];
+			bool done = false;
+			if (c2 >= min_pos && src[c2 - 1] == cur[0]) {
+				mix[1] = pos - c2 - 1;
+				if (src[c2 - 1 + 2] == cur[2]) {
+					mix[0] = 3;
+					done = true;
+				} else
+					mix[0] = 2;
+				nmix = 2;
+			}
+			if (!done && c3 >= min_pos && src[c3 - 1] == cur[0]) {
+				mix[nmix++] = 3;
+				mix[nmix++] = pos - c3 - 1;
+			}
+		}
+		const uint32_t cnt = nmix + nrec;
+		counts[i] = (uint8_t)cnt;
+		if (cnt) {
+			unsigned long long st = atomicAdd(cursor, (unsigned long long)cnt);
+			tmp_start[i] = st;
+			if (st + cnt > pool_cap) {
+				*err = 1;
+			} else {
+				uint32_t *o = pool + st;
+				for (uint32_t k = 0; k < nmix; k++)
+					o[k] = mix[k];
+				for (uint32_t k = 0; k < nrec; k++)
+					o[nmix + k] = rec[k];
+			}
+		}
+	}
+}
+
+struct CountToU64 {
+	__host__ __device__ unsigned long long operator()(const uint8_t &c) const { return (unsigned long long)c; }
+};
+
+__global__ void __launch_bounds__(256) k_gather(const uint8_t *__restrict__ counts, const uint64_t *__restrict__ tmp_start,
+						const unsigned long long *__restrict__ offsets, const uint32_t *__restrict__ pool,
+						uint32_t *__restrict__ out, uint32_t n, unsigned long long pool_cap)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t stride = gridDim.x * blockDim.x;
+	for (; i < n; i += stride) {
+		uint32_t c = counts[i];
+		if (!c || tmp_start[i] + c > pool_cap || offsets[i] + c > pool_cap)
+			continue;
+		const uint32_t *s = pool + tmp_start[i];
+		uint32_t *d = out + offsets[i];
+		for (uint32_t k = 0; k < c; k++)
+			d[k] = s[k];
+	}
+}
+
+__global__ void k_total(const uint8_t *counts, const unsigned long long *offsets, uint32_t n, unsigned long long *total)
+{
+	*total = n ? offsets[n - 1] + counts[n - 1] : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+
+int mf_workspace_create(MfWorkspace **out, size_t max_n, double pool_per_pos)
+{
+	MfWorkspace *w = (MfWorkspace *)calloc(1, sizeof(MfWorkspace));
+	if (!w)
+		return -1;
+	w->max_n = max_n;
+	w->pool_cap = (unsigned long long)((double)max_n * pool_per_pos) + 4096;
+	size_t n = max_n + 8;
+	HIPCHK(hipMalloc(&w->key_a, n * 4));
+	HIPCHK(hipMalloc(&w->key_b, n * 4));
+	HIPCHK(hipMalloc(&w->val_a, n * 4));
+	HIPCHK(hipMalloc(&w->val_b, n * 4));
+	HIPCHK(hipMalloc(&w->spos, n * 4));
+	HIPCHK(hipMalloc(&w->prev2, n * 4));
+	HIPCHK(hipMalloc(&w->prev3, n * 4));
+	HIPCHK(hipMalloc(&w->seg_start, n * 4));
+	HIPCHK(hipMalloc(&w->seg_len, n * 4));
+	HIPCHK(hipMalloc(&w->seg_start_s, n * 4));
+	HIPCHK(hipMalloc(&w->seg_len_s, n * 4));
+	HIPCHK(hipMalloc(&w->flags, n));
+	HIPCHK(hipMalloc(&w->son, (n + 1) * 8));
+	HIPCHK(hipMalloc(&w->counts, n));
+	HIPCHK(hipMalloc(&w->tmp_start, n * 8));
+	HIPCHK(hipMalloc(&w->offsets, n * 8));
+	HIPCHK(hipMalloc(&w->pool_tmp, w->pool_cap * 4));
+	HIPCHK(hipMalloc(&w->pool_out, w->pool_cap * 4));
+	HIPCHK(hipMalloc(&w->scalars, 64));
+	// temp storage: the largest request among the cub calls used below
+	size_t need = 0, t = 0;
+	(void)hipcub::DeviceRadixSort::SortPairs(nullptr, t, w->key_a, w->key_b, w->val_a, w->val_b, (int)max_n, 0, 32);
+	need = t;
+	(void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, t, w->key_a, w->key_b, w->val_a, w->val_b, (int)max_n, 0, 32);
+	if (t > need) need = t;
+	(void)hipcub::DeviceSelect::Flagged(nullptr, t, hipcub::CountingInputIterator<uint32_t>(0), w->flags, w->seg_start,
+				      (uint32_t *)w->scalars, (int)max_n);
+	if (t > need) need = t;
+	hipcub::TransformInputIterator<unsigned long long, CountToU64, const uint8_t *> it(w->counts, CountToU64());
+	(void)hipcub::DeviceScan::ExclusiveSum(nullptr, t, it, (unsigned long long *)w->offsets, (int)max_n);
+	if (t > need) need = t;
+	w->cub_bytes = need + 256;
+	HIPCHK(hipMalloc(&w->cub_tmp, w->cub_bytes));
+	*out = w;
+	return 0;
+}
+
+void mf_workspace_destroy(MfWorkspace *w)
+{
+	if (!w)
+		return;
+	void *ptrs[] = {w->key_a, w->key_b, w->val_a, w->val_b, w->spos, w->prev2, w->prev3, w->seg_start, w->seg_len,
+			w->seg_start_s, w->seg_len_s, w->flags, w->son, w->counts, w->tmp_start, w->offsets, w->pool_tmp,
+			w->pool_out, w->scalars, w->cub_tmp};
+	for (void *p : ptrs)
+		if (p)
+			(void)hipFree(p);
+	free(w);
+}
+
+static inline int grid_for(size_t n, int block) // ~8 blocks per CU, grid-stride beyond
+{
+	size_t g = (n + block - 1) / block;
+	if (g > 256 * 8)
+		g = 256 * 8;
+	if (g == 0)
+		g = 1;
+	return (int)g;
+}
+
+// Runs the finder on d_src[0..n) (device). Results stay on the device in w->counts / w->pool_out;
+// *total_entries receives the number of u32 entries.
+int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict, uint32_t fb, uint32_t cut,
+		  hipStream_t s, unsigned long long *total_entries)
+{
+	if (n > w->max_n || n >= 0xFFFFFFF0ull)
+		return -2;
+	if (2 * (cut + 2) > (uint32_t)kMaxRec || 2 * (cut + 2) > 255)
+		return -3;
+	unsigned long long *d_cursor = (unsigned long long *)w->scalars;      // [0]
+	unsigned long long *d_total = (unsigned long long *)w->scalars + 1;   // [1]
+	uint32_t *d_nseg = (uint32_t *)((unsigned long long *)w->scalars + 2); // [2]
+	int *d_err = (int *)((unsigned long long *)w->scalars + 3);           // [3]
+	HIPCHK(hipMemsetAsync(w->scalars, 0, 64, s));
+	*total_entries = 0;
+	if (n == 0)
+		return 0;
+	HIPCHK(hipMemsetAsync(w->counts, 0, n, s));
+	if (n >= 4) {
+		const uint32_t n4 = (uint32_t)(n - 3);
+		const uint32_t mask = lzma_hash_mask(dict, n);
+		const int big = mask >= 0xFFFFFF;
+		int bits = 32 - __builtin_clz(mask);
+		size_t tb;
+		const int g = grid_for(n4, 256);
+
+		// h2 table: previous position with the same 10-bit hash
+		hipLaunchKernelGGL(k_keys<2>, dim3(g), dim3(256), 0, s, d_src, n4, mask, big, w->key_a, w->val_a);
+		tb = w->cub_bytes;
+		HIPCHK(hipcub::DeviceRadixSort::SortPairs(w->cub_tmp, tb, w->key_a, w->key_b, w->val_a, w->val_b, (int)n4, 0, 10, s));
+		hipLaunchKernelGGL(k_link_prev, dim3(g), dim3(256), 0, s, w->key_b, w->val_b, n4, w->prev2);
+		// h3 table
+		hipLaunchKernelGGL(k_keys<3>, dim3(g), dim3(256), 0, s, d_src, n4, mask, big, w->key_a, w->val_a);
+		tb = w->cub_bytes;
+		HIPCHK(hipcub::DeviceRadixSort::SortPairs(w->cub_tmp, tb, w->key_a, w->key_b, w->val_a, w->val_b, (int)n4, 0, 16, s));
+		hipLaunchKernelGGL(k_link_prev, dim3(g), dim3(256), 0, s, w->key_b, w->val_b, n4, w->prev3);
+		// main hash: buckets
+		hipLaunchKernelGGL(k_keys<4>, dim3(g), dim3(256), 0, s, d_src, n4, mask, big, w->key_a, w->val_a);
+		tb = w->cub_bytes;
+		HIPCHK(hipcub::DeviceRadixSort::SortPairs(w->cub_tmp, tb, w->key_a, w->key_b, w->val_a, w->spos, (int)n4, 0, bits, s));
+		hipLaunchKernelGGL(k_flag_heads, dim3(g), dim3(256), 0, s, w->key_b, n4, w->flags);
+		tb = w->cub_bytes;
+		HIPCHK(hipcub::DeviceSelect::Flagged(w->cub_tmp, tb, hipcub::CountingInputIterator<uint32_t>(0), w->flags,
+						     w->seg_start, d_nseg, (int)n4, s));
+		hipLaunchKernelGGL(k_seg_len, dim3(g), dim3(256), 0, s, w->seg_start, d_nseg, n4, w->seg_len);
+		uint32_t nseg = 0;
+		HIPCHK(hipMemcpyAsync(&nseg, d_nseg, 4, hipMemcpyDeviceToHost, s));
+		HIPCHK(hipStreamSynchronize(s));
+		// longest buckets first
+		tb = w->cub_bytes;
+		HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(w->cub_tmp, tb, w->seg_len, w->seg_len_s, w->seg_start,
+								    w->seg_start_s, (int)nseg, 0, 32, s));
+		hipLaunchKernelGGL(k_bt, dim3((nseg + 63) / 64), dim3(64), 0, s, d_src, (uint32_t)n, w->spos, w->seg_len_s,
+				   w->seg_start_s, d_nseg, w->son, w->prev2, w->prev3, dict, fb, cut, w->counts, w->tmp_start,
+				   w->pool_tmp, d_cursor, w->pool_cap, d_err);
+	}
+	{
+		size_t tb = w->cub_bytes;
+		hipcub::TransformInputIterator<unsigned long long, CountToU64, const uint8_t *> it(w->counts, CountToU64());
+		HIPCHK(hipcub::DeviceScan::ExclusiveSum(w->cub_tmp, tb, it, (unsigned long long *)w->offsets, (int)n, s));
+		hipLaunchKernelGGL(k_gather, dim3(grid_for(n, 256)), dim3(256), 0, s, w->counts, w->tmp_start,
+				   (const unsigned long long *)w->offsets, w->pool_tmp, w->pool_out, (uint32_t)n, w->pool_cap);
+		hipLaunchKernelGGL(k_total, dim3(1), dim3(1), 0, s, w->counts, (const unsigned long long *)w->offsets, (uint32_t)n, d_total);
+	}
+	unsigned long long host_sc[4];
+	HIPCHK(hipMemcpyAsync(host_sc, w->scalars, 32, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	int err = (int)(host_sc[3] & 0xFFFFFFFFu);
+	if (err == 1)
+		return -4; // pool too small
+	if (err)
+		return -5;
+	*total_entries = host_sc[1];
+	return 0;
+}
+
+} // namespace lrzgpu

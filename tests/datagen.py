@@ -1,0 +1,63 @@
+"""Seeded synthetic inputs shared by the tests and bench.py (numpy, fast)."""
+import numpy as np
+
+
+def text_like(n, seed=1, nwords=5000):
+    """Word-list pseudo text (LZMA-compressible, few long repeats)."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(2, 10, size=nwords)
+    words = [bytes(rng.integers(97, 123, size=int(l), dtype=np.uint8)) + b" " for l in lens]
+    out = bytearray()
+    # draw in batches
+    while len(out) < n:
+        idx = rng.integers(0, nwords, size=65536)
+        out += b"".join(words[i] for i in idx)
+    return bytes(out[:n])
+
+
+def random_bytes(n, seed=2):
+    return np.random.default_rng(seed).integers(0, 256, size=n, dtype=np.uint8).tobytes()
+
+
+def few_symbols(n, seed=3, k=4):
+    return (np.random.default_rng(seed).integers(0, k, size=n, dtype=np.uint8) + 97).astype(np.uint8).tobytes()
+
+
+def phrase_mix(n, seed=4):
+    rng = np.random.default_rng(seed)
+    phrases = [rng.integers(0, 256, size=int(rng.integers(3, 41)), dtype=np.uint8).tobytes() for _ in range(50)]
+    out = bytearray()
+    while len(out) < n:
+        idx = rng.integers(0, 50, size=4096)
+        out += b"".join(phrases[i] for i in idx)
+    return bytes(out[:n])
+
+
+def sparse_repeats(n, seed=5):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 256, size=n, dtype=np.uint8)
+    if n > 16:
+        for _ in range(n // 500 + 1):
+            s, d = int(rng.integers(0, n)), int(rng.integers(0, n))
+            l = int(min(rng.integers(4, 301), n - s, n - d))
+            a[d:d + l] = a[s:s + l].copy()
+    return a.tobytes()
+
+
+def long_range(n, seed=6, base_frac=0.5, mutate_every=0):
+    """First base_frac of the buffer is text-like; the rest repeats it (optionally mutated)."""
+    nb = max(1, int(n * base_frac))
+    base = np.frombuffer(text_like(nb, seed), dtype=np.uint8)
+    reps = -(-n // nb)
+    a = np.tile(base, reps)[:n].copy()
+    if mutate_every:
+        rng = np.random.default_rng(seed + 100)
+        pos = np.arange(nb + mutate_every // 2, n, mutate_every)
+        a[pos] = rng.integers(0, 256, size=len(pos), dtype=np.uint8)
+    return a.tobytes()
+
+
+KINDS = {
+    "text": text_like, "random": random_bytes, "few": few_symbols, "phrases": phrase_mix,
+    "sparse": sparse_repeats, "zeros": lambda n, seed=0: bytes(n), "longrange": long_range,
+}

@@ -1,0 +1,99 @@
+"""GPU parity of the per-block backends (lz4 gate, LZMA match finder, LzmaCompress) through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import datagen
+
+pytestmark = pytest.mark.gpu
+
+SIZES_SMALL = [0, 1, 2, 3, 4, 5, 7, 12, 13, 31, 64, 100, 1000, 5000, 65535, 65546, 65547, 70000, 300000]
+
+
+def _lists_from_oracle(O, data, dict_size, fb, cut):
+    offs, pairs = O.mf_bt4(data, dict_size=dict_size, fb=fb, cut=cut)
+    counts = np.diff(offs).astype(np.uint8)
+    return counts, pairs
+
+
+@pytest.mark.parametrize("kind", ["text", "random", "few", "phrases", "sparse", "zeros"])
+def test_match_lists_equal_oracle(B, O, kind):
+    for n in SIZES_SMALL + [1500000]:
+        data = datagen.KINDS[kind](n, seed=n % 97 + 1)
+        for dict_size, fb in ((1 << 25, 64), (1 << 24, 32)):
+            cut = 16 + fb // 2
+            oc, op = _lists_from_oracle(O, data, dict_size, fb, cut)
+            gc, gp = B.lzma_match_lists(data, dict_size=dict_size, fb=fb, cut=cut, per_pos=110)
+            assert np.array_equal(gc, oc), (kind, n, dict_size)
+            assert np.array_equal(gp, op), (kind, n, dict_size)
+
+
+def test_match_lists_small_dict_window(B, O):
+    # dictionary smaller than the block: exercises the delta >= cyclicBufferSize cut-off
+    data = datagen.phrase_mix(400000, seed=9)
+    for dict_size in (1 << 16, 1 << 12):
+        oc, op = _lists_from_oracle(O, data, dict_size, 64, 48)
+        gc, gp = B.lzma_match_lists(data, dict_size=dict_size, fb=64, cut=48, per_pos=110)
+        assert np.array_equal(gc, oc) and np.array_equal(gp, op)
+
+
+@pytest.mark.parametrize("kind", ["text", "random", "few", "phrases", "sparse", "zeros"])
+def test_lzma_compress_equals_reference(B, O, kind):
+    """lrzgpu_LzmaCompress (GPU finder + host parser) == the reference's own LzmaCompress, bit for bit."""
+    if O.ref_lzma() is None:
+        pytest.skip("oracle/_ref/liblzma_ref.so not present")
+    for n in [0, 1, 5, 100, 5000, 70000, 1200000]:
+        data = datagen.KINDS[kind](n, seed=n % 89 + 3)
+        for level, dict_size, fb in ((7, 1 << 25, 64), (5, 1 << 24, 32), (9, 1 << 27, 64)):
+            rc_r, ref, props_r = O.lzma_compress_ref(data, level=level, dict_size=dict_size, fb=fb, threads=2)
+            rc_g, got, props_g = B.lzma_compress(data, level=level, dict_size=dict_size, fb=fb)
+            assert rc_g == rc_r and props_g == props_r, (kind, n, level)
+            assert got == ref, (kind, n, level, len(got), len(ref))
+
+
+def test_lzma_bighash_regime(B, O):
+    """Blocks above 16 MiB switch the reference to GetHeads4b (hashMask 0xFFFFFF)."""
+    if O.ref_lzma() is None:
+        pytest.skip("oracle/_ref/liblzma_ref.so not present")
+    data = datagen.long_range(17 * 1048576 + 12345, seed=11, base_frac=0.8)
+    assert O.lib().lrzo_lzma_hash_mask(1 << 25, len(data)) == 0xFFFFFF
+    rc_r, ref, _ = O.lzma_compress_ref(data, level=7, dict_size=1 << 25, fb=64, threads=2)
+    rc_g, got, _ = B.lzma_compress(data, level=7, dict_size=1 << 25, fb=64)
+    assert rc_g == rc_r == 0 and got == ref
+    rc, back = O.lzma_uncompress_ref(got, bytes([0x5D, 0, 0, 0, 2]), len(data))
+    assert back == data
+
+
+def test_lzma_output_eof(B, O):
+    data = datagen.random_bytes(100000, seed=5)
+    rc_r, _, _ = O.lzma_compress_ref(data, level=7)
+    # capacity below the stream size -> SZ_ERROR_OUTPUT_EOF (7), as lzma_compress_buf relies on
+    rc_g, got, _ = B.lzma_compress(data, level=7, cap=50000)
+    assert rc_g == 7
+
+
+def test_lz4_size_equals_liblz4_and_oracle(B, O):
+    try:
+        lz4 = C.CDLL("liblz4.so.1")
+        lz4.LZ4_compress_default.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+    except OSError:
+        lz4 = None
+    for kind in ["text", "random", "few", "phrases", "sparse", "zeros"]:
+        for n in SIZES_SMALL + [2000001]:
+            data = datagen.KINDS[kind](n, seed=n % 31 + 2)
+            for cap in (n + 1, n, n // 2, n + n // 255 + 16):
+                want = O.lib().lrzo_lz4_compress_default_size(data, n, cap)
+                got = B.lib().lrzgpu_lz4_compress_default_size(data, n, cap, 0)
+                assert got == want, (kind, n, cap)
+                if lz4 is not None:
+                    dst = C.create_string_buffer(max(cap, 1))
+                    assert lz4.LZ4_compress_default(data, dst, n, cap) == want, (kind, n, cap)
+
+
+def test_lz4_gate_decision(B, O):
+    for kind in ["text", "random", "few", "zeros"]:
+        for n in (64, 4096, 300000):
+            data = datagen.KINDS[kind](n, seed=7)
+            for thr in (100, 90, 50):
+                assert B.lib().lrzgpu_lz4_compresses(data, n, thr, 0) == O.lib().lrzo_lz4_compresses(data, n, thr)
