@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- compress MB/s (input) at -L7 lzma on MI355X, with roofline and CPU baseline.
+
+A "step" = one complete pass of the hot path (rzip scan + lz4 gate + LZMA match finder on the GPU,
+LZMA parser/range coder on host threads, container assembly) over one synthetic buffer that is
+already resident in HBM when the timed region starts.
+
+N=1 workload = BASELINE.json configs[1]: 4 GiB synthetic 50 %-long-range-redundant buffer
+(2 GiB seeded word-list text followed by an identical copy), -L7 lzma, single rzip chunk.
+N>1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank compresses its own
+buffer of that shape -- independent rzip chunks, no data-path collective (weak scaling); the only
+collectives are the bracketing barriers and the MAX-reduce of the elapsed time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import importlib.util
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def load_bindings():
+    name = "lrzip_next_amd_bindings"
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "lrzip-next_amd", "bindings.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class Profile(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("tag_scan_ms", "resolve_ms", "crc_ms", "gather_ms", "lz4_ms", "mf_bt_ms",
+                                           "mf_total_ms")] + \
+               [(n, C.c_int64) for n in ("tag_scan_launches", "resolve_launches", "crc_launches", "gather_launches",
+                                          "lz4_launches", "mf_launches", "tag_scan_positions", "resolve_lookups",
+                                          "resolve_inserts", "resolve_match_bytes", "crc_bytes", "gather_bytes",
+                                          "lz4_bytes", "mf_positions", "mf_entries")] + \
+               [("scan_wall_ms", C.c_double)]
+
+
+def text_like_torch(n, seed, device, piece=256 << 20):
+    """Seeded word-list pseudo text (5000 lowercase words of 2..9 letters, space separated)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    nwords = 5000
+    wl = torch.randint(2, 10, (nwords,), generator=g, device=device)
+    chars = torch.randint(97, 123, (nwords, 10), generator=g, device=device, dtype=torch.uint8)
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    done = 0
+    while done < n:
+        want = min(piece, n - done)
+        m = want // 6 + 4096  # mean word+space is 6.5 bytes
+        idx = torch.randint(0, nwords, (m,), generator=g, device=device)
+        lens = wl[idx] + 1
+        off = torch.cumsum(lens, 0) - lens
+        total = int(off[-1] + lens[-1])
+        buf = torch.full((total,), 32, dtype=torch.uint8, device=device)
+        for j in range(9):
+            sel = (lens - 1) > j
+            buf[off[sel] + j] = chars[idx[sel], j]
+        take = min(want, total)
+        out[done:done + take] = buf[:take]
+        done += take
+        del idx, lens, off, buf
+    return out
+
+
+def make_workload(n_bytes, seed, device):
+    """50 % long-range redundant: first half seeded text, second half an identical copy."""
+    import torch
+    half = n_bytes // 2
+    base = text_like_torch(half, seed, device)
+    buf = torch.empty(n_bytes + 256, dtype=torch.uint8, device=device)  # 256 B of readable padding
+    buf[:half] = base
+    buf[half:2 * half] = base
+    buf[2 * half:] = 0
+    return buf
+
+
+def cpu_baseline(sample_bytes, ctl_kw, cores):
+    """Oracle driver (CPU restatement of rzip/lz4/container + the reference's own LZMA build) on a
+    bounded sample of the same workload shape, all host cores as block-compression workers."""
+    import oracle_lib as O
+    import torch
+    O.build()
+    if O.ref_lzma() is None:
+        return None
+    data = bytes(make_workload(sample_bytes, 1, "cpu")[:sample_bytes].numpy())
+    t0 = time.time()
+    out, fs = O.compress_buffer(data, compression_level=ctl_kw["level"], threads=ctl_kw["threads"],
+                                processors=ctl_kw["processors"], ramsize=ctl_kw["ramsize"], workers=cores)
+    dt = time.time() - t0
+    return {"value": round(sample_bytes / 1048576 / dt, 2), "unit": "MB/s", "cores": cores, "kind": "port",
+            "sample": "%d MiB of the same shape (half seeded text + identical copy), -L7, oracle rzip/lz4/container "
+                      "restatement + oracle/_ref LzmaCompress (reference LZMA sources, numThreads=2) on %d worker "
+                      "threads; %.1f s; %d blocks of %d B" % (sample_bytes >> 20, cores, dt, fs.n_blocks, fs.stream_bufsize),
+            "seconds": round(dt, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--mib", type=int, default=int(os.environ.get("LRZGPU_BENCH_MIB", "4096")),
+                    help="workload size per GPU in MiB (default: the 4 GiB configuration)")
+    ap.add_argument("--cpu-sample-mib", type=int, default=int(os.environ.get("LRZGPU_CPU_SAMPLE_MIB", "128")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--threads", type=int, default=0, help="-p (default: host cores)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    B = load_bindings()
+    L = B.lib()
+    L.lrzgpu_profile_get.argtypes = [C.POINTER(Profile)]
+    if L.lrzgpu_device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: liblrzgpu has no CPU fallback")
+
+    cores = os.cpu_count() or 1
+    threads = args.threads or max(1, cores // world)
+    phys = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    ctl_kw = dict(level=7, threads=threads, processors=cores, ramsize=phys)
+    n_bytes = args.mib << 20
+
+    buf = make_workload(n_bytes, 1 + rank, dev)
+    torch.cuda.synchronize()
+
+    def one_step():
+        ctl = B.make_control(device=local_rank, host_threads=threads, gpu_slots=4, **ctl_kw)
+        out, ctl = B.compress_device(buf.data_ptr(), n_bytes, ctl=ctl)
+        return out, ctl
+
+    for _ in range(args.warmup):
+        one_step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    L.lrzgpu_profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    out = ctl = None
+    for _ in range(args.steps):
+        out, ctl = one_step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    prof = Profile()
+    L.lrzgpu_profile_get(C.byref(prof))
+
+    if rank == 0:
+        total_mib = args.steps * world * (n_bytes / 1048576)
+        value = total_mib / dt
+        # dominant kernel by accumulated device time
+        kernels = {
+            "k_resolve": (prof.resolve_ms, prof.resolve_launches,
+                          16 * (prof.resolve_lookups + prof.resolve_inserts) + 2 * prof.resolve_match_bytes),
+            "k_bt": (prof.mf_bt_ms, prof.mf_launches, 13 * prof.mf_positions),
+            "k_tag_scan": (prof.tag_scan_ms, prof.tag_scan_launches, prof.tag_scan_positions),
+            "k_lz4_size": (prof.lz4_ms, prof.lz4_launches, prof.lz4_bytes),
+            "k_crc32_tiles": (prof.crc_ms, prof.crc_launches, prof.crc_bytes),
+            "k_gather_runs": (prof.gather_ms, prof.gather_launches, 2 * prof.gather_bytes),
+        }
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        ms, launches, alg_bytes = kernels[dom]
+        avg_ms = ms / max(launches, 1)
+        achieved = (alg_bytes / max(launches, 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(achieved / 8000.0, 6), "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 3), "launches": int(launches),
+                    "algorithmic_bytes_per_launch": int(alg_bytes / max(launches, 1)),
+                    "per_kernel_ms": {k: round(v[0], 2) for k, v in kernels.items()},
+                    "per_kernel_GBps": {k: (round(v[2] / (v[0] * 1e-3) / 1e9, 3) if v[0] > 0 else 0.0)
+                                        for k, v in kernels.items()},
+                    "scan_wall_ms": round(prof.scan_wall_ms, 1)}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(min(args.cpu_sample_mib << 20, n_bytes), ctl_kw, cores)
+        line = {
+            "metric": "compress MB/s (input) at -L7 lzma", "value": round(value, 2), "unit": "MB/s (2^20 B/s)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1000 / args.steps, 1),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%d MiB synthetic 50%%-long-range-redundant buffer (seeded word-list text + identical "
+                                   "copy), -L7 lzma, single rzip chunk per GPU, input resident in HBM" % args.mib,
+                       "flags": "-L7 -p%d (PROCESSORS=%d, ramsize=%d)" % (threads, cores, phys),
+                       "stream_bufsize": int(ctl.stream_bufsize), "dict_size": int(ctl.dictSize_used),
+                       "output_bytes": len(out), "host_threads": threads, "parallelism": "chunk-per-gpu x%d" % world},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

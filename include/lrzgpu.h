@@ -125,6 +125,35 @@ int lrzgpu_lzma_encode_with_lists(unsigned char *dest, size_t *destLen, const un
 				  const uint8_t *counts, const uint32_t *pairs, int level, unsigned dictSize,
 				  int lc, int lp, int pb, int fb);
 
+/* ---- host-only pieces of the stream layer (usable without a device) ----------------------------
+ * lrzgpu_plan: the sizing open_stream_out()/rzip_fd() derive before the first chunk
+ * (src/stream.c:1169-1331, src/rzip.c:999-1020); fills stream_bufsize, dictSize_used, threads_used.
+ * lrzgpu_container_store: lays out a .lrz from ready-made rzip streams with every block stored
+ * (CTYPE_NONE), i.e. what compthread writes under -n (src/stream.c:1716-1821) plus write_magic. */
+int lrzgpu_plan(lrzgpu_control *control, int64_t st_size, int64_t *chunk_size);
+int lrzgpu_container_store(lrzgpu_control *control, int64_t st_size, int n_chunks, const int64_t *chunk_sizes,
+			   const uint8_t *const *stream0, const int64_t *stream0_len,
+			   const uint8_t *const *stream1, const int64_t *stream1_len, const uint8_t md5[16],
+			   uint8_t **out, int64_t *out_len);
+
+/* ---- measurement --------------------------------------------------------------------------------
+ * Per-kernel durations measured with HIP events on the stream each kernel is launched on, summed
+ * over launches since the last reset, plus the algorithmic work counters they processed. */
+typedef struct lrzgpu_profile {
+	double tag_scan_ms, resolve_ms, crc_ms, gather_ms, lz4_ms, mf_bt_ms, mf_total_ms;
+	int64_t tag_scan_launches, resolve_launches, crc_launches, gather_launches, lz4_launches, mf_launches;
+	int64_t tag_scan_positions;   /* positions tagged by k_tag_scan                       */
+	int64_t resolve_lookups;      /* candidates probed by k_resolve                       */
+	int64_t resolve_inserts;
+	int64_t resolve_match_bytes;  /* bytes covered by emitted matches (verified both sides) */
+	int64_t crc_bytes, gather_bytes, lz4_bytes;
+	int64_t mf_positions;         /* block bytes through the match finder                 */
+	int64_t mf_entries;           /* u32 match-list entries produced                      */
+	double scan_wall_ms;          /* host wall time inside scan_chunk_device              */
+} lrzgpu_profile;
+void lrzgpu_profile_reset(void);
+void lrzgpu_profile_get(lrzgpu_profile *out);
+
 /* ---- misc ------------------------------------------------------------------------------------- */
 int lrzgpu_device_count(void);
 const char *lrzgpu_version(void);

@@ -51,8 +51,52 @@ def lib():
         L.lrzgpu_LzmaCompress.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t, C.c_void_p,
                                           C.POINTER(C.c_size_t), C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_int]
+        L.lrzgpu_hash_search.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64),
+                                         C.POINTER(C.POINTER(C.c_ubyte)), C.POINTER(C.c_int64), C.c_void_p,
+                                         C.POINTER(C.c_int64), C.POINTER(C.c_uint32), C.POINTER(ScanStats), C.c_int]
+        L.lrzgpu_hash_index.argtypes = [C.POINTER(C.c_uint64)]
+        L.lrzgpu_control_init.argtypes = [C.POINTER(Control)]
+        L.lrzgpu_compress_buffer.argtypes = [C.POINTER(Control), C.c_char_p, C.c_int64,
+                                             C.POINTER(C.POINTER(C.c_ubyte)), C.POINTER(C.c_int64)]
+        L.lrzgpu_compress_buffer_dev.argtypes = [C.POINTER(Control), C.c_void_p, C.c_int64,
+                                                 C.POINTER(C.POINTER(C.c_ubyte)), C.POINTER(C.c_int64)]
+        L.lrzgpu_compress_file.argtypes = [C.POINTER(Control), C.c_int, C.c_int]
+        L.lrzgpu_rzip_fd.argtypes = [C.POINTER(Control), C.c_int, C.c_int]
+        L.lrzgpu_plan.argtypes = [C.POINTER(Control), C.c_int64, C.POINTER(C.c_int64)]
+        L.lrzgpu_container_store.argtypes = [C.POINTER(Control), C.c_int64, C.c_int, C.POINTER(C.c_int64),
+                                             C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_char_p),
+                                             C.POINTER(C.c_int64), C.c_char_p, C.POINTER(C.POINTER(C.c_ubyte)),
+                                             C.POINTER(C.c_int64)]
         _lib = L
     return _lib
+
+
+def chunk_bytes_for(n):
+    bits = 8
+    while n >> bits > 0:
+        bits += 1
+    return bits // 8 + (1 if bits % 8 else 0)
+
+
+def hash_search(data: bytes, level=7, chunk_bytes=None, victim_round=0, device=0):
+    """One rzip chunk through the GPU scan -> (stream0, stream1, stats, crc, victim_round_out)."""
+    n = len(data)
+    if chunk_bytes is None:
+        chunk_bytes = chunk_bytes_for(n)
+    s0 = C.POINTER(C.c_ubyte)()
+    s0len = C.c_int64()
+    s1 = C.create_string_buffer(max(n, 1))
+    s1len = C.c_int64()
+    crc = C.c_uint32()
+    st = ScanStats()
+    vr = C.c_int64(victim_round)
+    rc = lib().lrzgpu_hash_search(data, n, level, chunk_bytes, C.byref(vr), C.byref(s0), C.byref(s0len), s1,
+                                  C.byref(s1len), C.byref(crc), C.byref(st), device)
+    if rc != 0:
+        raise RuntimeError("lrzgpu_hash_search rc=%d" % rc)
+    stream0 = C.string_at(s0, s0len.value)
+    C.CDLL(None).free(s0)
+    return stream0, s1.raw[:s1len.value], st, crc.value, vr.value
 
 
 def lzma_match_lists(data: bytes, dict_size=1 << 25, fb=64, cut=48, device=0, per_pos=16):
@@ -96,3 +140,78 @@ def lzma_compress(data: bytes, level=7, dict_size=1 << 25, fb=64, lc=3, lp=0, pb
     rc = lib().lrzgpu_LzmaCompress(dst, C.byref(dlen), data, n, props, C.byref(plen), level, dict_size, lc, lp, pb,
                                    fb, threads)
     return rc, dst.raw[:dlen.value], props.raw
+
+
+def make_control(level=7, rzip_level=0, threads=1, processors=1, ramsize=80 * 100 * 1048576, window=0, dict_size=0,
+                 no_compress=False, lz4_test=True, threshold=100, nobemt=False, device=0, host_threads=0,
+                 gpu_slots=0, verbose=0):
+    c = Control()
+    lib().lrzgpu_control_init(C.byref(c))
+    c.compression_level = level
+    c.rzip_compression_level = rzip_level
+    c.threads = threads
+    c.processors = processors
+    c.ramsize = ramsize
+    c.window = window
+    c.dictSize = dict_size
+    c.flags = (FLAG_NO_COMPRESS if no_compress else 0) | (FLAG_THRESHOLD if lz4_test else 0) | \
+              (FLAG_NOBEMT if nobemt else 0)
+    c.threshold = threshold
+    c.device = device
+    c.host_threads = host_threads
+    c.gpu_slots = gpu_slots
+    c.verbose = verbose
+    return c
+
+
+def _take(out, olen):
+    res = C.string_at(out, olen.value)
+    C.CDLL(None).free(out)
+    return res
+
+
+def compress_buffer(data: bytes, **kw):
+    """Whole-file compress of a host buffer -> (.lrz bytes, Control)."""
+    c = make_control(**kw)
+    out = C.POINTER(C.c_ubyte)()
+    olen = C.c_int64()
+    rc = lib().lrzgpu_compress_buffer(C.byref(c), data, len(data), C.byref(out), C.byref(olen))
+    if rc != 0:
+        raise RuntimeError("lrzgpu_compress_buffer rc=%d" % rc)
+    return _take(out, olen), c
+
+
+def compress_device(ptr: int, n: int, ctl=None, **kw):
+    """Whole-file compress of a buffer resident in HBM (ptr = device address) -> (.lrz bytes, Control)."""
+    c = ctl if ctl is not None else make_control(**kw)
+    out = C.POINTER(C.c_ubyte)()
+    olen = C.c_int64()
+    rc = lib().lrzgpu_compress_buffer_dev(C.byref(c), C.c_void_p(ptr), n, C.byref(out), C.byref(olen))
+    if rc != 0:
+        raise RuntimeError("lrzgpu_compress_buffer_dev rc=%d" % rc)
+    return _take(out, olen), c
+
+
+def plan(st_size, **kw):
+    c = make_control(**kw)
+    chunk = C.c_int64()
+    rc = lib().lrzgpu_plan(C.byref(c), st_size, C.byref(chunk))
+    if rc != 0:
+        raise RuntimeError("lrzgpu_plan rc=%d" % rc)
+    return c, chunk.value
+
+
+def container_store(st_size, chunk_sizes, streams0, streams1, md5, **kw):
+    c = make_control(**kw)
+    n = len(chunk_sizes)
+    cs = (C.c_int64 * n)(*chunk_sizes)
+    s0 = (C.c_char_p * n)(*streams0)
+    s0l = (C.c_int64 * n)(*[len(x) for x in streams0])
+    s1 = (C.c_char_p * n)(*streams1)
+    s1l = (C.c_int64 * n)(*[len(x) for x in streams1])
+    out = C.POINTER(C.c_ubyte)()
+    olen = C.c_int64()
+    rc = lib().lrzgpu_container_store(C.byref(c), st_size, n, cs, s0, s0l, s1, s1l, md5, C.byref(out), C.byref(olen))
+    if rc != 0:
+        raise RuntimeError("lrzgpu_container_store rc=%d" % rc)
+    return _take(out, olen)

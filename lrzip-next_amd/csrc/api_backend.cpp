@@ -13,6 +13,7 @@
 #include "lz4_gate.h"
 #include "lzma_enc.h"
 #include "lzma_mf.h"
+#include "profile.h"
 
 using namespace lrzgpu;
 
@@ -236,4 +237,18 @@ extern "C" int lrzgpu_LzmaCompress(unsigned char *dest, size_t *destLen, const u
 		return r;
 	}
 	return LZ_ERROR_MEM;
+}
+
+extern "C" void lrzgpu_profile_reset(void)
+{
+	ProfileStore &ps = ProfileStore::get();
+	std::lock_guard<std::mutex> lk(ps.mu);
+	memset(&ps.p, 0, sizeof(ps.p));
+}
+
+extern "C" void lrzgpu_profile_get(lrzgpu_profile *out)
+{
+	ProfileStore &ps = ProfileStore::get();
+	std::lock_guard<std::mutex> lk(ps.mu);
+	*out = ps.p;
 }

@@ -25,6 +25,7 @@
 #include <cstring>
 
 #include "lzma_mf.h"
+#include "profile.h"
 
 namespace lrzgpu {
 
@@ -339,6 +340,8 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 	unsigned long long *d_total = (unsigned long long *)w->scalars + 1;   // [1]
 	uint32_t *d_nseg = (uint32_t *)((unsigned long long *)w->scalars + 2); // [2]
 	int *d_err = (int *)((unsigned long long *)w->scalars + 3);           // [3]
+	EventTimer t_all(s);
+	EventTimer *t_bt = nullptr;
 	HIPCHK(hipMemsetAsync(w->scalars, 0, 64, s));
 	*total_entries = 0;
 	if (n == 0)
@@ -378,9 +381,11 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 		tb = w->cub_bytes;
 		HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(w->cub_tmp, tb, w->seg_len, w->seg_len_s, w->seg_start,
 								    w->seg_start_s, (int)nseg, 0, 32, s));
+		t_bt = new EventTimer(s);
 		hipLaunchKernelGGL(k_bt, dim3((nseg + 63) / 64), dim3(64), 0, s, d_src, (uint32_t)n, w->spos, w->seg_len_s,
 				   w->seg_start_s, d_nseg, w->son, w->prev2, w->prev3, dict, fb, cut, w->counts, w->tmp_start,
 				   w->pool_tmp, d_cursor, w->pool_cap, d_err);
+		t_bt->stop();
 	}
 	{
 		size_t tb = w->cub_bytes;
@@ -390,9 +395,21 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 				   (const unsigned long long *)w->offsets, w->pool_tmp, w->pool_out, (uint32_t)n, w->pool_cap);
 		hipLaunchKernelGGL(k_total, dim3(1), dim3(1), 0, s, w->counts, (const unsigned long long *)w->offsets, (uint32_t)n, d_total);
 	}
+	t_all.stop();
 	unsigned long long host_sc[4];
 	HIPCHK(hipMemcpyAsync(host_sc, w->scalars, 32, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
+	{
+		ProfileStore &ps = ProfileStore::get();
+		std::lock_guard<std::mutex> lk(ps.mu);
+		ps.p.mf_total_ms += t_all.ms();
+		if (t_bt)
+			ps.p.mf_bt_ms += t_bt->ms();
+		ps.p.mf_launches++;
+		ps.p.mf_positions += (int64_t)n;
+		ps.p.mf_entries += (int64_t)host_sc[1];
+	}
+	delete t_bt;
 	int err = (int)(host_sc[3] & 0xFFFFFFFFu);
 	if (err == 1)
 		return -4; // pool too small

@@ -1,0 +1,77 @@
+// rzip_scan.h -- device-side rzip long-range preprocessor (see rzip_scan.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+namespace lrzgpu {
+
+struct MatchRec {
+	int64_t p, ofs, len; // match at chunk offset p copies `len` bytes from chunk offset `ofs`
+};
+
+// Resolver state, resident in device memory for the lifetime of one chunk scan
+// (the automaton state of reference src/rzip.c:586-705 hash_search + struct rzip_state).
+struct ScanState {
+	// constants of the chunk
+	int64_t chunk_size, end;
+	int32_t hash_bits;
+	uint32_t max_chain_len;
+	int64_t hash_limit;
+	// automaton
+	int64_t p_skip;     // candidates at positions <= p_skip are not examined
+	int64_t last_match;
+	int64_t cur_p, cur_ofs, cur_len;
+	uint64_t tag_mask, min_mask;
+	int64_t hash_count, clean_ptr, victim_round;
+	// outputs
+	int64_t n_records, rec_cap;
+	int32_t error; // 1 = record buffer full, 2 = internal
+	int32_t pad;
+	// statistics (reference st->stats)
+	int64_t inserts, lookups, tag_hits, tag_misses;
+	uint64_t sink; // keeps prefetch loads alive
+};
+
+struct ScanWorkspace {
+	int hash_bits;
+	void *table;       // 16 B slots
+	ScanState *state;  // device
+	uint64_t *hx;      // device copy of hash_index[256]
+	uint32_t *cand_rel;
+	uint64_t *cand_tag;
+	uint32_t *tile_count;
+	size_t seg_cap;    // positions per segment the candidate arrays can hold
+	MatchRec *records;
+	int64_t rec_cap;
+	uint32_t *crc_partial;
+	size_t crc_cap;
+};
+
+struct ScanResult {
+	std::vector<MatchRec> records;
+	uint32_t crc;
+	ScanState final_state;
+};
+
+int scan_workspace_create(ScanWorkspace **out, int rzip_level, int64_t max_chunk);
+void scan_workspace_destroy(ScanWorkspace *w);
+
+// Scans d_chunk[0..chunk_size) (device). victim_round in/out.
+int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_size, int rzip_level,
+		      int64_t *victim_round, ScanResult *res, hipStream_t s);
+
+// literal gather: dst[dst_off + k] = src[src_off + k] for each run (device pointers)
+struct CopyRun {
+	int64_t src_off, dst_off, len;
+};
+int gather_runs_device(const uint8_t *d_src, uint8_t *d_dst, const CopyRun *d_runs, int nruns, int64_t total_len, hipStream_t s);
+
+// CRC-32/IEEE of a device buffer
+int crc32_device(ScanWorkspace *w, const uint8_t *d_buf, int64_t n, uint32_t *crc, hipStream_t s);
+
+void hash_index_table(uint64_t out[256]);
+void rzip_level_params(int level, unsigned *mb_used, unsigned *initial_freq, unsigned *max_chain_len);
+
+} // namespace lrzgpu

@@ -1,0 +1,1015 @@
+// rzip_scan.hip -- the rzip long-range-match preprocessor on MI355X (gfx950).
+//
+// Reference: src/rzip.c hash_search (586-762) with insert_hash (304-353), clean_one_from_hash
+// (357-383), find_best_match (495-534), single_match_len (431-461), tags (385-416).
+// The reference is one CPU loop over every byte.  Here the work is split by what is and is not
+// order-dependent:
+//
+//   K1 k_tag_scan      all CUs.  Rolling 31-byte XOR tags for every position of a segment from an
+//                      LDS-staged byte tile (coalesced 16 B HBM reads), filtered by the resolver's
+//                      CURRENT minimum tag mask (masks only ever gain bits, so the filter yields a
+//                      superset of every later lookup/insert), compacted in position order with a
+//                      workgroup prefix sum.  HBM-bound: 1 B read per position.
+//   K2 k_resolve       one wavefront.  The exact hash-table automaton over the candidates:
+//                      a probe is ONE 64-slot (1 KiB) coalesced window load + wave ballots
+//                      (empty / tag-equal / min-bitness / lesser-bitness) instead of a slot-by-slot
+//                      pointer walk; insert displacement uses an explicit LDS stack; the clean
+//                      sweep is a ballot+ffs over the window at tag_clean_ptr; match verification
+//                      is a 64-lane wide compare (512 B per step, 16 KiB per step once a match is
+//                      long).  Upcoming candidates' bucket windows are prefetched a batch ahead.
+//                      Latency-bound by design (serial table state); bit-exact by construction.
+//   K4 k_gather_runs   all CUs.  Materialises stream 1 (literal bytes) from the run table.
+//   K5 k_crc32_tiles   all CUs.  CRC-32 of the chunk, 64 KiB tiles combined with GF(2) shifts.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include <chrono>
+
+#include "profile.h"
+#include "rzip_scan.h"
+
+namespace lrzgpu {
+
+#define HIPCHK(x)                                                                              \
+	do {                                                                                   \
+		hipError_t e_ = (x);                                                           \
+		if (e_ != hipSuccess) {                                                        \
+			fprintf(stderr, "lrzgpu: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+			return -1;                                                             \
+		}                                                                              \
+	} while (0)
+
+constexpr int MINIMUM_MATCH = 31; // src/rzip.c:51
+constexpr int GREAT_MATCH = 1024; // src/rzip.c:50
+constexpr int TILE = 4096;        // positions per K1 workgroup
+constexpr int PER_THREAD = 16;
+
+typedef unsigned long long u64;
+typedef long long i64;
+
+struct __attribute__((aligned(16))) Slot {
+	i64 offset;
+	u64 t;
+};
+
+struct __attribute__((packed, aligned(1))) U64u {
+	u64 v;
+};
+struct __attribute__((packed, aligned(1))) U128u {
+	u64 a, b;
+};
+
+void rzip_level_params(int level, unsigned *mb_used, unsigned *initial_freq, unsigned *max_chain_len)
+{
+	// src/rzip.c:67-82
+	static const unsigned L[10][3] = {{1, 4, 1}, {2, 4, 2}, {4, 4, 2}, {8, 4, 2}, {16, 4, 3},
+					  {32, 4, 4}, {32, 2, 6}, {64, 1, 16}, {64, 1, 32}, {64, 1, 128}};
+	if (level < 0) level = 0;
+	if (level > 9) level = 9;
+	*mb_used = L[level][0];
+	*initial_freq = L[level][1];
+	*max_chain_len = L[level][2];
+}
+
+void hash_index_table(uint64_t out[256])
+{
+	// src/rzip.c:765-771: hash_index[i] = (random() << 16) ^ random() with glibc's default-seeded
+	// TYPE_3 additive feedback generator (the reference never seeds it). Frozen here so the table
+	// does not depend on libc or on other random() users in the process.
+	static int32_t r[34 + 310 + 512];
+	r[0] = 1;
+	for (int i = 1; i < 31; i++) {
+		long hi = r[i - 1] / 127773, lo = r[i - 1] % 127773;
+		long w = 16807 * lo - 2836 * hi;
+		if (w < 0)
+			w += 2147483647;
+		r[i] = (int32_t)w;
+	}
+	for (int i = 31; i < 34; i++)
+		r[i] = r[i - 31];
+	for (int i = 34; i < 34 + 310 + 512; i++)
+		r[i] = (int32_t)((uint32_t)r[i - 31] + (uint32_t)r[i - 3]);
+	int k = 0;
+	for (int i = 0; i < 256; i++) {
+		uint64_t a = ((uint32_t)r[344 + k++]) >> 1;
+		uint64_t b = ((uint32_t)r[344 + k++]) >> 1;
+		out[i] = (a << 16) ^ b;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: tags + candidate compaction
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_tag_scan(const uint8_t *__restrict__ buf, i64 seg_lo, i64 seg_hi,
+						  const u64 *__restrict__ hx_g, const ScanState *__restrict__ st,
+						  uint32_t *__restrict__ cand_rel, u64 *__restrict__ cand_tag,
+						  uint32_t *__restrict__ tile_count)
+{
+	__shared__ u64 hx[256];
+	__shared__ __attribute__((aligned(16))) uint8_t stage[TILE + 64];
+	__shared__ uint32_t wave_tot[4];
+
+	const int tid = threadIdx.x;
+	const i64 p0 = seg_lo + (i64)blockIdx.x * TILE;
+	const u64 min_mask = st->min_mask;
+	hx[tid] = hx_g[tid];
+
+	// stage bytes [p0, p0 + need + 30] with aligned 16-byte loads; the chunk base is 16-byte
+	// aligned and its allocation is readable 64 B past the end (caller contract).
+	i64 need = seg_hi - p0;
+	if (need > TILE)
+		need = TILE;
+	const i64 nbytes = need + (MINIMUM_MATCH - 1);
+	const int mis = (int)((uintptr_t)(buf + p0) & 15);
+	{
+		const uint8_t *ga = buf + p0 - mis;
+		for (int off = tid * 16; off < nbytes + mis; off += 256 * 16)
+			*reinterpret_cast<uint4 *>(stage + off) = *reinterpret_cast<const uint4 *>(ga + off);
+	}
+	const uint8_t *bytes = stage + mis;
+	__syncthreads();
+
+	// tags for PER_THREAD consecutive positions
+	const int l0 = tid * PER_THREAD;
+	u64 tags[PER_THREAD];
+	uint32_t bits = 0;
+	if (l0 < need) {
+		u64 t = 0;
+#pragma unroll
+		for (int i = 0; i < MINIMUM_MATCH; i++)
+			t ^= hx[bytes[l0 + i]];
+#pragma unroll
+		for (int k = 0; k < PER_THREAD; k++) {
+			if (k)
+				t ^= hx[bytes[l0 + k - 1]] ^ hx[bytes[l0 + k + MINIMUM_MATCH - 1]];
+			tags[k] = t;
+			if (l0 + k < need && (t & min_mask) == min_mask)
+				bits |= 1u << k;
+		}
+	}
+	// workgroup exclusive scan of popcounts
+	uint32_t cnt = __popc(bits);
+	uint32_t incl = cnt;
+	const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		uint32_t o = __shfl_up(incl, d);
+		if (lane >= d)
+			incl += o;
+	}
+	if (lane == 63)
+		wave_tot[wv] = incl;
+	__syncthreads();
+	uint32_t base = 0;
+	for (int w = 0; w < wv; w++)
+		base += wave_tot[w];
+	uint32_t pos = base + incl - cnt;
+	const size_t out0 = (size_t)blockIdx.x * TILE;
+#pragma unroll
+	for (int k = 0; k < PER_THREAD; k++)
+		if (bits & (1u << k)) {
+			cand_rel[out0 + pos] = (uint32_t)((i64)blockIdx.x * TILE + l0 + k);
+			cand_tag[out0 + pos] = tags[k];
+			pos++;
+		}
+	if (tid == 255)
+		tile_count[blockIdx.x] = base + incl;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: the resolver (one wavefront)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 bcast64(u64 v, int src)
+{
+	uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)(v >> 32), src);
+	return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 mask_up(u64 m) { return (m << 1) | 1; }
+__device__ __forceinline__ int bitness_rank(u64 t) // ffsll(~t)
+{
+	u64 v = ~t;
+	return v ? __ffsll((long long)v) : 0;
+}
+__device__ __forceinline__ u64 low_mask(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1); }
+// index of the k-th (0-based) set bit of m; m must have more than k bits set
+__device__ __forceinline__ int nth_set_bit(u64 m, int k)
+{
+	for (int i = 0; i < k; i++)
+		m &= m - 1;
+	return __ffsll((long long)m) - 1;
+}
+
+struct Resolver {
+	const uint8_t *buf;
+	Slot *tbl;
+	u64 hmask;
+	i64 end, last_match;
+	u64 tag_mask, min_mask;
+	i64 hash_count, hash_limit, clean_ptr, victim_round;
+	uint32_t max_chain;
+	i64 tag_hits, tag_misses;
+	int lane;
+	// LDS stack for displaced entries
+	u64 *stk_t;
+	i64 *stk_off, *stk_h;
+
+	// Forward extent: number of equal bytes of buf[p..] and buf[op..], p bounded by `end`.
+	__device__ i64 extent_fwd(i64 p, i64 op) const
+	{
+		const i64 total = end - p;
+		if (total <= 0)
+			return 0;
+		i64 done = 0;
+		// phase 1: 512 B per step (8 B per lane) -- false tag positives die here
+		for (int it = 0; it < 4; it++) {
+			i64 off = done + (i64)lane * 8;
+			int mism = 8;
+			if (off < total) {
+				i64 lim = total - off < 8 ? total - off : 8;
+				if (lim == 8) {
+					u64 a = reinterpret_cast<const U64u *>(buf + p + off)->v;
+					u64 b = reinterpret_cast<const U64u *>(buf + op + off)->v;
+					u64 x = a ^ b;
+					mism = x ? (__ffsll((long long)x) - 1) >> 3 : 8;
+				} else {
+					mism = (int)lim;
+					for (int k = 0; k < (int)lim; k++)
+						if (buf[p + off + k] != buf[op + off + k]) {
+							mism = k;
+							break;
+						}
+				}
+			} else
+				mism = 0;
+			u64 stop = __ballot(mism < 8);
+			if (stop) {
+				int first = __ffsll((long long)stop) - 1;
+				i64 r = done + (i64)first * 8 + __shfl(mism, first);
+				return r < total ? r : total;
+			}
+			done += 512;
+			if (done >= total)
+				return total;
+		}
+		// phase 2: 16 KiB per step (16 x 16 B per lane, all loads in flight together)
+		for (;;) {
+			int mism_chunk = 16; // first differing 16-byte piece among my 16
+			int mism_byte = 0;
+			const i64 base = done + (i64)lane * 16;
+#pragma unroll
+			for (int c = 15; c >= 0; c--) {
+				i64 off = base + (i64)c * 1024;
+				if (off + 16 <= total) {
+					U128u a = *reinterpret_cast<const U128u *>(buf + p + off);
+					U128u b = *reinterpret_cast<const U128u *>(buf + op + off);
+					u64 x0 = a.a ^ b.a, x1 = a.b ^ b.b;
+					if (x0 | x1) {
+						mism_chunk = c;
+						mism_byte = x0 ? (__ffsll((long long)x0) - 1) >> 3 : 8 + ((__ffsll((long long)x1) - 1) >> 3);
+					}
+				} else if (off < total) {
+					int lim = (int)(total - off), m = lim;
+					for (int k = 0; k < lim; k++)
+						if (buf[p + off + k] != buf[op + off + k]) {
+							m = k;
+							break;
+						}
+					mism_chunk = c;
+					mism_byte = m;
+				} else {
+					mism_chunk = c;
+					mism_byte = 0;
+				}
+			}
+			// earliest mismatch position in this 16 KiB step, across lanes
+			i64 mypos = mism_chunk < 16 ? (i64)mism_chunk * 1024 + (i64)lane * 16 + mism_byte : (i64)1 << 40;
+			i64 best = mypos;
+#pragma unroll
+			for (int d = 32; d >= 1; d >>= 1) {
+				i64 o = (i64)bcast64((u64)best, (lane ^ d));
+				if (o < best)
+					best = o;
+			}
+			best = (i64)bcast64((u64)best, 0);
+			if (best < ((i64)1 << 40)) {
+				i64 r = done + best;
+				return r < total ? r : total;
+			}
+			done += 16384;
+			if (done >= total)
+				return total;
+		}
+	}
+
+	// Backward extent: equal bytes buf[p-1-k] == buf[op-1-k], k < max_back.
+	__device__ i64 extent_back(i64 p, i64 op, i64 max_back) const
+	{
+		if (max_back <= 0)
+			return 0;
+		i64 done = 0;
+		for (;;) {
+			i64 off = done + (i64)lane * 8; // bytes p-1-off .. p-8-off
+			int mism = 8;
+			if (off < max_back) {
+				i64 lim = max_back - off < 8 ? max_back - off : 8;
+				mism = (int)lim;
+				for (int k = 0; k < (int)lim; k++)
+					if (buf[p - 1 - off - k] != buf[op - 1 - off - k]) {
+						mism = k;
+						break;
+					}
+				if (lim == 8 && mism == 8)
+					mism = 8;
+			} else
+				mism = 0;
+			u64 stop = __ballot(mism < 8);
+			if (stop) {
+				int first = __ffsll((long long)stop) - 1;
+				i64 r = done + (i64)first * 8 + __shfl(mism, first);
+				return r < max_back ? r : max_back;
+			}
+			done += 512;
+			if (done >= max_back)
+				return max_back;
+		}
+	}
+
+	// single_match_len, src/rzip.c:431-461
+	__device__ i64 match_len(i64 p0, i64 op, i64 *rev) const
+	{
+		if (op >= p0)
+			return 0;
+		i64 len = extent_fwd(p0, op);
+		i64 floor_p = last_match > 0 ? last_match : 0;
+		i64 max_back = p0 - floor_p;
+		if (op < max_back)
+			max_back = op;
+		i64 r = extent_back(p0, op, max_back);
+		*rev = r;
+		len += r;
+		return len < MINIMUM_MATCH ? 0 : len;
+	}
+
+	// find_best_match, src/rzip.c:495-534
+	__device__ i64 lookup(u64 t, i64 p, i64 *offset, i64 *reverse)
+	{
+		i64 best = 0;
+		u64 h = t & hmask;
+		*reverse = 0;
+		for (;;) {
+			Slot s = tbl[(h + lane) & hmask];
+			bool empty = !(s.offset | (i64)s.t);
+			u64 em = __ballot(empty);
+			int first_empty = em ? __ffsll((long long)em) - 1 : 64;
+			u64 hits = __ballot(!empty && s.t == t) & low_mask(first_empty);
+			while (hits) {
+				int idx = __ffsll((long long)hits) - 1;
+				hits &= hits - 1;
+				i64 cand_off = (i64)bcast64((u64)s.offset, idx);
+				i64 rev = 0;
+				i64 mlen = match_len(p, cand_off, &rev);
+				if (mlen) {
+					if (mlen > best) {
+						best = mlen;
+						*offset = cand_off - rev;
+						*reverse = rev;
+					}
+					tag_hits++;
+				} else
+					tag_misses++;
+			}
+			if (first_empty < 64)
+				break;
+			h = (h + 64) & hmask;
+		}
+		return best;
+	}
+
+	// insert_hash, src/rzip.c:304-353 (recursion unrolled onto an LDS stack)
+	__device__ void insert(u64 t, i64 offset)
+	{
+		int depth = 0;
+		u64 cur_t = t;
+		i64 cur_off = offset;
+		const u64 better = mask_up(min_mask);
+		for (;;) {
+			u64 h = cur_t & hmask;
+			i64 round = 0;
+			i64 victim_h = 0;
+			const int my_rank = bitness_rank(cur_t);
+			i64 write_h = -1;
+			bool displaced = false;
+			u64 disp_t = 0;
+			i64 disp_off = 0;
+			for (;;) {
+				const u64 slot_idx = (h + lane) & hmask;
+				Slot s = tbl[slot_idx];
+				bool empty = !(s.offset | (i64)s.t);
+				bool below = !empty && (s.t & better) != better;
+				bool lesser = !empty && !below && bitness_rank(s.t) < my_rank;
+				bool eq = !empty && !below && !lesser && s.t == cur_t;
+				u64 stopm = __ballot(empty || below || lesser);
+				int s1 = stopm ? __ffsll((long long)stopm) - 1 : 64;
+				u64 eqm = __ballot(eq) & low_mask(s1);
+				int neq = __popcll(eqm);
+				// victim bookkeeping: the eq slot whose running index equals victim_round
+				i64 need_v = victim_round - round;
+				// chain limit inside this window?
+				i64 left = (i64)max_chain - round; // eq slots still allowed before the limit
+				if (neq >= left) {
+					// the left-th eq slot (1-based) triggers the limit
+					if (need_v >= 0 && need_v < left)
+						victim_h = (i64)((h + (u64)nth_set_bit(eqm, (int)need_v)) & hmask);
+					write_h = victim_h;
+					hash_count--;
+					if (++victim_round == (i64)max_chain)
+						victim_round = 0;
+					break;
+				}
+				if (need_v >= 0 && need_v < neq)
+					victim_h = (i64)((h + (u64)nth_set_bit(eqm, (int)need_v)) & hmask);
+				round += neq;
+				if (s1 < 64) {
+					const u64 sh = (h + (u64)s1) & hmask;
+					bool s_empty = (__ballot(empty) >> s1) & 1;
+					bool s_below = (__ballot(below) >> s1) & 1;
+					if (s_empty) {
+						write_h = (i64)sh;
+					} else if (s_below) {
+						hash_count--;
+						write_h = (i64)sh;
+					} else { // lesser bitness: rehash the occupant, then take its place
+						displaced = true;
+						disp_t = bcast64(s.t, s1);
+						disp_off = (i64)bcast64((u64)s.offset, s1);
+						write_h = (i64)sh;
+					}
+					break;
+				}
+				h = (h + 64) & hmask;
+			}
+			if (displaced) {
+				if (lane == 0) {
+					stk_t[depth] = cur_t;
+					stk_off[depth] = cur_off;
+					stk_h[depth] = write_h;
+				}
+				depth++;
+				cur_t = disp_t;
+				cur_off = disp_off;
+				continue;
+			}
+			if (lane == 0) {
+				Slot w;
+				w.offset = cur_off;
+				w.t = cur_t;
+				tbl[write_h] = w;
+			}
+			break;
+		}
+		// unwind: outer frames overwrite the displaced occupant's old slot
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		while (depth > 0) {
+			depth--;
+			if (lane == 0) {
+				Slot w;
+				w.offset = stk_off[depth];
+				w.t = stk_t[depth];
+				tbl[stk_h[depth]] = w;
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	}
+
+	// clean_one_from_hash, src/rzip.c:357-383
+	__device__ u64 clean_one()
+	{
+		const i64 size = (i64)hmask + 1;
+		for (;;) {
+			const u64 better = mask_up(min_mask);
+			while (clean_ptr < size) {
+				i64 idx = clean_ptr + lane;
+				bool cand = false;
+				if (idx < size) {
+					Slot s = tbl[idx];
+					bool empty = !(s.offset | (i64)s.t);
+					cand = !empty && (s.t & better) != better;
+				}
+				u64 m = __ballot(cand);
+				if (m) {
+					int k = __ffsll((long long)m) - 1;
+					if (lane == k) {
+						Slot z;
+						z.offset = 0;
+						z.t = 0;
+						tbl[idx] = z;
+					}
+					clean_ptr += k;
+					hash_count--;
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+					return better;
+				}
+				clean_ptr += 64;
+			}
+			min_mask = better;
+			clean_ptr = 0;
+		}
+	}
+};
+
+__global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf, Slot *__restrict__ tbl, ScanState *__restrict__ st,
+						i64 seg_lo, int ntiles, const uint32_t *__restrict__ cand_rel,
+						const u64 *__restrict__ cand_tag, const uint32_t *__restrict__ tile_count,
+						MatchRec *__restrict__ records)
+{
+	__shared__ u64 stk_t[64];
+	__shared__ i64 stk_off[64];
+	__shared__ i64 stk_h[64];
+
+	Resolver R;
+	R.buf = buf;
+	R.tbl = tbl;
+	R.lane = threadIdx.x;
+	R.hmask = ((u64)1 << st->hash_bits) - 1;
+	R.end = st->end;
+	R.last_match = st->last_match;
+	R.tag_mask = st->tag_mask;
+	R.min_mask = st->min_mask;
+	R.hash_count = st->hash_count;
+	R.hash_limit = st->hash_limit;
+	R.clean_ptr = st->clean_ptr;
+	R.victim_round = st->victim_round;
+	R.max_chain = st->max_chain_len;
+	R.tag_hits = st->tag_hits;
+	R.tag_misses = st->tag_misses;
+	R.stk_t = stk_t;
+	R.stk_off = stk_off;
+	R.stk_h = stk_h;
+
+	i64 p_skip = st->p_skip;
+	i64 cur_p = st->cur_p, cur_ofs = st->cur_ofs, cur_len = st->cur_len;
+	i64 n_rec = st->n_records;
+	const i64 rec_cap = st->rec_cap;
+	i64 inserts = st->inserts, lookups = st->lookups;
+	int error = st->error;
+	u64 sink = 0;
+	const int lane = threadIdx.x;
+
+	for (int tile = 0; tile < ntiles && !error; tile++) {
+		const uint32_t cnt = tile_count[tile];
+		const size_t base = (size_t)tile * TILE;
+		// skip whole tiles that lie inside an emitted match
+		if (seg_lo + (i64)(tile + 1) * TILE - 1 <= p_skip)
+			continue;
+		for (uint32_t b0 = 0; b0 < cnt && !error; b0 += 64) {
+			i64 pos = -1;
+			u64 tag = 0;
+			if (b0 + lane < cnt) {
+				pos = seg_lo + (i64)cand_rel[base + b0 + lane];
+				tag = cand_tag[base + b0 + lane];
+			}
+			bool valid = pos > p_skip && (tag & R.min_mask) == R.min_mask;
+			// warm L2 with the bucket windows of the whole batch while the first ones resolve
+			if (valid) {
+				const u64 *w = reinterpret_cast<const u64 *>(&tbl[tag & R.hmask]);
+				sink ^= __builtin_nontemporal_load(w + 1);
+			}
+			u64 todo = __ballot(valid);
+			while (todo && !error) {
+				const int i = __ffsll((long long)todo) - 1;
+				todo &= todo - 1;
+				const i64 P = (i64)bcast64((u64)pos, i);
+				const u64 T = bcast64(tag, i);
+				if (P <= p_skip)
+					continue;
+				if ((T & R.min_mask) != R.min_mask)
+					continue;
+
+				// One automaton step at position P.  After an emission the reference resumes at
+				// last_match + 1 (src/rzip.c:685-687); when the emitted match ends BEFORE P -- the
+				// emission was delayed until this candidate -- P itself is examined a second time
+				// (it is the only candidate in (last_match, P], any other would have emitted earlier).
+				bool again;
+				do {
+					again = false;
+					i64 offset = 0, reverse = 0;
+					lookups++;
+					i64 mlen = R.lookup(T, P, &offset, &reverse);
+
+					if ((T & R.tag_mask) == R.tag_mask) {
+						inserts++;
+						R.hash_count++;
+						R.insert(T, P);
+						if (R.hash_count > R.hash_limit)
+							R.tag_mask = R.clean_one();
+					}
+					if (mlen > cur_len) {
+						cur_p = P - reverse;
+						cur_len = mlen;
+						cur_ofs = offset;
+					}
+					if ((cur_len >= GREAT_MATCH || P >= cur_p + MINIMUM_MATCH) && cur_len >= MINIMUM_MATCH) {
+						if (n_rec >= rec_cap) {
+							error = 1;
+							break;
+						}
+						if (lane == 0) {
+							MatchRec r;
+							r.p = cur_p;
+							r.ofs = cur_ofs;
+							r.len = cur_len;
+							records[n_rec] = r;
+						}
+						n_rec++;
+						R.last_match = cur_p + cur_len;
+						p_skip = R.last_match;
+						cur_p = R.last_match;
+						cur_len = 0;
+						again = P > p_skip && P <= R.end && (T & R.min_mask) == R.min_mask;
+					}
+				} while (again);
+			}
+		}
+	}
+
+	if (lane == 0) {
+		st->p_skip = p_skip;
+		st->last_match = R.last_match;
+		st->cur_p = cur_p;
+		st->cur_ofs = cur_ofs;
+		st->cur_len = cur_len;
+		st->tag_mask = R.tag_mask;
+		st->min_mask = R.min_mask;
+		st->hash_count = R.hash_count;
+		st->clean_ptr = R.clean_ptr;
+		st->victim_round = R.victim_round;
+		st->n_records = n_rec;
+		st->error = error;
+		st->inserts = inserts;
+		st->lookups = lookups;
+		st->tag_hits = R.tag_hits;
+		st->tag_misses = R.tag_misses;
+	}
+	// keep the prefetch loads observable
+	u64 any = sink;
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1)
+		any ^= bcast64(any, lane ^ d);
+	if (lane == 0 && any == 0x9E3779B97F4A7C15ull)
+		st->sink = any;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: literal gather (stream 1)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gather_runs(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+						     const CopyRun *__restrict__ runs, int nruns, i64 total)
+{
+	// each workgroup owns 64 KiB of destination
+	const i64 tile0 = (i64)blockIdx.x * 65536;
+	i64 tile1 = tile0 + 65536;
+	if (tile1 > total)
+		tile1 = total;
+	// binary search: last run with dst_off <= tile0
+	int lo = 0, hi = nruns - 1;
+	while (lo < hi) {
+		int mid = (lo + hi + 1) >> 1;
+		if (runs[mid].dst_off <= tile0)
+			lo = mid;
+		else
+			hi = mid - 1;
+	}
+	int r = lo;
+	for (i64 d = tile0 + (i64)threadIdx.x * 16; d < tile1; d += 256 * 16) {
+		while (r + 1 < nruns && runs[r + 1].dst_off <= d)
+			r++;
+		CopyRun cr = runs[r];
+		i64 in_run = d - cr.dst_off;
+		if (in_run + 16 <= cr.len && d + 16 <= tile1) {
+			U128u v = *reinterpret_cast<const U128u *>(src + cr.src_off + in_run);
+			uint4 o;
+			o.x = (uint32_t)v.a;
+			o.y = (uint32_t)(v.a >> 32);
+			o.z = (uint32_t)v.b;
+			o.w = (uint32_t)(v.b >> 32);
+			*reinterpret_cast<uint4 *>(dst + d) = o;
+		} else {
+			int rr = r;
+			for (int k = 0; k < 16 && d + k < tile1; k++) {
+				i64 dd = d + k;
+				while (rr + 1 < nruns && runs[rr + 1].dst_off <= dd)
+					rr++;
+				dst[dd] = src[runs[rr].src_off + (dd - runs[rr].dst_off)];
+			}
+		}
+	}
+}
+
+int gather_runs_device(const uint8_t *d_src, uint8_t *d_dst, const CopyRun *d_runs, int nruns, int64_t total_len, hipStream_t s)
+{
+	if (total_len <= 0 || nruns <= 0)
+		return 0;
+	int64_t tiles = (total_len + 65535) / 65536;
+	hipLaunchKernelGGL(k_gather_runs, dim3((unsigned)tiles), dim3(256), 0, s, d_src, d_dst, d_runs, nruns, (i64)total_len);
+	return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5: CRC-32 (IEEE, reflected).  raw CRC (init 0, no final xor) per 64 KiB tile; tiles are folded
+// on the host with the x^(8*65536) operator.
+// ---------------------------------------------------------------------------------------------
+constexpr int CRC_TILE = 65536;
+
+__device__ __forceinline__ uint32_t gf2_apply(const uint32_t *mat, uint32_t v)
+{
+	uint32_t r = 0;
+#pragma unroll
+	for (int b = 0; b < 32; b++)
+		r ^= mat[b] & (0u - ((v >> b) & 1));
+	return r;
+}
+
+// ops: 8 matrices (32 u32 each): shift by 256 << k bytes, k = 0..7
+__global__ void __launch_bounds__(256) k_crc32_tiles(const uint8_t *__restrict__ buf, i64 n, const uint32_t *__restrict__ ops,
+						     uint32_t *__restrict__ partial)
+{
+	__shared__ uint32_t tab[256];
+	__shared__ uint32_t mats[8 * 32];
+	__shared__ __attribute__((aligned(16))) uint8_t tile[CRC_TILE];
+	__shared__ uint32_t red[256];
+	const int tid = threadIdx.x;
+	{
+		uint32_t r = tid;
+		for (int j = 0; j < 8; j++)
+			r = (r >> 1) ^ (0xEDB88320u & (0u - (r & 1)));
+		tab[tid] = r;
+		mats[tid] = ops[tid];
+	}
+	const i64 t0 = (i64)blockIdx.x * CRC_TILE;
+	i64 len = n - t0;
+	if (len > CRC_TILE)
+		len = CRC_TILE;
+	// stage (zero-padded FRONT so that every thread covers exactly 256 bytes: leading zeros do not
+	// change a raw CRC with init 0)
+	const i64 pad = CRC_TILE - len;
+	for (int off = tid * 16; off < CRC_TILE; off += 256 * 16) {
+		uint4 v = make_uint4(0, 0, 0, 0);
+		i64 s = (i64)off - pad; // source offset within the tile's data
+		if (s >= 0 && s + 16 <= len && (((uintptr_t)(buf + t0 + s)) & 15) == 0)
+			v = *reinterpret_cast<const uint4 *>(buf + t0 + s);
+		else {
+			uint8_t *vb = reinterpret_cast<uint8_t *>(&v);
+			for (int k = 0; k < 16; k++) {
+				i64 ss = s + k;
+				vb[k] = (ss >= 0 && ss < len) ? buf[t0 + ss] : 0;
+			}
+		}
+		*reinterpret_cast<uint4 *>(tile + off) = v;
+	}
+	__syncthreads();
+	uint32_t c = 0;
+	const uint8_t *mine = tile + tid * 256;
+	for (int k = 0; k < 256; k += 4) {
+		uint32_t w = *reinterpret_cast<const uint32_t *>(mine + k);
+		c ^= w;
+		c = tab[c & 0xFF] ^ (c >> 8);
+		c = tab[c & 0xFF] ^ (c >> 8);
+		c = tab[c & 0xFF] ^ (c >> 8);
+		c = tab[c & 0xFF] ^ (c >> 8);
+	}
+	red[tid] = c;
+	__syncthreads();
+	// tree fold: combine(left, right) = shift(left, len(right)) ^ right
+	for (int k = 0; k < 8; k++) {
+		int stride = 1 << k;
+		if ((tid & (2 * stride - 1)) == 0)
+			red[tid] = gf2_apply(mats + k * 32, red[tid]) ^ red[tid + stride];
+		__syncthreads();
+	}
+	if (tid == 0)
+		partial[blockIdx.x] = red[0];
+}
+
+static void gf2_square(uint32_t *sq, const uint32_t *m)
+{
+	for (int i = 0; i < 32; i++) {
+		uint32_t v = m[i], r = 0;
+		for (int b = 0; v; b++, v >>= 1)
+			if (v & 1)
+				r ^= m[b];
+		sq[i] = r;
+	}
+}
+static uint32_t gf2_times(const uint32_t *m, uint32_t v)
+{
+	uint32_t r = 0;
+	for (int b = 0; v; b++, v >>= 1)
+		if (v & 1)
+			r ^= m[b];
+	return r;
+}
+// operator "append one zero byte" for the reflected CRC-32 register, then powers of two of it
+static void crc_shift_ops(uint32_t ops[64][32])
+{
+	uint32_t bit[32], t[32];
+	// one zero BIT: v -> (v >> 1) ^ (poly if v & 1)
+	bit[0] = 0xEDB88320u;
+	for (int i = 1; i < 32; i++)
+		bit[i] = 1u << (i - 1);
+	gf2_square(t, bit);   // 2 bits
+	gf2_square(bit, t);   // 4 bits
+	gf2_square(ops[0], bit); // 8 bits = 1 byte
+	for (int k = 1; k < 64; k++)
+		gf2_square(ops[k], ops[k - 1]); // 2^k bytes
+}
+static uint32_t crc_shift(const uint32_t ops[64][32], uint32_t v, uint64_t nbytes)
+{
+	for (int k = 0; nbytes; k++, nbytes >>= 1)
+		if (nbytes & 1)
+			v = gf2_times(ops[k], v);
+	return v;
+}
+
+int crc32_device(ScanWorkspace *w, const uint8_t *d_buf, int64_t n, uint32_t *crc, hipStream_t s)
+{
+	static uint32_t ops[64][32];
+	static bool ready = false;
+	if (!ready) {
+		crc_shift_ops(ops);
+		ready = true;
+	}
+	if (n <= 0) {
+		*crc = 0;
+		return 0;
+	}
+	size_t tiles = (size_t)((n + CRC_TILE - 1) / CRC_TILE);
+	if (tiles > w->crc_cap)
+		return -2;
+	uint32_t *d_ops = w->crc_partial + w->crc_cap; // 256 u32 reserved after the partials
+	HIPCHK(hipMemcpyAsync(d_ops, &ops[8][0], 8 * 32 * 4, hipMemcpyHostToDevice, s)); // 256 B << k
+	EventTimer tc(s);
+	hipLaunchKernelGGL(k_crc32_tiles, dim3((unsigned)tiles), dim3(256), 0, s, d_buf, (i64)n, d_ops, w->crc_partial);
+	tc.stop();
+	std::vector<uint32_t> part(tiles);
+	HIPCHK(hipMemcpyAsync(part.data(), w->crc_partial, tiles * 4, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	{
+		ProfileStore &ps = ProfileStore::get();
+		std::lock_guard<std::mutex> lk(ps.mu);
+		ps.p.crc_ms += tc.ms();
+		ps.p.crc_launches++;
+		ps.p.crc_bytes += n;
+	}
+	// tiles 0..T-2 are full; the last one was front-padded with zeros, i.e. its raw CRC is that of
+	// its real bytes.  raw(total) = fold over tiles with the right shift lengths.
+	uint32_t raw = 0;
+	for (size_t t = 0; t < tiles; t++) {
+		int64_t len = (t + 1 < tiles) ? CRC_TILE : n - (int64_t)t * CRC_TILE;
+		raw = crc_shift(ops, raw, (uint64_t)len) ^ part[t];
+	}
+	*crc = raw ^ crc_shift(ops, 0xFFFFFFFFu, (uint64_t)n) ^ 0xFFFFFFFFu;
+	return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------------------------
+int scan_workspace_create(ScanWorkspace **out, int rzip_level, int64_t max_chunk)
+{
+	ScanWorkspace *w = (ScanWorkspace *)calloc(1, sizeof(ScanWorkspace));
+	if (!w)
+		return -1;
+	unsigned mb, freq, chain;
+	rzip_level_params(rzip_level, &mb, &freq, &chain);
+	int64_t hashsize = (int64_t)mb * (1048576 / 16);
+	for (w->hash_bits = 0; ((int64_t)1 << w->hash_bits) < hashsize; w->hash_bits++)
+		;
+	HIPCHK(hipMalloc(&w->table, ((size_t)16 << w->hash_bits) + 64 * 16));
+	HIPCHK(hipMalloc(&w->state, sizeof(ScanState)));
+	HIPCHK(hipMalloc(&w->hx, 256 * 8));
+	w->seg_cap = (size_t)1 << 30; // up to 1 GiB of positions per segment
+	if ((int64_t)w->seg_cap > max_chunk + TILE)
+		w->seg_cap = (size_t)(((max_chunk + TILE) / TILE + 1) * TILE);
+	HIPCHK(hipMalloc(&w->cand_rel, w->seg_cap * 4));
+	HIPCHK(hipMalloc(&w->cand_tag, w->seg_cap * 8));
+	HIPCHK(hipMalloc(&w->tile_count, (w->seg_cap / TILE + 2) * 4));
+	w->rec_cap = max_chunk / MINIMUM_MATCH + 16;
+	if (w->rec_cap > (int64_t)1 << 26)
+		w->rec_cap = (int64_t)1 << 26;
+	HIPCHK(hipMalloc(&w->records, (size_t)w->rec_cap * sizeof(MatchRec)));
+	w->crc_cap = (size_t)(max_chunk / CRC_TILE + 2);
+	HIPCHK(hipMalloc(&w->crc_partial, (w->crc_cap + 256) * 4));
+	uint64_t hx[256];
+	hash_index_table(hx);
+	HIPCHK(hipMemcpy(w->hx, hx, sizeof(hx), hipMemcpyHostToDevice));
+	*out = w;
+	return 0;
+}
+
+void scan_workspace_destroy(ScanWorkspace *w)
+{
+	if (!w)
+		return;
+	void *ptrs[] = {w->table, w->state, w->hx, w->cand_rel, w->cand_tag, w->tile_count, w->records, w->crc_partial};
+	for (void *p : ptrs)
+		if (p)
+			(void)hipFree(p);
+	free(w);
+}
+
+int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_size, int rzip_level,
+		      int64_t *victim_round, ScanResult *res, hipStream_t s)
+{
+	unsigned mb, freq, chain;
+	rzip_level_params(rzip_level, &mb, &freq, &chain);
+	ScanState h;
+	memset(&h, 0, sizeof(h));
+	h.chunk_size = chunk_size;
+	h.end = chunk_size - MINIMUM_MATCH;
+	h.hash_bits = w->hash_bits;
+	h.max_chain_len = chain;
+	h.hash_limit = ((int64_t)1 << w->hash_bits) / 3 * 2;
+	h.tag_mask = ((uint64_t)1 << freq) - 1;
+	h.min_mask = h.tag_mask;
+	h.victim_round = *victim_round;
+	h.rec_cap = w->rec_cap;
+	HIPCHK(hipMemsetAsync(w->table, 0, ((size_t)16 << w->hash_bits) + 64 * 16, s));
+	HIPCHK(hipMemcpyAsync(w->state, &h, sizeof(h), hipMemcpyHostToDevice, s));
+
+	const auto wall0 = std::chrono::steady_clock::now();
+	const int64_t end = h.end;
+	int64_t p_skip = 0;
+	uint64_t min_mask = h.min_mask;
+	while (p_skip + 1 <= end) {
+		const int64_t seg_lo = p_skip + 1;
+		// size the segment for ~2M candidates under the current mask
+		int mbits = __builtin_popcountll(min_mask);
+		int64_t seg = (int64_t)(2 << 20) << (mbits > 9 ? 9 : mbits);
+		if (seg < (16 << 20))
+			seg = 16 << 20;
+		if (seg > (int64_t)w->seg_cap - TILE)
+			seg = (int64_t)w->seg_cap - TILE;
+		int64_t seg_hi = seg_lo + seg;
+		if (seg_hi > end + 1)
+			seg_hi = end + 1;
+		const int ntiles = (int)((seg_hi - seg_lo + TILE - 1) / TILE);
+		EventTimer t1(s);
+		hipLaunchKernelGGL(k_tag_scan, dim3(ntiles), dim3(256), 0, s, d_chunk, (i64)seg_lo, (i64)seg_hi, (const u64 *)w->hx,
+				   (const ScanState *)w->state, w->cand_rel, (u64 *)w->cand_tag, w->tile_count);
+		t1.stop();
+		EventTimer t2(s);
+		hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), 0, s, d_chunk, (Slot *)w->table, w->state, (i64)seg_lo, ntiles,
+				   (const uint32_t *)w->cand_rel, (const u64 *)w->cand_tag, (const uint32_t *)w->tile_count, w->records);
+		t2.stop();
+		HIPCHK(hipMemcpyAsync(&h, w->state, sizeof(h), hipMemcpyDeviceToHost, s));
+		HIPCHK(hipStreamSynchronize(s));
+		{
+			ProfileStore &ps = ProfileStore::get();
+			std::lock_guard<std::mutex> lk(ps.mu);
+			ps.p.tag_scan_ms += t1.ms();
+			ps.p.tag_scan_launches++;
+			ps.p.tag_scan_positions += seg_hi - seg_lo;
+			ps.p.resolve_ms += t2.ms();
+			ps.p.resolve_launches++;
+		}
+		if (h.error)
+			return h.error == 1 ? -4 : -5;
+		p_skip = h.p_skip > seg_hi - 1 ? h.p_skip : seg_hi - 1;
+		min_mask = h.min_mask;
+	}
+	if (chunk_size > 0 && end > 0) {
+		// state already in h from the last segment
+	} else {
+		HIPCHK(hipMemcpyAsync(&h, w->state, sizeof(h), hipMemcpyDeviceToHost, s));
+		HIPCHK(hipStreamSynchronize(s));
+	}
+	res->records.resize((size_t)h.n_records);
+	if (h.n_records)
+		HIPCHK(hipMemcpyAsync(res->records.data(), w->records, (size_t)h.n_records * sizeof(MatchRec), hipMemcpyDeviceToHost, s));
+	uint32_t crc = 0;
+	if (crc32_device(w, d_chunk, chunk_size, &crc, s) != 0)
+		return -6;
+	HIPCHK(hipStreamSynchronize(s));
+	res->crc = crc;
+	res->final_state = h;
+	*victim_round = h.victim_round;
+	{
+		int64_t mb = 0;
+		for (const MatchRec &r : res->records)
+			mb += r.len;
+		ProfileStore &ps = ProfileStore::get();
+		std::lock_guard<std::mutex> lk(ps.mu);
+		ps.p.resolve_lookups += h.lookups;
+		ps.p.resolve_inserts += h.inserts;
+		ps.p.resolve_match_bytes += mb;
+		ps.p.scan_wall_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+	}
+	return 0;
+}
+
+} // namespace lrzgpu

@@ -1,0 +1,238 @@
+// stream_layer.cpp -- see stream_layer.h.  Host-only logic, no device code.
+#include "stream_layer.h"
+
+#include <cstring>
+
+namespace lrzgpu {
+
+namespace {
+constexpr int64_t ONE_MB = 1048576;
+constexpr int64_t STREAM_BUFSIZE = 10 * ONE_MB; // src/include/lrzip_private.h:16
+constexpr int64_t CHUNK_MULTIPLE = 100 * ONE_MB; // src/rzip.c:48
+
+int64_t round_to_page(int64_t v) // src/util.c:190-195
+{
+	v -= v % kPage;
+	return v ? v : kPage;
+}
+int64_t round_up_page(int64_t v) // src/util.c:197-204
+{
+	int64_t r = v % kPage;
+	return r ? v + kPage - r : v;
+}
+uint32_t lzma2_dic_from_prop(unsigned p) // src/include/lrzip_private.h:236
+{
+	return p == 40 ? 0xFFFFFFFFu : ((uint32_t)(2 | (p & 1)) << (p / 2 + 11));
+}
+unsigned lzma2_prop_from_dic(uint32_t d)
+{
+	unsigned i = 0;
+	for (; i <= 40; i++)
+		if (d <= lzma2_dic_from_prop(i))
+			break;
+	return i;
+}
+uint32_t level_dict(int level) // src/util.c:108-127
+{
+	switch (level) {
+	case 1: case 2: case 3: return 1u << (level * 2 + 16);
+	case 4: case 5: case 6: return 1u << (level + 19);
+	case 7: return 1u << 25;
+	case 8: return 1u << 26;
+	case 9: return 1u << 27;
+	default: return 1u << 24;
+	}
+}
+int64_t overhead_for(uint32_t dict) { return ((int64_t)dict * 23 / 2) + 6 * ONE_MB + 16384; } // src/util.c:131
+} // namespace
+
+int compute_sizing(const lrzgpu_control *c, int64_t st_size, Sizing *out)
+{
+	Sizing s;
+	s.level = c->compression_level;
+	s.rzip_level = c->rzip_compression_level ? c->rzip_compression_level : c->compression_level; // src/main.c:779-780
+	s.no_compress = (c->flags & LRZGPU_FLAG_NO_COMPRESS) != 0;
+	s.lz4_test = (c->flags & LRZGPU_FLAG_THRESHOLD) != 0 && !s.no_compress; // src/main.c:858-861
+	s.nobemt = (c->flags & LRZGPU_FLAG_NOBEMT) != 0;
+	s.threshold = c->threshold;
+	if (s.level < 1 || s.level > 9 || s.rzip_level < 1 || s.rzip_level > 9 || c->threads < 1 || c->ramsize <= 0)
+		return LRZGPU_E_PARAM;
+	const bool lzma = !s.no_compress;
+	s.dict_size = c->dictSize ? c->dictSize : level_dict(s.level);
+	s.overhead = lzma ? overhead_for(s.dict_size) : 0;
+
+	// setup_ram(), src/util.c:179-188 (not writing to stdout)
+	const int64_t usable_ram = c->ramsize / 3;
+	const int64_t maxram = round_to_page(usable_ram);
+
+	// rzip_fd(), src/rzip.c:999-1013
+	int64_t max_mmap = round_to_page(maxram);
+	int64_t max_chunk = c->window ? c->window * CHUNK_MULTIPLE : c->ramsize / 3 * 2;
+	if (max_mmap > max_chunk)
+		max_mmap = max_chunk;
+	if (max_chunk < st_size)
+		max_chunk = round_to_page(max_chunk);
+	s.max_chunk = max_chunk;
+
+	// prepare_streamout_threads(), src/stream.c:1099-1102
+	s.threads = c->threads;
+	if (s.threads > 1)
+		s.threads++;
+	if (s.no_compress)
+		s.threads = 1;
+
+	// open_stream_out() first call, src/stream.c:1169-1331
+	int64_t chunk_limit = max_chunk < st_size ? max_chunk : st_size;
+	if (chunk_limit < kPage)
+		chunk_limit = kPage;
+	const int testbufs = s.no_compress ? 1 : 2;
+	int64_t limit = usable_ram / testbufs;
+	if (lzma) {
+		const int save_threads = s.threads;
+		int thread_limit = s.threads >= c->processors / 2 ? s.threads / 2 : s.threads;
+		unsigned exponent = lzma2_prop_from_dic(s.dict_size);
+		const uint32_t save_dict = s.dict_size;
+		const unsigned save_exp = exponent;
+		bool found = false;
+		for (;;) {
+			do {
+				for (s.threads = save_threads; s.threads >= thread_limit; s.threads--)
+					if (limit >= s.overhead * s.threads / testbufs) {
+						found = true;
+						break;
+					}
+				if (found)
+					break;
+				exponent -= 1;
+				s.dict_size = lzma2_dic_from_prop(exponent);
+				s.overhead = overhead_for(s.dict_size);
+			} while (s.dict_size > (1u << 24));
+			if (!found && thread_limit > 1) {
+				thread_limit--;
+				s.dict_size = save_dict;
+				exponent = save_exp;
+				s.overhead = overhead_for(s.dict_size);
+				continue;
+			}
+			break;
+		}
+	}
+	if (st_size > 0 && st_size < limit)
+		limit = st_size > STREAM_BUFSIZE ? st_size : STREAM_BUFSIZE;
+	else if (limit > chunk_limit)
+		limit = chunk_limit;
+	// (the reference shrinks `limit` by 10% steps while malloc(limit + overhead*threads) fails;
+	//  that host-dependent retry is not modelled: the allocation is assumed to succeed)
+	if (lzma && limit / s.threads > STREAM_BUFSIZE) {
+		int64_t a = s.overhead - (int64_t)s.dict_size;
+		s.stream_bufsize = round_up_page((limit > a ? limit : a) / s.threads);
+	} else {
+		int64_t a = limit / s.threads;
+		if (a < STREAM_BUFSIZE)
+			a = STREAM_BUFSIZE;
+		s.stream_bufsize = round_up_page(limit < a ? limit : a);
+	}
+	*out = s;
+	return 0;
+}
+
+void block_order(const std::vector<uint8_t> &stream0, int chunk_bytes, int64_t stream1_len, int64_t bufsize,
+		 std::vector<BlockRef> *blocks)
+{
+	int64_t fill[2] = {0, 0}, start[2] = {0, 0};
+	auto put = [&](int s, int64_t n) {
+		while (n) {
+			int64_t k = bufsize - fill[s];
+			if (k > n)
+				k = n;
+			fill[s] += k;
+			n -= k;
+			if (fill[s] == bufsize) {
+				blocks->push_back(BlockRef{s, start[s], bufsize});
+				start[s] += bufsize;
+				fill[s] = 0;
+			}
+		}
+	};
+	size_t i = 0;
+	const size_t n0 = stream0.size();
+	while (i + 3 <= n0) {
+		const int head = stream0[i];
+		const int64_t len = stream0[i + 1] | ((int64_t)stream0[i + 2] << 8);
+		put(0, 3);
+		i += 3;
+		if (head == 1) {
+			put(0, chunk_bytes);
+			i += (size_t)chunk_bytes;
+		} else {
+			if (len == 0) { // terminator: the 4 CRC bytes follow
+				put(0, (int64_t)(n0 - i));
+				i = n0;
+				break;
+			}
+			put(1, len);
+		}
+	}
+	(void)stream1_len;
+	// close_stream_out(): stream 0 then stream 1, unconditionally (zero-length blocks included)
+	blocks->push_back(BlockRef{0, start[0], fill[0]});
+	blocks->push_back(BlockRef{1, start[1], fill[1]});
+}
+
+static void put_val(std::vector<uint8_t> &o, size_t at, int64_t v, int n)
+{
+	if (o.size() < at + (size_t)n)
+		o.resize(at + (size_t)n);
+	for (int i = 0; i < n; i++)
+		o[at + i] = i < 8 ? (uint8_t)((uint64_t)v >> (8 * i)) : 0;
+}
+
+void write_chunk(std::vector<uint8_t> *outp, int cb, bool eof, int64_t chunk_size, const std::vector<DoneBlock> &blocks)
+{
+	std::vector<uint8_t> &o = *outp;
+	size_t pos = o.size();
+	o.push_back((uint8_t)cb);
+	o.push_back(eof ? 1 : 0);
+	pos += 2;
+	put_val(o, pos, chunk_size < kPage ? kPage : chunk_size, cb); // sinfo->size, src/stream.c:1150-1152, 1747
+	pos += (size_t)cb;
+	const size_t initial_pos = pos;
+	int64_t cur_pos = 0, last_head[2];
+	for (int j = 0; j < 2; j++) { // src/stream.c:1755-1769
+		last_head[j] = cur_pos + 1 + cb * 2;
+		put_val(o, initial_pos + (size_t)cur_pos, CTYPE_NONE, 1);
+		put_val(o, initial_pos + (size_t)cur_pos + 1, 0, cb * 3);
+		cur_pos += 1 + cb * 3;
+	}
+	for (const DoneBlock &b : blocks) { // src/stream.c:1772-1821
+		put_val(o, initial_pos + (size_t)last_head[b.streamno], cur_pos, cb);
+		last_head[b.streamno] = cur_pos + 1 + cb * 2;
+		put_val(o, initial_pos + (size_t)cur_pos, b.c_type, 1);
+		put_val(o, initial_pos + (size_t)cur_pos + 1, (int64_t)b.payload.size(), cb);
+		put_val(o, initial_pos + (size_t)cur_pos + 1 + cb, b.s_len, cb);
+		put_val(o, initial_pos + (size_t)cur_pos + 1 + 2 * cb, 0, cb);
+		cur_pos += 1 + cb * 3;
+		o.resize(initial_pos + (size_t)cur_pos);
+		o.insert(o.end(), b.payload.begin(), b.payload.end());
+		cur_pos += (int64_t)b.payload.size();
+	}
+}
+
+void write_magic(uint8_t magic[21], const Sizing &s, int64_t st_size)
+{
+	memset(magic, 0, 21);
+	memcpy(magic, "LRZI", 4);
+	magic[4] = 0;  // LRZIP_MAJOR_VERSION
+	magic[5] = 14; // LRZIP_MINOR_VERSION
+	for (int i = 0; i < 8; i++)
+		magic[6 + i] = (uint8_t)((uint64_t)st_size >> (8 * i));
+	magic[14] = 1; // hash_code: MD5
+	if (!s.no_compress) {
+		magic[17] = 1;
+		magic[18] = (uint8_t)lzma2_prop_from_dic(s.dict_size);
+	}
+	magic[19] = (uint8_t)((s.rzip_level << 4) + s.level);
+	magic[20] = 0; // comment length
+}
+
+} // namespace lrzgpu

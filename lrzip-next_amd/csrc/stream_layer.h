@@ -1,0 +1,67 @@
+// stream_layer.h -- host stream layer: sizing, block order and container layout of lrzip-next 0.14.
+//
+// Mirrors the compress side of reference src/stream.c:
+//   prepare_streamout_threads 1090-1118, open_stream_out 1140-1348 (threads / dictionary / limit /
+//   stream_bufsize heuristics), write_stream 2198-2216 + flush_buffer 1878-1881 (block boundaries
+//   and flush order), compthread 1550-1834 (chunk + block headers), close_stream_out 2253-2282,
+// and src/util.c:103-188 (setup_overhead, setup_ram), src/rzip.c:999-1020, 1129-1133 (chunking),
+// src/lrzip.c:131-208 (write_magic).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../../include/lrzgpu.h"
+
+namespace lrzgpu {
+
+constexpr int CTYPE_NONE = 3; // src/include/lrzip_private.h:287-294
+constexpr int CTYPE_LZMA = 6;
+constexpr int64_t kPage = 4096;
+
+struct Sizing {
+	int level = 7, rzip_level = 7;
+	bool no_compress = false, lz4_test = true, nobemt = false;
+	int threads = 1;          // after prepare_streamout_threads() and open_stream_out() reductions
+	uint32_t dict_size = 0;   // possibly reduced
+	int64_t overhead = 0;
+	int64_t stream_bufsize = 0;
+	int64_t max_chunk = 0;    // rzip chunk size
+	int threshold = 100;
+};
+
+// Everything the reference derives from (flags, -p, -m, -w, file size) before the first chunk.
+int compute_sizing(const lrzgpu_control *c, int64_t st_size, Sizing *out);
+
+inline int chunk_bytes_for(int64_t chunk_size) // src/rzip.c:1129-1133
+{
+	int bits = 8;
+	while (chunk_size >> bits > 0)
+		bits++;
+	return bits / 8 + (bits % 8 ? 1 : 0);
+}
+
+// One flushed stream buffer (a "block"): bytes [off, off+len) of stream `streamno` of its chunk.
+struct BlockRef {
+	int streamno;
+	int64_t off, len;
+};
+
+// Replays write_stream()/write_sbstream()/flush_buffer() over a chunk's token stream to obtain the
+// blocks in the order the reference hands them to compthreads (which is the file order).
+void block_order(const std::vector<uint8_t> &stream0, int chunk_bytes, int64_t stream1_len, int64_t bufsize,
+		 std::vector<BlockRef> *blocks);
+
+struct DoneBlock {
+	int streamno = 0;
+	int c_type = CTYPE_NONE;
+	int64_t s_len = 0;
+	std::vector<uint8_t> payload; // c_len bytes
+};
+
+// Appends one chunk (header, initial stream headers, chained blocks) to `out` (src/stream.c:1716-1821).
+void write_chunk(std::vector<uint8_t> *out, int chunk_bytes, bool eof, int64_t chunk_size,
+		 const std::vector<DoneBlock> &blocks);
+
+void write_magic(uint8_t magic[21], const Sizing &s, int64_t st_size); // src/lrzip.c:131-208
+
+} // namespace lrzgpu

@@ -238,32 +238,15 @@ static void sink_put1(void *ctx, i64 off, i64 len)
 	}
 }
 
-int lrzo_compress_buffer(const lrzo_params *prm, const uchar *in, i64 n, lrzo_lzma_fn lzma,
-			 uchar **out, i64 *out_len, lrzo_file_stats *fs)
+struct plan_out { int threads; uint32_t dict_size; i64 bufsize, max_chunk; };
+
+/* setup_overhead / setup_ram / rzip_fd sizing / prepare_streamout_threads / open_stream_out */
+static void make_plan(const lrzo_params *prm, i64 n, struct plan_out *po)
 {
-	struct driver d;
-	struct outbuf ob = {0};
-	lrzo_file_stats lfs;
-	lrzo_md5 md5;
-	uint64_t hx[256];
-	i64 victim_round = 0;
-	int rzip_level, lzma_on, nworkers, w;
-	pthread_t *tids;
-	i64 maxram, usable_ram, max_mmap, max_chunk, overhead, limit, len, *chunk_sizes = NULL, nchunks = 0;
-	int *chunk_cbytes = NULL;
-
-	memset(&d, 0, sizeof(d));
-	memset(&lfs, 0, sizeof(lfs));
-	d.prm = prm;
-	d.lzma = lzma;
-	d.fs = &lfs;
+	struct { int threads, level; uint32_t dict_size; i64 bufsize; } d;
+	i64 maxram, usable_ram, max_mmap, max_chunk, overhead, limit;
+	const int lzma_on = !prm->no_compress;
 	d.level = prm->compression_level;
-	rzip_level = prm->rzip_level ? prm->rzip_level : prm->compression_level;
-	lzma_on = !prm->no_compress;
-	d.lz4_test = prm->lz4_test && !prm->no_compress; /* src/main.c:858-861 */
-	if (lzma_on && !lzma)
-		return -1;
-
 	/* setup_overhead / setup_ram */
 	d.dict_size = prm->dict_size ? prm->dict_size : dict_for_level(d.level);
 	overhead = lzma_on ? lzma_overhead(d.dict_size) : 0;
@@ -335,6 +318,57 @@ int lrzo_compress_buffer(const lrzo_params *prm, const uchar *in, i64 n, lrzo_lz
 				a = STREAM_BUFSIZE;
 			d.bufsize = round_up_page(limit < a ? limit : a);
 		}
+	}
+	po->threads = d.threads;
+	po->dict_size = d.dict_size;
+	po->bufsize = d.bufsize;
+	po->max_chunk = max_chunk;
+}
+
+int lrzo_plan(const lrzo_params *prm, i64 n, lrzo_file_stats *fs)
+{
+	struct plan_out po;
+	make_plan(prm, n, &po);
+	memset(fs, 0, sizeof(*fs));
+	fs->stream_bufsize = po.bufsize;
+	fs->threads_used = po.threads;
+	fs->dict_size = po.dict_size;
+	return 0;
+}
+
+int lrzo_compress_buffer(const lrzo_params *prm, const uchar *in, i64 n, lrzo_lzma_fn lzma,
+			 uchar **out, i64 *out_len, lrzo_file_stats *fs)
+{
+	struct driver d;
+	struct outbuf ob = {0};
+	lrzo_file_stats lfs;
+	lrzo_md5 md5;
+	uint64_t hx[256];
+	i64 victim_round = 0;
+	int rzip_level, lzma_on, nworkers, w;
+	pthread_t *tids;
+	i64 max_chunk, len, *chunk_sizes = NULL, nchunks = 0;
+	int *chunk_cbytes = NULL;
+
+	memset(&d, 0, sizeof(d));
+	memset(&lfs, 0, sizeof(lfs));
+	d.prm = prm;
+	d.lzma = lzma;
+	d.fs = &lfs;
+	d.level = prm->compression_level;
+	rzip_level = prm->rzip_level ? prm->rzip_level : prm->compression_level;
+	lzma_on = !prm->no_compress;
+	d.lz4_test = prm->lz4_test && !prm->no_compress; /* src/main.c:858-861 */
+	if (lzma_on && !lzma)
+		return -1;
+
+	{
+		struct plan_out po;
+		make_plan(prm, n, &po);
+		d.threads = po.threads;
+		d.dict_size = po.dict_size;
+		d.bufsize = po.bufsize;
+		max_chunk = po.max_chunk;
 	}
 	lfs.stream_bufsize = d.bufsize;
 	lfs.threads_used = d.threads;

@@ -129,6 +129,9 @@ typedef struct {
 	lrzo_rzip_stats rz;
 } lrzo_file_stats;
 
+/* Sizing only: stream_bufsize / threads_used / dict_size as open_stream_out() settles them. */
+int lrzo_plan(const lrzo_params *p, i64 n, lrzo_file_stats *fs);
+
 /* Compress in[0..n) into a malloc'd .lrz image (caller frees *out).
  * Restates rzip_fd (src/rzip.c:922), open_stream_out sizing (src/stream.c:1140),
  * compthread header/block layout (src/stream.c:1550), write_magic (src/lrzip.c:131). */

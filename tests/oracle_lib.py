@@ -75,6 +75,7 @@ def lib():
         L.lrzo_compress_buffer.argtypes = [C.POINTER(Params), C.c_char_p, C.c_int64, C.c_void_p,
                                            C.POINTER(C.POINTER(C.c_ubyte)), C.POINTER(C.c_int64),
                                            C.POINTER(FileStats)]
+        L.lrzo_plan.argtypes = [C.POINTER(Params), C.c_int64, C.POINTER(FileStats)]
         L.lrzo_rzip_level.argtypes = [C.c_int]
         L.lrzo_rzip_level.restype = C.POINTER(Level)
         _lib = L

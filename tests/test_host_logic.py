@@ -1,0 +1,88 @@
+"""CPU tests of the product's host logic and of the C ABI surface (no compute calls needing a GPU)."""
+import ctypes as C
+import hashlib
+import os
+import re
+
+import pytest
+
+import datagen
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(B):
+    hdr = open(os.path.join(ROOT, "include", "lrzgpu.h")).read()
+    names = sorted(set(re.findall(r"\b(lrzgpu_[A-Za-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 15
+    L = B.lib()
+    for n in names:
+        assert hasattr(L, n), "missing export %s" % n
+
+
+def test_compute_entry_points_fail_loudly_without_gpu(B):
+    L = B.lib()
+    if L.lrzgpu_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    assert L.lrzgpu_lz4_compresses(b"x" * 100, 100, 100, 0) == -100  # LRZGPU_E_NODEVICE
+    with pytest.raises(RuntimeError):
+        B.compress_buffer(b"hello world" * 100)
+    with pytest.raises(RuntimeError):
+        B.hash_search(b"hello world" * 100)
+
+
+@pytest.mark.parametrize("st_size", [0, 1, 5000, 10 << 20, 64 << 20, 700 << 20, 4 << 30, 16 << 30])
+def test_plan_equals_oracle_sizing(B, O, st_size):
+    """open_stream_out / rzip_fd sizing: product (stream_layer.cpp) vs oracle (container_oracle.c)."""
+    import ctypes
+    for level in (5, 7, 9):
+        for threads, procs in ((1, 1), (4, 8), (8, 8), (64, 256), (256, 256)):
+            for ram in (80 * 100 << 20, 16 << 30, 3000 << 30):
+                for window in (0, 1, 21):
+                    for nc in (False, True):
+                        c, chunk = B.plan(st_size, level=level, threads=threads, processors=procs, ramsize=ram,
+                                          window=window, no_compress=nc)
+                        p = O.Params()
+                        O.lib().lrzo_params_default(ctypes.byref(p))
+                        p.compression_level, p.threads, p.processors, p.ramsize = level, threads, procs, ram
+                        p.window, p.no_compress = window, int(nc)
+                        fs = O.FileStats()
+                        O.lib().lrzo_plan(ctypes.byref(p), st_size, ctypes.byref(fs))
+                        key = (st_size, level, threads, procs, ram, window, nc)
+                        assert c.stream_bufsize == fs.stream_bufsize, key
+                        assert c.threads_used == fs.threads_used and c.dictSize_used == fs.dict_size, key
+
+
+def test_container_store_equals_oracle_no_compress(B, O):
+    """Block order, headers, chaining, magic: product container writer vs oracle for -n, 1 and 3 chunks."""
+    data = datagen.long_range(3 * 1048576 + 17, seed=2) + datagen.random_bytes(1500000, seed=3)
+    for window_bytes in (0, 2 << 20):
+        # emulate -w with a chunk size below 100 MiB via ramsize: max_chunk = ramsize/3*2
+        ram = 80 * 100 << 20 if not window_bytes else window_bytes * 3 // 2
+        want, fs = O.compress_buffer(data, no_compress=1, threads=1, ramsize=ram)
+        c, chunk = B.plan(len(data), no_compress=True, threads=1, ramsize=ram)
+        sizes, s0s, s1s = [], [], []
+        off, vr = 0, 0
+        while off < len(data) or not sizes:
+            n = min(chunk, len(data) - off)
+            s0, s1, st, crc, vr = O.rzip_chunk(data[off:off + n], level=7, chunk_bytes=B.chunk_bytes_for(n), victim_round=vr)
+            sizes.append(n); s0s.append(s0); s1s.append(s1)
+            off += n
+        assert len(sizes) == fs.n_chunks
+        got = B.container_store(len(data), sizes, s0s, s1s, hashlib.md5(data).digest(), no_compress=True, threads=1, ramsize=ram)
+        assert got == want
+
+
+def test_container_store_tiny_inputs(B, O):
+    for n in (0, 1, 30, 31, 100):
+        data = datagen.text_like(n, seed=4)
+        want, _ = O.compress_buffer(data, no_compress=1, threads=1)
+        s0, s1, st, crc, vr = O.rzip_chunk(data, level=7)
+        got = B.container_store(n, [n], [s0], [s1], hashlib.md5(data).digest(), no_compress=True, threads=1)
+        assert got == want, n
+
+
+def test_hash_index_frozen_table(B, O):
+    a = (C.c_uint64 * 256)()
+    B.lib().lrzgpu_hash_index(a)
+    assert list(a) == O.hash_index()

@@ -1,0 +1,60 @@
+"""GPU parity of the rzip scan (tags, hash-table automaton, match extension, literal gather, CRC)
+against the oracle restatement of src/rzip.c hash_search, through the C ABI."""
+import zlib
+
+import pytest
+
+import datagen
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(B, O, data, level, victim_round=0):
+    o0, o1, ost, ocrc, ovr = O.rzip_chunk(data, level=level, victim_round=victim_round)
+    g0, g1, gst, gcrc, gvr = B.hash_search(data, level=level, victim_round=victim_round)
+    assert gcrc == ocrc == (zlib.crc32(data) & 0xFFFFFFFF)
+    assert g0 == o0, ("stream0", len(g0), len(o0))
+    assert g1 == o1, ("stream1", len(g1), len(o1))
+    assert gvr == ovr
+    for f in ("matches", "match_bytes", "literals", "literal_bytes", "inserts", "lookups", "tag_hits", "tag_misses",
+              "hash_count", "tag_clean_ptr", "minimum_tag_mask", "tag_mask"):
+        assert getattr(gst, f) == getattr(ost, f), f
+    return gst
+
+
+@pytest.mark.parametrize("n", [0, 1, 30, 31, 32, 61, 62, 63, 100, 4095, 4096, 4097, 70000])
+@pytest.mark.parametrize("kind", ["text", "zeros", "few", "longrange"])
+def test_tiny_chunks(B, O, kind, n):
+    _check(B, O, datagen.KINDS[kind](n, seed=3), level=7)
+
+
+@pytest.mark.parametrize("level", [1, 4, 6, 7, 9])
+@pytest.mark.parametrize("kind", ["text", "random", "few", "phrases", "sparse", "zeros", "longrange"])
+def test_scan_equals_oracle(B, O, kind, level):
+    n = 3 * 1048576 + 777
+    _check(B, O, datagen.KINDS[kind](n, seed=level + 11), level=level)
+
+
+def test_table_fill_and_clean_sweeps(B, O):
+    """Large enough that the L7 table (2.8M entries) fills and the clean sweep wraps several times."""
+    n = 48 * 1048576 + 5
+    st = _check(B, O, datagen.text_like(n, seed=21), level=7)
+    assert st.minimum_tag_mask > 1
+    # small table (level 1): many mask generations on a few MiB
+    st = _check(B, O, datagen.random_bytes(6 * 1048576, seed=22), level=1)
+    assert st.minimum_tag_mask > 15
+
+
+def test_long_range_copy(B, O):
+    """Half of the chunk is a copy of the other half at 12 MiB distance, with sparse mutations."""
+    data = datagen.long_range(24 * 1048576, seed=5, base_frac=0.5, mutate_every=70001)
+    st = _check(B, O, data, level=7)
+    assert st.match_bytes > 11 * 1048576
+
+
+def test_victim_round_carry(B, O):
+    """Many identical tags force the round-robin victim path; the static victim_round is carried in/out."""
+    pat = (b"0123456789abcdefghijklmnopqrstu" * 40 + b"XYZ") * 3000
+    for vr in (0, 5):
+        _check(B, O, pat, level=7, victim_round=vr)
+        _check(B, O, pat, level=4, victim_round=vr % 3)
