@@ -117,6 +117,8 @@ int compute_sizing(const lrzgpu_control *c, int64_t st_size, Sizing *out)
 			break;
 		}
 	}
+	if (s.threads < 1)
+		return LRZGPU_E_PARAM; // ramsize too small for any LZMA thread (the reference divides by zero here)
 	if (st_size > 0 && st_size < limit)
 		limit = st_size > STREAM_BUFSIZE ? st_size : STREAM_BUFSIZE;
 	else if (limit > chunk_limit)
