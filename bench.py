@@ -41,7 +41,7 @@ class Profile(C.Structure):
                                           "lz4_launches", "mf_launches", "tag_scan_positions", "resolve_lookups",
                                           "resolve_inserts", "resolve_match_bytes", "crc_bytes", "gather_bytes",
                                           "lz4_bytes", "mf_positions", "mf_entries")] + \
-               [("scan_wall_ms", C.c_double)]
+               [("scan_wall_ms", C.c_double), ("resolve_dbg", C.c_int64 * 16)]
 
 
 def text_like_torch(n, seed, device, piece=256 << 20):
@@ -198,7 +198,11 @@ def main():
                     "per_kernel_ms": {k: round(v[0], 2) for k, v in kernels.items()},
                     "per_kernel_GBps": {k: (round(v[2] / (v[0] * 1e-3) / 1e9, 3) if v[0] > 0 else 0.0)
                                         for k, v in kernels.items()},
-                    "scan_wall_ms": round(prof.scan_wall_ms, 1)}
+                    "scan_wall_ms": round(prof.scan_wall_ms, 1),
+                    "resolver": dict(zip(("batches", "committed", "serial_steps", "stop_complex", "stop_match",
+                                          "stop_conflict", "stop_novictim", "stop_sweptrange", "cyc_refill",
+                                          "cyc_simulate", "cyc_victims", "cyc_conflict", "cyc_apply", "cyc_tail", "cyc_verify", "cyc_displace"),
+                                         [int(v) for v in prof.resolve_dbg]))}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(min(args.cpu_sample_mib << 20, n_bytes), ctl_kw, cores)

@@ -150,6 +150,9 @@ typedef struct lrzgpu_profile {
 	int64_t mf_positions;         /* block bytes through the match finder                 */
 	int64_t mf_entries;           /* u32 match-list entries produced                      */
 	double scan_wall_ms;          /* host wall time inside scan_chunk_device              */
+	int64_t resolve_dbg[16];      /* batches, committed lanes, serial steps, stops: complex, match,
+	                                 conflict, no-victim, swept-range; [8..13] shader cycles in
+	                                 refill, simulate, victim scan, conflict test, apply, tail */
 } lrzgpu_profile;
 void lrzgpu_profile_reset(void);
 void lrzgpu_profile_get(lrzgpu_profile *out);

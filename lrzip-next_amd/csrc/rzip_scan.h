@@ -32,10 +32,14 @@ struct ScanState {
 	// statistics (reference st->stats)
 	int64_t inserts, lookups, tag_hits, tag_misses;
 	uint64_t sink; // keeps prefetch loads alive
+	// resolver diagnostics: batches, committed lanes, serial steps, first-stop reasons
+	// (complex, real match, conflict, no victim in reach, insert inside swept range)
+	int64_t dbg[16]; // [8..15]: shader-clock cycles per phase (refill, simulate, victims, conflict, apply, tail)
 };
 
 struct ScanWorkspace {
 	int hash_bits;
+	int batch_mode;    // 1 = speculative batch resolver, 0 = serial reference path
 	void *table;       // 16 B slots
 	ScanState *state;  // device
 	uint64_t *hx;      // device copy of hash_index[256]

@@ -46,6 +46,9 @@ constexpr int MINIMUM_MATCH = 31; // src/rzip.c:51
 constexpr int GREAT_MATCH = 1024; // src/rzip.c:50
 constexpr int TILE = 4096;        // positions per K1 workgroup
 constexpr int PER_THREAD = 16;
+constexpr int MAX_HITS = 24; // tag hits one speculative lookup may verify (more -> serial path)
+constexpr int CT_BITS = 10; // conflict map: 1024 granule entries for <= 320 writes per round
+constexpr int CT_SIZE = 1 << CT_BITS;
 
 typedef unsigned long long u64;
 typedef long long i64;
@@ -522,14 +525,74 @@ struct Resolver {
 	}
 };
 
+// Per-lane speculative simulation of one automaton step against the table as it stands at the
+// start of a batch (see k_resolve).  Everything it would read lies in [lo, hi]; everything it
+// would write is listed in w_*.
+struct LaneSim {
+	bool complex_;   // must take the serial path (victim round-robin, wrap, deep displacement, ...)
+	bool match;      // a tag hit verifies as a real match (>= MINIMUM_MATCH): batch ends here
+	bool ins;        // (T & tag_mask) == tag_mask
+	int dec;         // insert replaces an entry that was due for cleaning: hash_count--
+	int misses;      // false tag positives met by the lookup
+	int nw;          // table writes of the insert (displacement chain), <= 4
+	uint32_t w_slot[4];
+	u64 w_t[4];
+	i64 w_off[4];
+	uint32_t lo, hi; // inclusive slot interval read
+};
+
+// is there a match of at least MINIMUM_MATCH bytes between p0 and op? (single_match_len() != 0)
+__device__ __forceinline__ bool lane_verify(const uint8_t *buf, i64 p0, i64 op, i64 end, i64 last_match)
+{
+	if (op >= p0)
+		return false;
+	i64 fwd_max = end - p0;
+	if (fwd_max < 0)
+		fwd_max = 0;
+	i64 fwd = 0;
+	const i64 cap = fwd_max < 32 ? fwd_max : 32;
+	while (fwd + 8 <= cap) {
+		u64 a = reinterpret_cast<const U64u *>(buf + p0 + fwd)->v;
+		u64 b = reinterpret_cast<const U64u *>(buf + op + fwd)->v;
+		u64 x = a ^ b;
+		if (x) {
+			fwd += (__ffsll((long long)x) - 1) >> 3;
+			goto fwd_done;
+		}
+		fwd += 8;
+	}
+	while (fwd < cap && buf[p0 + fwd] == buf[op + fwd])
+		fwd++;
+fwd_done:
+	if (fwd >= MINIMUM_MATCH)
+		return true;
+	i64 floor_p = last_match > 0 ? last_match : 0;
+	i64 max_back = p0 - floor_p;
+	if (op < max_back)
+		max_back = op;
+	const i64 need = MINIMUM_MATCH - fwd;
+	if (max_back < need)
+		return false;
+	for (i64 k = 0; k < need; k++)
+		if (buf[p0 - 1 - k] != buf[op - 1 - k])
+			return false;
+	return true;
+}
+
 __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf, Slot *__restrict__ tbl, ScanState *__restrict__ st,
 						i64 seg_lo, int ntiles, const uint32_t *__restrict__ cand_rel,
 						const u64 *__restrict__ cand_tag, const uint32_t *__restrict__ tile_count,
-						MatchRec *__restrict__ records)
+						MatchRec *__restrict__ records, int batch_mode)
 {
 	__shared__ u64 stk_t[64];
 	__shared__ i64 stk_off[64];
 	__shared__ i64 stk_h[64];
+	__shared__ uint32_t vict[64];
+	__shared__ i64 ring_pos[256];
+	__shared__ u64 ring_tag[256];
+	__shared__ i64 hit_lds[MAX_HITS * 64];
+	__shared__ uint32_t ct_key[CT_SIZE];
+	__shared__ uint32_t ct_val[CT_SIZE];
 
 	Resolver R;
 	R.buf = buf;
@@ -558,82 +621,580 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 	i64 inserts = st->inserts, lookups = st->lookups;
 	int error = st->error;
 	u64 sink = 0;
+	i64 dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	u64 tclk = __builtin_amdgcn_s_memtime();
+	auto lap = [&](int slot) {
+		const u64 now = __builtin_amdgcn_s_memtime();
+		dbg[slot] += (i64)(now - tclk);
+		tclk = now;
+	};
 	const int lane = threadIdx.x;
+	const u64 lane_bit = 1ull << lane;
+	const u64 lanes_below = lane_bit - 1;
+	const i64 tbl_size = (i64)R.hmask + 1;
 
-	for (int tile = 0; tile < ntiles && !error; tile++) {
-		const uint32_t cnt = tile_count[tile];
-		const size_t base = (size_t)tile * TILE;
-		// skip whole tiles that lie inside an emitted match
-		if (seg_lo + (i64)(tile + 1) * TILE - 1 <= p_skip)
-			continue;
-		for (uint32_t b0 = 0; b0 < cnt && !error; b0 += 64) {
+	// One exact automaton step at candidate (P, T): the serial path.
+	auto serial_step = [&](i64 P, u64 T) {
+		dbg[2]++;
+		// After an emission the reference resumes at last_match + 1 (src/rzip.c:685-687); when the
+		// emitted match ends BEFORE P -- the emission was delayed until this candidate -- P itself
+		// is examined a second time (it is the only candidate in (last_match, P]).
+		bool again;
+		do {
+			again = false;
+			i64 offset = 0, reverse = 0;
+			lookups++;
+			i64 mlen = R.lookup(T, P, &offset, &reverse);
+
+			if ((T & R.tag_mask) == R.tag_mask) {
+				inserts++;
+				R.hash_count++;
+				R.insert(T, P);
+				if (R.hash_count > R.hash_limit)
+					R.tag_mask = R.clean_one();
+			}
+			if (mlen > cur_len) {
+				cur_p = P - reverse;
+				cur_len = mlen;
+				cur_ofs = offset;
+			}
+			if ((cur_len >= GREAT_MATCH || P >= cur_p + MINIMUM_MATCH) && cur_len >= MINIMUM_MATCH) {
+				if (n_rec >= rec_cap) {
+					error = 1;
+					return;
+				}
+				if (lane == 0) {
+					MatchRec r;
+					r.p = cur_p;
+					r.ofs = cur_ofs;
+					r.len = cur_len;
+					records[n_rec] = r;
+				}
+				n_rec++;
+				R.last_match = cur_p + cur_len;
+				p_skip = R.last_match;
+				cur_p = R.last_match;
+				cur_len = 0;
+				again = P > p_skip && P <= R.end && (T & R.min_mask) == R.min_mask;
+			}
+		} while (again);
+	};
+
+	// ---- candidate stream: compacted (pos, tag) queue in LDS, refilled from the K1 tiles ----
+	int tile = 0;
+	uint32_t tb0 = 0;
+	int ring_head = 0, ring_cnt = 0;
+	auto refill_ring = [&]() {
+		while (ring_cnt <= 192 && tile < ntiles) {
+			const uint32_t cnt = tile_count[tile];
+			if (tb0 >= cnt || seg_lo + (i64)(tile + 1) * TILE - 1 <= p_skip) { // exhausted / inside a match
+				tile++;
+				tb0 = 0;
+				continue;
+			}
+			const size_t base = (size_t)tile * TILE;
 			i64 pos = -1;
 			u64 tag = 0;
-			if (b0 + lane < cnt) {
-				pos = seg_lo + (i64)cand_rel[base + b0 + lane];
-				tag = cand_tag[base + b0 + lane];
+			if (tb0 + lane < cnt) {
+				pos = seg_lo + (i64)cand_rel[base + tb0 + lane];
+				tag = cand_tag[base + tb0 + lane];
 			}
-			bool valid = pos > p_skip && (tag & R.min_mask) == R.min_mask;
-			// warm L2 with the bucket windows of the whole batch while the first ones resolve
-			if (valid) {
-				const u64 *w = reinterpret_cast<const u64 *>(&tbl[tag & R.hmask]);
-				sink ^= __builtin_nontemporal_load(w + 1);
+			const bool ok = pos > p_skip && (tag & R.min_mask) == R.min_mask;
+			const u64 m = __ballot(ok);
+			if (ok) {
+				const int slot = (ring_head + ring_cnt + __popcll(m & lanes_below)) & 255;
+				ring_pos[slot] = pos;
+				ring_tag[slot] = tag;
 			}
-			u64 todo = __ballot(valid);
-			while (todo && !error) {
-				const int i = __ffsll((long long)todo) - 1;
-				todo &= todo - 1;
-				const i64 P = (i64)bcast64((u64)pos, i);
-				const u64 T = bcast64(tag, i);
-				if (P <= p_skip)
-					continue;
-				if ((T & R.min_mask) != R.min_mask)
-					continue;
+			ring_cnt += __popcll(m);
+			tb0 += 64;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	};
 
-				// One automaton step at position P.  After an emission the reference resumes at
-				// last_match + 1 (src/rzip.c:685-687); when the emitted match ends BEFORE P -- the
-				// emission was delayed until this candidate -- P itself is examined a second time
-				// (it is the only candidate in (last_match, P], any other would have emitted earlier).
-				bool again;
-				do {
-					again = false;
-					i64 offset = 0, reverse = 0;
-					lookups++;
-					i64 mlen = R.lookup(T, P, &offset, &reverse);
+	// ---- in-order window of up to 64 candidates, one per lane (lane order = candidate order) ----
+	int wcount = 0;
+	i64 w_pos = -1;
+	u64 w_tag = 0;
+	bool w_simd = false;
+	LaneSim L;
+	L.complex_ = L.match = L.ins = false;
+	L.dec = L.misses = L.nw = 0;
+	L.lo = L.hi = 0;
+	for (int k = 0; k < 4; k++) {
+		L.w_slot[k] = 0;
+		L.w_t[k] = 0;
+		L.w_off[k] = 0;
+	}
+	auto shift_window = [&](int c) { // drop the first c lanes
+		if (c <= 0)
+			return;
+		const int src = (lane + c) & 63;
+		w_pos = (i64)bcast64((u64)w_pos, src);
+		w_tag = bcast64(w_tag, src);
+		w_simd = __shfl((int)w_simd, src) != 0;
+		L.complex_ = __shfl((int)L.complex_, src) != 0;
+		L.match = __shfl((int)L.match, src) != 0;
+		L.ins = __shfl((int)L.ins, src) != 0;
+		L.dec = __shfl(L.dec, src);
+		L.misses = __shfl(L.misses, src);
+		L.nw = __shfl(L.nw, src);
+		L.lo = __shfl(L.lo, src);
+		L.hi = __shfl(L.hi, src);
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			L.w_slot[k] = __shfl(L.w_slot[k], src);
+			L.w_t[k] = bcast64(L.w_t[k], src);
+			L.w_off[k] = (i64)bcast64((u64)L.w_off[k], src);
+		}
+		wcount -= c;
+		if (lane >= wcount)
+			w_simd = false;
+	};
 
-					if ((T & R.tag_mask) == R.tag_mask) {
-						inserts++;
-						R.hash_count++;
-						R.insert(T, P);
-						if (R.hash_count > R.hash_limit)
-							R.tag_mask = R.clean_one();
+	while (!error) {
+		lap(13);
+		refill_ring();
+		// top up the window from the queue
+		{
+			int k = 64 - wcount;
+			if (k > ring_cnt)
+				k = ring_cnt;
+			if (k > 0) {
+				if (lane >= wcount && lane < wcount + k) {
+					const int slot = (ring_head + lane - wcount) & 255;
+					w_pos = ring_pos[slot];
+					w_tag = ring_tag[slot];
+					w_simd = false;
+				}
+				ring_head = (ring_head + k) & 255;
+				ring_cnt -= k;
+				wcount += k;
+			}
+		}
+		if (wcount == 0)
+			break;
+
+		const bool has = lane < wcount;
+		const bool alive = has && w_pos > p_skip && (w_tag & R.min_mask) == R.min_mask;
+
+		// ---- serial path: pending lazy match, or batching disabled ----
+		if (!batch_mode || cur_len > 0) {
+			const i64 P = (i64)bcast64((u64)w_pos, 0);
+			const u64 T = bcast64(w_tag, 0);
+			const bool a0 = __shfl((int)alive, 0) != 0;
+			shift_window(1);
+			if (a0)
+				serial_step(P, T);
+			w_simd = false; // the table changed in ways the sims did not see
+			continue;
+		}
+
+		const u64 better = mask_up(R.min_mask);
+		lap(8);
+
+		// Phase A/B: lanes without a valid simulation run one against the table as it stands.
+		// The three sub-phases are wave-convergent so that every dependent HBM round trip is
+		// shared by all simulating lanes: (A1) lookup walk in 8-slot chunks, (A2) verification of
+		// tag hits, (A3) the displacement chain of the insert, one level at a time.
+		const bool need_sim = alive && !w_simd;
+		if (__ballot(need_sim)) {
+			const u64 T = w_tag;
+			const i64 P = w_pos;
+			const int my_rank = bitness_rank(T);
+			int kind = -1; // insert stop: 0 empty, 1 due for cleaning, 2 lesser bitness
+			i64 sidx = 0;
+			Slot occ;
+			occ.offset = 0;
+			occ.t = 0;
+			int nhit = 0; // tag hits met by the lookup walk, offsets parked in LDS (hit_lds)
+			// ---- A1: lookup walk to the first empty slot ----
+			{
+				i64 idx = (i64)(T & R.hmask);
+				uint32_t neq = 0;
+				int steps = 0;
+				bool fin = !need_sim;
+				if (need_sim) {
+					L.complex_ = false;
+					L.match = false;
+					L.dec = 0;
+					L.misses = 0;
+					L.nw = 0;
+					L.ins = (T & R.tag_mask) == R.tag_mask;
+					L.lo = (uint32_t)idx;
+					L.hi = (uint32_t)idx;
+				}
+				while (__ballot(!fin)) {
+					if (!fin) {
+						Slot c8[8];
+#pragma unroll
+						for (int q = 0; q < 8; q++)
+							c8[q] = tbl[idx + q]; // the table is padded by 64 slots
+#pragma unroll
+						for (int q = 0; q < 8; q++) {
+							if (!fin) {
+								if (idx + q >= tbl_size || ++steps > 192) {
+									L.complex_ = true;
+									L.hi = (uint32_t)(tbl_size - 1 < idx + q ? tbl_size - 1 : idx + q);
+									fin = true;
+								} else {
+									const Slot sl = c8[q];
+									const bool empty = !(sl.offset | (i64)sl.t);
+									if (kind < 0 && L.ins) {
+										if (empty) {
+											kind = 0;
+											sidx = idx + q;
+										} else if ((sl.t & better) != better) {
+											kind = 1;
+											sidx = idx + q;
+										} else if (bitness_rank(sl.t) < my_rank) {
+											kind = 2;
+											sidx = idx + q;
+											occ = sl;
+										} else if (sl.t == T) {
+											if (++neq >= R.max_chain)
+												L.complex_ = true; // round-robin victim path
+										}
+									}
+									if (empty) {
+										L.hi = (uint32_t)(idx + q);
+										fin = true;
+									} else if (sl.t == T) {
+										if (nhit < MAX_HITS)
+											hit_lds[nhit * 64 + lane] = sl.offset;
+										else
+											L.complex_ = true;
+										nhit++;
+									}
+								}
+							}
+						}
+						idx += 8;
 					}
-					if (mlen > cur_len) {
-						cur_p = P - reverse;
-						cur_len = mlen;
-						cur_ofs = offset;
+				}
+			}
+			lap(9);
+			// ---- A2: are the tag hits real matches (>= MINIMUM_MATCH)? ----
+#pragma unroll 1
+			for (int k = 0; k < MAX_HITS; k++) {
+				const bool act = need_sim && k < nhit && !L.match && !L.complex_;
+				if (!__ballot(act))
+					break;
+				if (act) {
+					if (lane_verify(buf, P, hit_lds[k * 64 + lane], R.end, R.last_match))
+						L.match = true;
+					else
+						L.misses++;
+				}
+			}
+			lap(14);
+			// ---- A3: displacement chain of the insert, level by level ----
+			{
+				u64 cur_t = T;
+				i64 cur_off = P;
+				bool chain = need_sim && L.ins && !L.complex_ && !L.match;
+#pragma unroll 1
+				for (int level = 0; level < 5; level++) {
+					if (!__ballot(chain))
+						break;
+					bool walk = false;
+					i64 j = 0;
+					int r2 = 0;
+					if (chain) {
+						if (L.nw == 4) {
+							L.complex_ = true;
+							chain = false;
+						} else {
+#pragma unroll
+							for (int k = 0; k < 4; k++)
+								if (k == L.nw) {
+									L.w_slot[k] = (uint32_t)sidx;
+									L.w_t[k] = cur_t;
+									L.w_off[k] = cur_off;
+								}
+							L.nw++;
+							if ((uint32_t)sidx > L.hi)
+								L.hi = (uint32_t)sidx;
+							if (kind == 0) {
+								chain = false;
+							} else if (kind == 1) {
+								L.dec = 1;
+								chain = false;
+							} else {
+								// lesser-bitness occupant: it is re-inserted from its own bucket
+								cur_t = occ.t;
+								cur_off = occ.offset;
+								r2 = bitness_rank(cur_t);
+								j = (i64)(cur_t & R.hmask);
+								if ((uint32_t)j < L.lo)
+									L.lo = (uint32_t)j;
+								kind = -1;
+								walk = true;
+							}
+						}
 					}
-					if ((cur_len >= GREAT_MATCH || P >= cur_p + MINIMUM_MATCH) && cur_len >= MINIMUM_MATCH) {
-						if (n_rec >= rec_cap) {
-							error = 1;
+					uint32_t neq2 = 0;
+					int st2 = 0;
+					while (__ballot(walk)) {
+						if (walk) {
+							Slot c8[8];
+#pragma unroll
+							for (int q = 0; q < 8; q++)
+								c8[q] = tbl[j + q];
+#pragma unroll
+							for (int q = 0; q < 8; q++) {
+								if (walk) {
+									if (j + q >= tbl_size || ++st2 > 192) {
+										L.complex_ = true;
+										chain = false;
+										walk = false;
+									} else {
+										const Slot sl = c8[q];
+										const bool empty = !(sl.offset | (i64)sl.t);
+										if (empty) {
+											kind = 0;
+										} else if ((sl.t & better) != better) {
+											kind = 1;
+										} else if (bitness_rank(sl.t) < r2) {
+											kind = 2;
+											occ = sl;
+										} else if (sl.t == cur_t) {
+											if (++neq2 >= R.max_chain) {
+												L.complex_ = true;
+												chain = false;
+												walk = false;
+											}
+										}
+										if (kind >= 0 && walk) {
+											sidx = j + q;
+											walk = false;
+										}
+									}
+								}
+							}
+							j += 8;
+						}
+					}
+				}
+				if (chain)
+					L.complex_ = true; // deeper than the write list allows
+			}
+			if (need_sim)
+				w_simd = true;
+			lap(15);
+		}
+
+
+		lap(9);
+		// Phase C: in-order commit of the longest conflict-free prefix, computed in parallel.
+		// hash_count saturates at hash_limit: every insert that pushes it over triggers exactly
+		// one clean (src/rzip.c:665-671).
+		const bool live = alive; // dead lanes (inside a match / mask tightened) commit as no-ops
+		const int x = (live && L.ins && !L.dec && !L.complex_ && !L.match) ? 1 : 0;
+		int px = x;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			int o = __shfl_up(px, d);
+			if (lane >= d)
+				px += o;
+		}
+		const i64 hc_before = R.hash_count + (px - x) < R.hash_limit ? R.hash_count + (px - x) : R.hash_limit;
+		const bool cleans = x && hc_before + 1 > R.hash_limit;
+		const u64 clean_m = __ballot(cleans);
+		const int kth = __popcll(clean_m & lanes_below);
+		const int want = __popcll(clean_m);
+
+		// victim list: the next `want` entries the sweep would delete, in sweep order
+		int nv = 0;
+		i64 scan_end = R.clean_ptr;
+		if (want) {
+			i64 ptr = R.clean_ptr;
+			int rounds = 0;
+			while (nv < want && ptr < tbl_size && rounds < 512) {
+				const i64 q = ptr + lane;
+				bool cand = false;
+				if (q < tbl_size) {
+					const Slot s = tbl[q];
+					cand = (s.offset | (i64)s.t) && (s.t & better) != better;
+				}
+				const u64 m = __ballot(cand);
+				const int r = nv + __popcll(m & lanes_below);
+				if (cand && r < 64)
+					vict[r] = (uint32_t)q;
+				nv += __popcll(m);
+				ptr += 64;
+				rounds++;
+			}
+			scan_end = ptr < tbl_size ? ptr : tbl_size;
+			if (nv > 64)
+				nv = 64;
+		}
+		lap(10);
+		uint32_t my_vict = 0xFFFFFFFFu;
+		int why = 0; // 3 complex, 4 match, 5 conflict, 6 no victim, 7 swept range
+		bool stop = false;
+		if (live && L.complex_) {
+			stop = true;
+			why = 3;
+		} else if (live && L.match) {
+			stop = true;
+			why = 4;
+		}
+		if (cleans) {
+			if (kth < nv)
+				my_vict = vict[kth];
+			else if (!stop) {
+				stop = true; // sweep wrap / no victim in reach: serial path
+				why = 6;
+			}
+		}
+		// the first clean of a chunk switches tag_mask from the initial mask to `better`
+		// (src/rzip.c:669-671): lanes after it were simulated with the old insert mask
+		if (R.tag_mask != better && clean_m && live && !stop && lane > __ffsll((long long)clean_m) - 1) {
+			stop = true;
+			why = 3;
+		}
+		// an insert landing inside the swept range could change what the sweep meets
+		if (live && want && !stop)
+			for (int k = 0; k < 4; k++)
+				if (k < L.nw && (i64)L.w_slot[k] >= R.clean_ptr && (i64)L.w_slot[k] < scan_end) {
+					stop = true;
+					why = 7;
+				}
+		// conflicts: the EARLIEST lane whose write (insert, displacement or clean) lies inside my
+		// read interval.  Writes are published as 8-slot granules in a small LDS hash map
+		// (granule -> lowest writing lane); every lane then looks up the granules its interval covers.
+		for (int k = lane; k < CT_SIZE; k += 64) {
+			ct_key[k] = 0xFFFFFFFFu;
+			ct_val[k] = 64;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		if (live) {
+#pragma unroll
+			for (int k = 0; k < 5; k++) {
+				uint32_t wslot = 0xFFFFFFFFu;
+				if (k < 4) {
+					if (k < L.nw)
+						wslot = L.w_slot[k];
+				} else
+					wslot = my_vict;
+				if (wslot != 0xFFFFFFFFu) {
+					const uint32_t g = wslot >> 3;
+					uint32_t h = (g * 2654435761u) >> (32 - CT_BITS);
+					for (;;) {
+						const uint32_t old = atomicCAS(&ct_key[h], 0xFFFFFFFFu, g);
+						if (old == 0xFFFFFFFFu || old == g) {
+							atomicMin(&ct_val[h], (uint32_t)lane);
 							break;
 						}
-						if (lane == 0) {
-							MatchRec r;
-							r.p = cur_p;
-							r.ofs = cur_ofs;
-							r.len = cur_len;
-							records[n_rec] = r;
-						}
-						n_rec++;
-						R.last_match = cur_p + cur_len;
-						p_skip = R.last_match;
-						cur_p = R.last_match;
-						cur_len = 0;
-						again = P > p_skip && P <= R.end && (T & R.min_mask) == R.min_mask;
+						h = (h + 1) & (CT_SIZE - 1);
 					}
-				} while (again);
+				}
 			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		int first_conf = 64;
+		if (live) {
+			const uint32_t g1 = L.hi >> 3;
+			for (uint32_t g = L.lo >> 3; g <= g1; g++) {
+				uint32_t h = (g * 2654435761u) >> (32 - CT_BITS);
+				for (;;) {
+					const uint32_t k = ct_key[h];
+					if (k == 0xFFFFFFFFu)
+						break;
+					if (k == g) {
+						const int v = (int)ct_val[h];
+						if (v < lane && v < first_conf)
+							first_conf = v;
+						break;
+					}
+					h = (h + 1) & (CT_SIZE - 1);
+				}
+			}
+		}
+		const bool conflict = first_conf < 64;
+		lap(11);
+		if (!stop && conflict)
+			why = 5;
+		const u64 bad = __ballot(live && (stop || conflict));
+		int f = bad ? __ffsll((long long)bad) - 1 : 64;
+		if (f > wcount)
+			f = wcount;
+		dbg[0]++;
+		const int why_f = f < 64 ? __shfl(why, f) : 0;
+		if (f < wcount && why_f >= 3 && why_f <= 7)
+			dbg[why_f]++;
+		const bool committed = lane < f && live;
+
+		// Phase D: apply the committed prefix
+		if (committed) {
+			for (int k = 0; k < 4; k++)
+				if (k < L.nw) {
+					Slot w;
+					w.offset = L.w_off[k];
+					w.t = L.w_t[k];
+					tbl[L.w_slot[k]] = w;
+				}
+			if (cleans) {
+				Slot z;
+				z.offset = 0;
+				z.t = 0;
+				tbl[my_vict] = z;
+			}
+		}
+		{
+			const u64 cm = __ballot(committed);
+			const int n_commit = __popcll(cm);
+			int my_miss = committed ? L.misses : 0;
+			int my_ins = (committed && L.ins) ? 1 : 0;
+			int my_x = committed ? x : 0;
+#pragma unroll
+			for (int d = 32; d >= 1; d >>= 1) {
+				my_miss += __shfl_xor(my_miss, d);
+				my_ins += __shfl_xor(my_ins, d);
+				my_x += __shfl_xor(my_x, d);
+			}
+			lookups += n_commit;
+			dbg[1] += n_commit;
+			inserts += my_ins;
+			R.tag_misses += my_miss;
+			const i64 hc = R.hash_count + my_x;
+			R.hash_count = hc < R.hash_limit ? hc : R.hash_limit;
+			const u64 cc = clean_m & cm;
+			if (cc) {
+				const int last = 63 - __clzll((long long)cc);
+				R.clean_ptr = (i64)__shfl(my_vict, last);
+				if (R.tag_mask != better)
+					w_simd = false; // the insert mask changed: every kept simulation is stale
+				R.tag_mask = better; // clean_one_from_hash() returns better_than_min
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+		lap(12);
+		// simulations that read something a committed lane has just written are stale
+		if (first_conf < f)
+			w_simd = false;
+		if (f < wcount) {
+			if (why_f == 5) {
+				// conflict only: lane f re-simulates against the updated table next round
+				if (lane == f)
+					w_simd = false;
+				shift_window(f);
+			} else {
+				// complex / real match / sweep wrap / swept range: exact serial step (progress)
+				const i64 P = (i64)bcast64((u64)w_pos, f);
+				const u64 T = bcast64(w_tag, f);
+				shift_window(f + 1);
+				serial_step(P, T);
+				w_simd = false;
+			}
+		} else {
+			shift_window(f);
 		}
 	}
 
@@ -654,6 +1215,8 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		st->lookups = lookups;
 		st->tag_hits = R.tag_hits;
 		st->tag_misses = R.tag_misses;
+		for (int k = 0; k < 16; k++)
+			st->dbg[k] += dbg[k];
 	}
 	// keep the prefetch loads observable
 	u64 any = sink;
@@ -892,7 +1455,11 @@ int scan_workspace_create(ScanWorkspace **out, int rzip_level, int64_t max_chunk
 	HIPCHK(hipMalloc(&w->table, ((size_t)16 << w->hash_bits) + 64 * 16));
 	HIPCHK(hipMalloc(&w->state, sizeof(ScanState)));
 	HIPCHK(hipMalloc(&w->hx, 256 * 8));
-	w->seg_cap = (size_t)1 << 30; // up to 1 GiB of positions per segment
+	{
+		const char *e = getenv("LRZGPU_RESOLVE_SERIAL");
+		w->batch_mode = (e && *e == '1') ? 0 : 1;
+	}
+	w->seg_cap = (size_t)1 << 28; // up to 256 Mi positions per segment
 	if ((int64_t)w->seg_cap > max_chunk + TILE)
 		w->seg_cap = (size_t)(((max_chunk + TILE) / TILE + 1) * TILE);
 	HIPCHK(hipMalloc(&w->cand_rel, w->seg_cap * 4));
@@ -964,7 +1531,8 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 		t1.stop();
 		EventTimer t2(s);
 		hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), 0, s, d_chunk, (Slot *)w->table, w->state, (i64)seg_lo, ntiles,
-				   (const uint32_t *)w->cand_rel, (const u64 *)w->cand_tag, (const uint32_t *)w->tile_count, w->records);
+				   (const uint32_t *)w->cand_rel, (const u64 *)w->cand_tag, (const uint32_t *)w->tile_count, w->records,
+				   w->batch_mode);
 		t2.stop();
 		HIPCHK(hipMemcpyAsync(&h, w->state, sizeof(h), hipMemcpyDeviceToHost, s));
 		HIPCHK(hipStreamSynchronize(s));
@@ -1007,6 +1575,8 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 		ps.p.resolve_lookups += h.lookups;
 		ps.p.resolve_inserts += h.inserts;
 		ps.p.resolve_match_bytes += mb;
+		for (int k = 0; k < 16; k++)
+			ps.p.resolve_dbg[k] += h.dbg[k];
 		ps.p.scan_wall_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
 	}
 	return 0;
