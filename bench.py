@@ -44,14 +44,25 @@ class Profile(C.Structure):
                [("scan_wall_ms", C.c_double), ("resolve_dbg", C.c_int64 * 16)]
 
 
-def text_like_torch(n, seed, device, piece=256 << 20):
-    """Seeded word-list pseudo text (5000 lowercase words of 2..9 letters, space separated)."""
+ALPHABETS = {
+    # 62 symbols: what source code / logs / mixed text look like to rzip's XOR tag.  The tag of a
+    # 31-byte window only depends on the PARITY of each byte value's count, so a 27-symbol alphabet
+    # collapses the tag space to 2^27 values and every bucket saturates at max_chain_len entries
+    # (the degenerate case of src/rzip.c's hash, kept available as --alphabet lower).
+    "alnum": b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789",
+    "lower": b"abcdefghijklmnopqrstuvwxyz",
+}
+
+
+def text_like_torch(n, seed, device, piece=256 << 20, alphabet="alnum"):
+    """Seeded word-list pseudo text: 5000 words of 2..9 symbols, space separated."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     nwords = 5000
+    abc = torch.tensor(list(ALPHABETS[alphabet]), dtype=torch.uint8, device=device)
     wl = torch.randint(2, 10, (nwords,), generator=g, device=device)
-    chars = torch.randint(97, 123, (nwords, 10), generator=g, device=device, dtype=torch.uint8)
+    chars = abc[torch.randint(0, len(abc), (nwords, 10), generator=g, device=device)]
     out = torch.empty(n, dtype=torch.uint8, device=device)
     done = 0
     while done < n:
@@ -72,11 +83,11 @@ def text_like_torch(n, seed, device, piece=256 << 20):
     return out
 
 
-def make_workload(n_bytes, seed, device):
+def make_workload(n_bytes, seed, device, alphabet="alnum"):
     """50 % long-range redundant: first half seeded text, second half an identical copy."""
     import torch
     half = n_bytes // 2
-    base = text_like_torch(half, seed, device)
+    base = text_like_torch(half, seed, device, alphabet=alphabet)
     buf = torch.empty(n_bytes + 256, dtype=torch.uint8, device=device)  # 256 B of readable padding
     buf[:half] = base
     buf[half:2 * half] = base
@@ -84,7 +95,7 @@ def make_workload(n_bytes, seed, device):
     return buf
 
 
-def cpu_baseline(sample_bytes, ctl_kw, cores):
+def cpu_baseline(sample_bytes, ctl_kw, cores, alphabet="alnum"):
     """Oracle driver (CPU restatement of rzip/lz4/container + the reference's own LZMA build) on a
     bounded sample of the same workload shape, all host cores as block-compression workers."""
     import oracle_lib as O
@@ -92,7 +103,7 @@ def cpu_baseline(sample_bytes, ctl_kw, cores):
     O.build()
     if O.ref_lzma() is None:
         return None
-    data = bytes(make_workload(sample_bytes, 1, "cpu")[:sample_bytes].numpy())
+    data = bytes(make_workload(sample_bytes, 1, "cpu", alphabet)[:sample_bytes].numpy())
     t0 = time.time()
     out, fs = O.compress_buffer(data, compression_level=ctl_kw["level"], threads=ctl_kw["threads"],
                                 processors=ctl_kw["processors"], ramsize=ctl_kw["ramsize"], workers=cores)
@@ -114,6 +125,8 @@ def main():
     ap.add_argument("--cpu-sample-mib", type=int, default=int(os.environ.get("LRZGPU_CPU_SAMPLE_MIB", "128")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--threads", type=int, default=0, help="-p (default: host cores)")
+    ap.add_argument("--alphabet", choices=sorted(ALPHABETS), default="alnum")
+    ap.add_argument("--gpu-slots", type=int, default=8)
     args = ap.parse_args()
 
     import torch
@@ -141,11 +154,11 @@ def main():
     ctl_kw = dict(level=7, threads=threads, processors=cores, ramsize=phys)
     n_bytes = args.mib << 20
 
-    buf = make_workload(n_bytes, 1 + rank, dev)
+    buf = make_workload(n_bytes, 1 + rank, dev, args.alphabet)
     torch.cuda.synchronize()
 
     def one_step():
-        ctl = B.make_control(device=local_rank, host_threads=threads, gpu_slots=4, **ctl_kw)
+        ctl = B.make_control(device=local_rank, host_threads=threads, gpu_slots=args.gpu_slots, **ctl_kw)
         out, ctl = B.compress_device(buf.data_ptr(), n_bytes, ctl=ctl)
         return out, ctl
 
@@ -205,13 +218,14 @@ def main():
                                          [int(v) for v in prof.resolve_dbg]))}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(min(args.cpu_sample_mib << 20, n_bytes), ctl_kw, cores)
+            cpu = cpu_baseline(min(args.cpu_sample_mib << 20, n_bytes), ctl_kw, cores, args.alphabet)
         line = {
             "metric": "compress MB/s (input) at -L7 lzma", "value": round(value, 2), "unit": "MB/s (2^20 B/s)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1000 / args.steps, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%d MiB synthetic 50%%-long-range-redundant buffer (seeded word-list text + identical "
-                                   "copy), -L7 lzma, single rzip chunk per GPU, input resident in HBM" % args.mib,
+            "config": {"workload": "%d MiB synthetic 50%%-long-range-redundant buffer (seeded 5000-word text over the "
+                                   "%d-symbol '%s' alphabet + identical copy at distance n/2), -L7 lzma, single rzip "
+                                   "chunk per GPU, input resident in HBM" % (args.mib, len(ALPHABETS[args.alphabet]), args.alphabet),
                        "flags": "-L7 -p%d (PROCESSORS=%d, ramsize=%d)" % (threads, cores, phys),
                        "stream_bufsize": int(ctl.stream_bufsize), "dict_size": int(ctl.dictSize_used),
                        "output_bytes": len(out), "host_threads": threads, "parallelism": "chunk-per-gpu x%d" % world},

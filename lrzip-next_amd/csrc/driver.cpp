@@ -243,29 +243,18 @@ struct Pipeline {
 				finish_job(j);
 				continue;
 			}
-			// lz4 gate, src/stream.c:437-440
+			// lz4 gate, src/stream.c:437-440.  Blocks whose gate result comes from the chunk-wide batch
+			// launch do not wait for it here: the finder below runs concurrently with that launch
+			// and its result is dropped if the gate says "incompressible".
 			bool compressible = true;
-			if (sz.lz4_test) {
-				int pct;
-				if (j->ref.streamno == 1 && n <= 100 * 1048576) {
-					std::unique_lock<std::mutex> lk(mu);
-					cv_lz4.wait(lk, [&] { return j->lz4_ready || err; });
-					if (err) {
-						lk.unlock();
-						cleanup();
-						return;
-					}
-					int r = j->lz4_size;
-					lk.unlock();
-					pct = lz4_compresses_decision(n, sz.threshold, [&](int, int) { return r; });
-				} else {
-					(void)hipStreamSynchronize(s);
-					pct = lrzgpu_lz4_compresses_dev(d_blk, n, sz.threshold, device);
-					if (pct < 0) {
-						fail(pct);
-						cleanup();
-						return;
-					}
+			const bool gate_from_batch = sz.lz4_test && j->ref.streamno == 1 && n <= 100 * 1048576;
+			if (sz.lz4_test && !gate_from_batch) {
+				(void)hipStreamSynchronize(s);
+				int pct = lrzgpu_lz4_compresses_dev(d_blk, n, sz.threshold, device);
+				if (pct < 0) {
+					fail(pct);
+					cleanup();
+					return;
 				}
 				compressible = pct != 0;
 			}
@@ -301,6 +290,23 @@ struct Pipeline {
 				fail(LRZGPU_E_INTERNAL);
 				cleanup();
 				return;
+			}
+			if (gate_from_batch) {
+				std::unique_lock<std::mutex> lk(mu);
+				cv_lz4.wait(lk, [&] { return j->lz4_ready || err; });
+				if (err) {
+					lk.unlock();
+					cleanup();
+					return;
+				}
+				const int r = j->lz4_size;
+				lk.unlock();
+				if (lz4_compresses_decision(n, sz.threshold, [&](int, int) { return r; }) == 0) {
+					(void)hipStreamSynchronize(s);
+					store_raw(j);
+					finish_job(j);
+					continue;
+				}
 			}
 			j->counts.resize((size_t)n);
 			j->pairs.resize((size_t)total ? (size_t)total : 1);

@@ -46,6 +46,8 @@ constexpr int MINIMUM_MATCH = 31; // src/rzip.c:51
 constexpr int GREAT_MATCH = 1024; // src/rzip.c:50
 constexpr int TILE = 4096;        // positions per K1 workgroup
 constexpr int PER_THREAD = 16;
+constexpr int WALK = 16;     // table slots a speculative lookup reads per step (one HBM round trip)
+constexpr int MAX_EQS = 32;  // round-robin eviction handled in the batch up to this max_chain_len
 constexpr int MAX_HITS = 24; // tag hits one speculative lookup may verify (more -> serial path)
 constexpr int CT_BITS = 10; // conflict map: 1024 granule entries for <= 320 writes per round
 constexpr int CT_SIZE = 1 << CT_BITS;
@@ -203,6 +205,30 @@ __device__ __forceinline__ int nth_set_bit(u64 m, int k)
 	for (int i = 0; i < k; i++)
 		m &= m - 1;
 	return __ffsll((long long)m) - 1;
+}
+
+// Cheap exact pre-test for a tag hit: true when single_match_len(p0, op) is certainly 0, decided
+// from the 8 bytes after and the 8 bytes before the two positions (a match needs fwd + rev >= 31;
+// two early mismatches bound the total by 14).  false = undecided, run the exact compare.
+__device__ __forceinline__ bool quick_reject(const uint8_t *buf, i64 p0, i64 op, i64 end, i64 last_match)
+{
+	if (op >= p0)
+		return true;
+	if (end - p0 < 8)
+		return false;
+	const u64 fa = reinterpret_cast<const U64u *>(buf + p0)->v;
+	const u64 fb = reinterpret_cast<const U64u *>(buf + op)->v;
+	if (fa == fb)
+		return false;
+	const i64 floor_p = last_match > 0 ? last_match : 0;
+	i64 max_back = p0 - floor_p;
+	if (op < max_back)
+		max_back = op;
+	if (max_back < 8)
+		return true; // fwd < 8 and rev <= max_back < 8
+	const u64 ba = reinterpret_cast<const U64u *>(buf + p0 - 8)->v;
+	const u64 bb = reinterpret_cast<const U64u *>(buf + op - 8)->v;
+	return ba != bb; // some byte among the 8 before differs: rev < 8
 }
 
 struct Resolver {
@@ -367,7 +393,13 @@ struct Resolver {
 			bool empty = !(s.offset | (i64)s.t);
 			u64 em = __ballot(empty);
 			int first_empty = em ? __ffsll((long long)em) - 1 : 64;
-			u64 hits = __ballot(!empty && s.t == t) & low_mask(first_empty);
+			const bool is_hit = !empty && s.t == t && lane < first_empty;
+			const u64 all_hits = __ballot(is_hit);
+			// every hit lane pre-tests its own slot in parallel (one memory round trip for all of
+			// them); only the undecided ones take the exact wave-wide compare, in slot order
+			const bool undecided = is_hit && !quick_reject(buf, p, s.offset, end, last_match);
+			u64 hits = __ballot(undecided);
+			tag_misses += __popcll(all_hits) - __popcll(hits);
 			while (hits) {
 				int idx = __ffsll((long long)hits) - 1;
 				hits &= hits - 1;
@@ -532,6 +564,7 @@ struct LaneSim {
 	bool complex_;   // must take the serial path (victim round-robin, wrap, deep displacement, ...)
 	bool match;      // a tag hit verifies as a real match (>= MINIMUM_MATCH): batch ends here
 	bool ins;        // (T & tag_mask) == tag_mask
+	bool victim;     // insert meets max_chain_len equal tags: round-robin eviction (w_slot[0] set at commit)
 	int dec;         // insert replaces an entry that was due for cleaning: hash_count--
 	int misses;      // false tag positives met by the lookup
 	int nw;          // table writes of the insert (displacement chain), <= 4
@@ -591,6 +624,7 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 	__shared__ i64 ring_pos[256];
 	__shared__ u64 ring_tag[256];
 	__shared__ i64 hit_lds[MAX_HITS * 64];
+	__shared__ uint32_t eqs_lds[MAX_EQS * 64]; // per window ticket: slots of the first equal tags of the insert walk
 	__shared__ uint32_t ct_key[CT_SIZE];
 	__shared__ uint32_t ct_val[CT_SIZE];
 
@@ -718,8 +752,10 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 	i64 w_pos = -1;
 	u64 w_tag = 0;
 	bool w_simd = false;
+	int w_ticket = 0; // stable id of the window entry (index into eqs_lds), travels with the shifts
+	int next_ticket = 0;
 	LaneSim L;
-	L.complex_ = L.match = L.ins = false;
+	L.complex_ = L.match = L.ins = L.victim = false;
 	L.dec = L.misses = L.nw = 0;
 	L.lo = L.hi = 0;
 	for (int k = 0; k < 4; k++) {
@@ -734,6 +770,8 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		w_pos = (i64)bcast64((u64)w_pos, src);
 		w_tag = bcast64(w_tag, src);
 		w_simd = __shfl((int)w_simd, src) != 0;
+		w_ticket = __shfl(w_ticket, src);
+		L.victim = __shfl((int)L.victim, src) != 0;
 		L.complex_ = __shfl((int)L.complex_, src) != 0;
 		L.match = __shfl((int)L.match, src) != 0;
 		L.ins = __shfl((int)L.ins, src) != 0;
@@ -767,7 +805,9 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 					w_pos = ring_pos[slot];
 					w_tag = ring_tag[slot];
 					w_simd = false;
+					w_ticket = (next_ticket + lane - wcount) & 63;
 				}
+				next_ticket = (next_ticket + k) & 63;
 				ring_head = (ring_head + k) & 255;
 				ring_cnt -= k;
 				wcount += k;
@@ -809,83 +849,128 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 			occ.offset = 0;
 			occ.t = 0;
 			int nhit = 0; // tag hits met by the lookup walk, offsets parked in LDS (hit_lds)
-			// ---- A1: lookup walk to the first empty slot ----
+			// ---- A1: lookup walk to the first empty slot, 16 slots per step, branch-free masks ----
 			{
 				i64 idx = (i64)(T & R.hmask);
 				uint32_t neq = 0;
 				int steps = 0;
 				bool fin = !need_sim;
+				const uint32_t T_lo = (uint32_t)T, T_hi = (uint32_t)(T >> 32);
+				const uint32_t b_lo = (uint32_t)better;
+				const int t_ones = my_rank - 1; // trailing one bits of T
+				const uint32_t m_lo = t_ones >= 32 ? 0xFFFFFFFFu : ((1u << t_ones) - 1);
 				if (need_sim) {
-					L.complex_ = false;
+					L.complex_ = (better >> 32) != 0 || t_ones >= 32; // 32-bit predicate forms below
 					L.match = false;
+					L.victim = false;
 					L.dec = 0;
 					L.misses = 0;
 					L.nw = 0;
 					L.ins = (T & R.tag_mask) == R.tag_mask;
 					L.lo = (uint32_t)idx;
 					L.hi = (uint32_t)idx;
+					if (L.complex_)
+						fin = true;
 				}
 				while (__ballot(!fin)) {
 					if (!fin) {
-						Slot c8[8];
+						uint4 c8[WALK];
 #pragma unroll
-						for (int q = 0; q < 8; q++)
-							c8[q] = tbl[idx + q]; // the table is padded by 64 slots
+						for (int q = 0; q < WALK; q++)
+							c8[q] = *reinterpret_cast<const uint4 *>(&tbl[idx + q]); // table padded by 64 slots
+						uint32_t E = 0, Bm = 0, Lm = 0, Q = 0;
 #pragma unroll
-						for (int q = 0; q < 8; q++) {
-							if (!fin) {
-								if (idx + q >= tbl_size || ++steps > 192) {
-									L.complex_ = true;
-									L.hi = (uint32_t)(tbl_size - 1 < idx + q ? tbl_size - 1 : idx + q);
-									fin = true;
-								} else {
-									const Slot sl = c8[q];
-									const bool empty = !(sl.offset | (i64)sl.t);
-									if (kind < 0 && L.ins) {
-										if (empty) {
-											kind = 0;
-											sidx = idx + q;
-										} else if ((sl.t & better) != better) {
-											kind = 1;
-											sidx = idx + q;
-										} else if (bitness_rank(sl.t) < my_rank) {
-											kind = 2;
-											sidx = idx + q;
-											occ = sl;
-										} else if (sl.t == T) {
-											if (++neq >= R.max_chain)
-												L.complex_ = true; // round-robin victim path
-										}
-									}
-									if (empty) {
-										L.hi = (uint32_t)(idx + q);
-										fin = true;
-									} else if (sl.t == T) {
-										if (nhit < MAX_HITS)
-											hit_lds[nhit * 64 + lane] = sl.offset;
+						for (int q = 0; q < WALK; q++) {
+							const uint32_t tl = c8[q].z, th = c8[q].w;
+							E |= (uint32_t)((c8[q].x | c8[q].y | tl | th) == 0) << q;
+							Bm |= (uint32_t)((tl & b_lo) != b_lo) << q;
+							Lm |= (uint32_t)((tl & m_lo) != m_lo) << q;
+							Q |= (uint32_t)(tl == T_lo && th == T_hi) << q;
+						}
+						steps += WALK;
+						if (idx + WALK > tbl_size || steps > 512) {
+							L.complex_ = true;
+							L.hi = (uint32_t)(tbl_size - 1);
+							fin = true;
+						} else {
+							const int fe = E ? __ffs((int)E) - 1 : WALK; // first empty slot of the step
+							if (kind < 0 && L.ins) {
+								const uint32_t S = E | Bm | Lm;
+								const int s1 = S ? __ffs((int)S) - 1 : WALK;
+								uint32_t eqb = Q & ((1u << s1) - 1);
+								while (eqb) {
+									const int q = __ffs((int)eqb) - 1;
+									eqb &= eqb - 1;
+									if (neq < MAX_EQS)
+										eqs_lds[neq * 64 + w_ticket] = (uint32_t)(idx + q);
+									if (++neq >= R.max_chain) {
+										if (R.max_chain <= MAX_EQS)
+											kind = 3; // round-robin eviction among these equal tags
 										else
 											L.complex_ = true;
-										nhit++;
+										eqb = 0;
 									}
 								}
+								if (kind < 0 && !L.complex_ && s1 < WALK) {
+									kind = ((E >> s1) & 1) ? 0 : ((Bm >> s1) & 1) ? 1 : 2;
+									sidx = idx + s1;
+									uint4 o = c8[0];
+#pragma unroll
+									for (int q = 1; q < WALK; q++)
+										if (q == s1)
+											o = c8[q];
+									occ.offset = (i64)(((u64)o.y << 32) | o.x);
+									occ.t = ((u64)o.w << 32) | o.z;
+								}
+							}
+							uint32_t hm = Q & ((1u << fe) - 1);
+							while (hm) {
+								const int q = __ffs((int)hm) - 1;
+								hm &= hm - 1;
+								uint4 o = c8[0];
+#pragma unroll
+								for (int qq = 1; qq < WALK; qq++)
+									if (qq == q)
+										o = c8[qq];
+								if (nhit < MAX_HITS)
+									hit_lds[nhit * 64 + lane] = (i64)(((u64)o.y << 32) | o.x);
+								else
+									L.complex_ = true;
+								nhit++;
+							}
+							if (fe < WALK) {
+								L.hi = (uint32_t)(idx + fe);
+								fin = true;
 							}
 						}
-						idx += 8;
+						idx += WALK;
 					}
 				}
 			}
+
 			lap(9);
 			// ---- A2: are the tag hits real matches (>= MINIMUM_MATCH)? ----
-#pragma unroll 1
-			for (int k = 0; k < MAX_HITS; k++) {
-				const bool act = need_sim && k < nhit && !L.match && !L.complex_;
-				if (!__ballot(act))
-					break;
-				if (act) {
-					if (lane_verify(buf, P, hit_lds[k * 64 + lane], R.end, R.last_match))
-						L.match = true;
-					else
-						L.misses++;
+			{
+				// all hits are pre-tested with independent loads (one round trip), the rare
+				// undecided ones get the exact compare
+				uint32_t und = 0; // bit k: hit k needs the exact compare
+				if (need_sim && !L.complex_) {
+					for (int k = 0; k < nhit && k < MAX_HITS; k++)
+						if (!quick_reject(buf, P, hit_lds[k * 64 + lane], R.end, R.last_match))
+							und |= 1u << k;
+					L.misses = (nhit < MAX_HITS ? nhit : MAX_HITS) - __popc(und);
+				}
+				while (__ballot(und != 0)) {
+					if (und) {
+						const int k = __ffs((int)und) - 1;
+						und &= und - 1;
+						if (!L.match) {
+							if (lane_verify(buf, P, hit_lds[k * 64 + lane], R.end, R.last_match))
+								L.match = true;
+							else
+								L.misses++;
+						}
+					}
 				}
 			}
 			lap(14);
@@ -919,6 +1004,11 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 							if (kind == 0) {
 								chain = false;
 							} else if (kind == 1) {
+								L.dec = 1;
+								chain = false;
+							} else if (kind == 3) {
+								// victim slot depends on victim_round at commit time (set in phase C)
+								L.victim = true;
 								L.dec = 1;
 								chain = false;
 							} else {
@@ -1004,6 +1094,13 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		const u64 clean_m = __ballot(cleans);
 		const int kth = __popcll(clean_m & lanes_below);
 		const int want = __popcll(clean_m);
+		// round-robin evictions: victim_round advances by one per eviction (src/rzip.c:332-341)
+		const bool evicts = live && L.victim && !L.complex_ && !L.match;
+		const u64 evict_m = __ballot(evicts);
+		if (evicts) {
+			const uint32_t r = (uint32_t)((R.victim_round + __popcll(evict_m & lanes_below)) % (i64)R.max_chain);
+			L.w_slot[0] = eqs_lds[r * 64 + w_ticket];
+		}
 
 		// victim list: the next `want` entries the sweep would delete, in sweep order
 		int nv = 0;
@@ -1163,6 +1260,7 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 			R.tag_misses += my_miss;
 			const i64 hc = R.hash_count + my_x;
 			R.hash_count = hc < R.hash_limit ? hc : R.hash_limit;
+			R.victim_round = (R.victim_round + __popcll(evict_m & cm)) % (i64)R.max_chain;
 			const u64 cc = clean_m & cm;
 			if (cc) {
 				const int last = 63 - __clzll((long long)cc);
@@ -1536,6 +1634,10 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 		t2.stop();
 		HIPCHK(hipMemcpyAsync(&h, w->state, sizeof(h), hipMemcpyDeviceToHost, s));
 		HIPCHK(hipStreamSynchronize(s));
+		if (getenv("LRZGPU_TRACE"))
+			fprintf(stderr, "lrzgpu scan: seg [%lld,%lld) tiles %d  k1 %.2f ms  k2 %.2f ms  p_skip %lld  mask %llx  lookups %lld recs %lld\n",
+				(long long)seg_lo, (long long)seg_hi, ntiles, t1.ms(), t2.ms(), (long long)h.p_skip,
+				(unsigned long long)h.min_mask, (long long)h.lookups, (long long)h.n_records);
 		{
 			ProfileStore &ps = ProfileStore::get();
 			std::lock_guard<std::mutex> lk(ps.mu);
