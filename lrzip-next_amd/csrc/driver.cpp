@@ -10,6 +10,7 @@
 //
 // Output bytes depend only on (input, control parameters), never on thread counts here.
 #include <hip/hip_runtime.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -51,6 +52,14 @@ extern "C" void lrzgpu_control_init(lrzgpu_control *c)
 
 namespace {
 
+static double now_s()
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+static bool tracing() { static int t = getenv("LRZGPU_TRACE") ? 1 : 0; return t != 0; }
+
 struct ChunkCtx {
 	int index = 0;
 	int64_t size = 0;
@@ -90,6 +99,8 @@ struct Pipeline {
 	size_t enc_inflight = 0;      // queued + running encodes (bounds host memory)
 	size_t enc_limit = 4;
 	bool closing = false;
+	double t_last_mf = 0, t_last_enc = 0, t_first_enc = 0; // trace only
+	double mf_busy = 0, d2h_busy = 0, blk_busy = 0, enc_busy = 0; // summed over workers (trace only)
 	std::vector<std::thread> threads;
 	std::vector<std::unique_ptr<Job>> all_jobs; // file order
 
@@ -167,6 +178,7 @@ struct Pipeline {
 			{
 				std::lock_guard<std::mutex> lk(mu);
 				enc_inflight--;
+				t_last_enc = now_s();
 				cv_jobs.notify_all();
 			}
 			finish_job(j);
@@ -207,6 +219,7 @@ struct Pipeline {
 				j = gpu_queue.front();
 				gpu_queue.pop_front();
 			}
+			const double tw0 = now_s();
 			const int64_t n = j->ref.len;
 			j->done.streamno = j->ref.streamno;
 			j->done.s_len = n;
@@ -271,6 +284,7 @@ struct Pipeline {
 				cleanup();
 				return;
 			}
+			const double tw1 = now_s();
 			unsigned long long total = 0;
 			for (int attempt = 0;; attempt++) {
 				if (!ws && mf_workspace_create(&ws, bufsize, per_pos) != 0) {
@@ -308,6 +322,7 @@ struct Pipeline {
 					continue;
 				}
 			}
+			const double tw2 = now_s();
 			j->counts.resize((size_t)n);
 			j->pairs.resize((size_t)total ? (size_t)total : 1);
 			if (hipMemcpyAsync(j->counts.data(), ws->counts, (size_t)n, hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -321,6 +336,10 @@ struct Pipeline {
 				std::lock_guard<std::mutex> lk(mu);
 				enc_queue.push_back(j);
 				enc_inflight++;
+				t_last_mf = now_s();
+				blk_busy += tw1 - tw0;
+				mf_busy += tw2 - tw1;
+				d2h_busy += t_last_mf - tw2;
 				cv_enc.notify_one();
 			}
 		}
@@ -411,6 +430,8 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 		m.finish(digest);
 	});
 
+	const double t0 = now_s();
+	double t_scan = 0, t_gather = 0, t_lz4 = 0;
 	P.start();
 
 	std::vector<std::unique_ptr<ChunkCtx>> chunks;
@@ -470,6 +491,7 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 			ret = r == -4 ? LRZGPU_E_NOMEM : LRZGPU_E_INTERNAL;
 			break;
 		}
+		t_scan = now_s();
 		EmitResult er;
 		emit_streams(sr.records, chunk_size, cc->chunk_bytes, sr.crc, &er);
 		cc->stream0.swap(er.stream0);
@@ -506,6 +528,7 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 				ps.p.gather_bytes += er.stream1_len;
 			}
 		}
+		t_gather = now_s();
 		// block list in flush order
 		std::vector<BlockRef> refs;
 		block_order(cc->stream0, cc->chunk_bytes, cc->stream1_len, P.sz.stream_bufsize, &refs);
@@ -586,6 +609,7 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 				P.gpu_queue.push_back(j);
 			P.cv_jobs.notify_all();
 		}
+		t_lz4 = now_s();
 		chunks.push_back(std::move(cc));
 		len -= chunk_size;
 	}
@@ -606,8 +630,10 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 		if (P.err && !ret)
 			ret = P.err;
 	}
+	const double t_blocks = now_s();
 	P.stop();
 	md5_thread.join();
+	const double t_md5 = now_s();
 	if (!ret && md5_err)
 		ret = md5_err;
 	scan_workspace_destroy(sw);
@@ -636,6 +662,9 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 	}
 	out->insert(out->end(), digest, digest + 16);
 	memcpy(ctl->hash_resblock, digest, 16);
+	if (tracing())
+		fprintf(stderr, "lrzgpu driver: scan %.2f  gather %.2f  lz4+enqueue %.2f  last finder %.2f  last encode %.2f  all blocks %.2f  md5 joined %.2f  assembled %.2f s (since start; last chunk); worker sums: block copy+gate %.2f finder %.2f lists D2H %.2f s\n",
+			t_scan - t0, t_gather - t0, t_lz4 - t0, P.t_last_mf - t0, P.t_last_enc - t0, t_blocks - t0, t_md5 - t0, now_s() - t0, P.blk_busy, P.mf_busy, P.d2h_busy);
 	if (with_magic) {
 		uint8_t magic[21];
 		write_magic(magic, P.sz, in.n);

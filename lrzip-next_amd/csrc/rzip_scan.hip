@@ -890,7 +890,7 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 						steps += WALK;
 						if (idx + WALK > tbl_size || steps > 512) {
 							L.complex_ = true;
-							L.hi = (uint32_t)(tbl_size - 1);
+							L.hi = (uint32_t)(idx + WALK - 1 < tbl_size - 1 ? idx + WALK - 1 : tbl_size - 1);
 							fin = true;
 						} else {
 							const int fe = E ? __ffs((int)E) - 1 : WALK; // first empty slot of the step
@@ -1194,7 +1194,7 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 		int first_conf = 64;
-		if (live) {
+		if (live && !L.complex_ && !L.match) { // lanes that stop anyway need no conflict test
 			const uint32_t g1 = L.hi >> 3;
 			for (uint32_t g = L.lo >> 3; g <= g1; g++) {
 				uint32_t h = (g * 2654435761u) >> (32 - CT_BITS);
