@@ -21,6 +21,9 @@ import os
 import sys
 import time
 
+# one hardware queue per stream (scan, gate, finder workers): must be set before HIP initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

@@ -6,6 +6,9 @@ CPU fallback here: if the library is missing, loading raises.
 import ctypes as C
 import os
 
+# scan, gate and finder streams should not share hardware queues (effective only if HIP is not yet initialised)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liblrzgpu.so")
 

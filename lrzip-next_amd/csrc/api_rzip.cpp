@@ -123,7 +123,7 @@ extern "C" int lrzgpu_hash_search_dev(const void *d_chunk, int64_t chunk_size, i
 		CopyRun *d_runs = nullptr;
 		if (hipMalloc(&d_runs, e.runs.size() * sizeof(CopyRun)) != hipSuccess ||
 		    hipMemcpy(d_runs, e.runs.data(), e.runs.size() * sizeof(CopyRun), hipMemcpyHostToDevice) != hipSuccess ||
-		    gather_runs_device((const uint8_t *)d_chunk, (uint8_t *)d_stream1, d_runs, (int)e.runs.size(), e.stream1_len, 0) != 0 ||
+		    gather_runs_device((const uint8_t *)d_chunk, (uint8_t *)d_stream1, d_runs, (int)e.runs.size(), 0, e.stream1_len, 0) != 0 ||
 		    hipDeviceSynchronize() != hipSuccess) {
 			if (d_runs)
 				(void)hipFree(d_runs);

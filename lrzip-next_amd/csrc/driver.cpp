@@ -1,14 +1,22 @@
 // driver.cpp -- whole-file compress driver: the rzip_fd() control flow (reference src/rzip.c:922-1264)
 // over the GPU stages, with the per-block back end pipelined between the GPU and host threads.
 //
-//   main thread      per chunk: K1/K2 scan -> token serialisation -> K4 literal gather -> block list
-//   lz4 batch        one wavefront per block of the chunk, all blocks in one launch (lz4_gate.hip)
-//   GPU workers      `gpu_slots` threads, each with a HIP stream + match-finder workspace: runs the
-//                    finder for the next block while earlier blocks are being parsed on the host
+//   main thread      per chunk: K1/K2 scan segments.  After every segment the literal bytes that are
+//                    already decided are gathered (K4) and every stream-1 block they complete is
+//                    handed to the back end AT ONCE, so the back end runs under the scan -- the
+//                    reference overlaps the same way through flush_buffer() (src/rzip.c:229-246).
+//                    "Decided" = behind every emitted match, or more than SPEC_MARGIN behind the
+//                    scan position; a later match reaching back over such bytes is detected and
+//                    the chunk's early blocks are then thrown away and redone (never observed on
+//                    real data: a backward extension is bounded by the candidate spacing).
+//   lz4 gate         one wavefront per block, launched per group of new blocks on its own stream
+//   GPU workers      `gpu_slots` threads, each with a HIP stream + match-finder workspace + pinned
+//                    staging: finder for block k+1 while block k is parsed on the host
 //   host encoders    `host_threads` threads: LZMA optimal parser + range coder (lzma_enc.cpp)
-//   writer           ordered container assembly (stream_layer.cpp)
+//   writer           ordered container assembly (stream_layer.cpp); the file order of the blocks is
+//                    block_order()'s replay of the reference flushes, whatever order they finished in
 //
-// Output bytes depend only on (input, control parameters), never on thread counts here.
+// Output bytes depend only on (input, control parameters), never on thread counts or timing here.
 #include <hip/hip_runtime.h>
 #include <time.h>
 #include <unistd.h>
@@ -19,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -52,57 +61,134 @@ extern "C" void lrzgpu_control_init(lrzgpu_control *c)
 
 namespace {
 
-static double now_s()
+constexpr int64_t SPEC_MARGIN = (int64_t)8 << 20; // literal bytes this far behind the scan count as decided
+constexpr size_t STAGE_BYTES = (size_t)32 << 20;  // pinned D2H staging piece (two per GPU worker)
+
+double now_s()
 {
 	struct timespec ts;
 	clock_gettime(CLOCK_MONOTONIC, &ts);
 	return ts.tv_sec + ts.tv_nsec * 1e-9;
 }
-static bool tracing() { static int t = getenv("LRZGPU_TRACE") ? 1 : 0; return t != 0; }
+bool tracing()
+{
+	static int t = getenv("LRZGPU_TRACE") ? 1 : 0;
+	return t != 0;
+}
+
+// The resolver is one latency-bound wavefront; finder / gate kernels of the blocks emitted early would
+// otherwise share its CU (issue slots, L1, LDS).  The scan stream therefore owns a small set of CUs
+// and every back-end stream gets the complement (hipExtStreamCreateWithCUMask).
+int scan_cu_words(uint32_t scan_mask[8], uint32_t rest_mask[8])
+{
+	int ncu = 256;
+	hipDeviceProp_t prop;
+	int dev = 0;
+	if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+		ncu = prop.multiProcessorCount;
+	if (ncu > 256)
+		ncu = 256;
+	const char *e = getenv("LRZGPU_SCAN_CUS");
+	int k = e ? atoi(e) : 0; // off by default: measured no gain, and masked streams are blocking streams
+	if (k <= 0 || k >= ncu)
+		return 0; // masking disabled
+	for (int w = 0; w < 8; w++)
+		scan_mask[w] = rest_mask[w] = 0;
+	for (int c = 0; c < ncu; c++) {
+		if (c < k)
+			scan_mask[c >> 5] |= 1u << (c & 31);
+		else
+			rest_mask[c >> 5] |= 1u << (c & 31);
+	}
+	return (ncu + 31) / 32;
+}
+hipError_t make_stream(hipStream_t *s, int words, const uint32_t *mask, bool high_priority = false)
+{
+	if (words > 0)
+		return hipExtStreamCreateWithCUMask(s, (uint32_t)words, mask);
+	if (high_priority) {
+		// the scan stream must never queue behind a multi-second gate/finder kernel: streams share a
+		// small pool of hardware queues (GPU_MAX_HW_QUEUES), priority streams get their own
+		int lo = 0, hi = 0;
+		if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
+			return hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi);
+	}
+	return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
 
 struct ChunkCtx {
 	int index = 0;
 	int64_t size = 0;
 	int chunk_bytes = 0;
-	uint8_t *d_stream1 = nullptr; // owned
+	uint8_t *d_stream1 = nullptr; // owned, chunk_size + 256 bytes
 	int64_t stream1_len = 0;
 	std::vector<uint8_t> stream0;
-	std::atomic<int> pending{0};
+};
+
+template <typename T> struct RawBuf { // uninitialised host buffer (std::vector would zero-fill)
+	std::unique_ptr<T[]> p;
+	size_t n = 0;
+	void alloc(size_t k)
+	{
+		p.reset(new T[k ? k : 1]);
+		n = k;
+	}
+	void release()
+	{
+		p.reset();
+		n = 0;
+	}
+	T *data() { return p.get(); }
 };
 
 struct Job {
 	ChunkCtx *chunk = nullptr;
 	BlockRef ref{0, 0, 0};
-	// lz4 gate
-	int lz4_size = -1;       // LZ4 size of the whole block (single pass case), -1 = not computed
+	// state, guarded by Pipeline::mu
+	bool gate_needed = false; // lz4 result comes from a batch launch
 	bool lz4_ready = false;
-	// finder results (host)
-	std::vector<uint8_t> bytes;
-	std::vector<uint8_t> counts;
-	std::vector<uint32_t> pairs;
-	// result
-	DoneBlock done;
+	int lz4_size = -1;
+	bool mf_done = false;
+	bool compressible_mf = false; // finder ran and produced lists
+	bool dispatched = false;
+	bool cancelled = false;
 	bool finished = false;
+	// data
+	RawBuf<uint8_t> bytes;
+	RawBuf<uint8_t> counts;
+	RawBuf<uint32_t> pairs;
+	bool packed = false;
+	DoneBlock done;
+};
+
+struct Lz4Batch {
+	hipEvent_t ev = nullptr;
+	Lz4Job *d_jobs = nullptr;
+	int *d_res = nullptr;
+	std::vector<Job *> jobs;
+	EventTimer *timer = nullptr;
+	int64_t bytes = 0;
 };
 
 struct Pipeline {
 	lrzgpu_control *ctl;
 	Sizing sz;
 	int device = 0;
+	int mask_words = 0;
+	uint32_t scan_mask[8], rest_mask[8];
 	int n_gpu_workers = 2, n_encoders = 1;
 	int err = 0;
 
 	std::mutex mu;
-	std::condition_variable cv_jobs, cv_enc, cv_done, cv_lz4;
-	std::deque<Job *> gpu_queue;  // jobs waiting for a GPU worker (file order)
-	std::deque<Job *> enc_queue;  // jobs with match lists, waiting for a host encoder
-	size_t enc_inflight = 0;      // queued + running encodes (bounds host memory)
-	size_t enc_limit = 4;
+	std::condition_variable cv_jobs, cv_enc, cv_done;
+	std::deque<Job *> gpu_queue; // blocks waiting for a GPU worker
+	std::deque<Job *> enc_queue; // blocks with match lists and a positive gate, waiting for a host encoder
+	size_t held = 0;             // blocks holding host match lists (bounds host memory)
+	size_t held_limit = 4;
 	bool closing = false;
-	double t_last_mf = 0, t_last_enc = 0, t_first_enc = 0; // trace only
-	double mf_busy = 0, d2h_busy = 0, blk_busy = 0, enc_busy = 0; // summed over workers (trace only)
+	double t_last_mf = 0, t_last_enc = 0;
+	double mf_busy = 0, d2h_busy = 0, blk_busy = 0;
 	std::vector<std::thread> threads;
-	std::vector<std::unique_ptr<Job>> all_jobs; // file order
 
 	void fail(int e)
 	{
@@ -112,33 +198,45 @@ struct Pipeline {
 		cv_jobs.notify_all();
 		cv_enc.notify_all();
 		cv_done.notify_all();
-		cv_lz4.notify_all();
 	}
 
-	void finish_job(Job *j)
+	void mark_finished(Job *j, bool held_lists)
 	{
-		ChunkCtx *c = j->chunk;
-		j->bytes.clear();
-		j->bytes.shrink_to_fit();
-		j->counts.clear();
-		j->counts.shrink_to_fit();
-		j->pairs.clear();
-		j->pairs.shrink_to_fit();
-		{
-			std::lock_guard<std::mutex> lk(mu);
-			j->finished = true;
-			cv_done.notify_all();
+		j->bytes.release();
+		j->counts.release();
+		j->pairs.release();
+		std::lock_guard<std::mutex> lk(mu);
+		if (held_lists) {
+			held--;
+			cv_jobs.notify_all();
 		}
-		if (c->pending.fetch_sub(1) == 1 && c->d_stream1) {
-			(void)hipFree(c->d_stream1);
-			c->d_stream1 = nullptr;
-		}
+		j->finished = true;
+		cv_done.notify_all();
 	}
 
 	void store_raw(Job *j)
 	{
 		j->done.c_type = CTYPE_NONE;
-		j->done.payload.swap(j->bytes);
+		j->done.payload.assign(j->bytes.data(), j->bytes.data() + j->ref.len);
+	}
+
+	// Called with mu held whenever the finder result or the gate result of a block arrives: once both
+	// are there the block either goes to the encoders or is stored.  Returns 1 if the caller must
+	// finish the block as stored (outside the lock).
+	int route(Job *j)
+	{
+		if (j->dispatched || !j->mf_done || (j->gate_needed && !j->lz4_ready))
+			return 0;
+		j->dispatched = true;
+		bool compressible = j->compressible_mf && !j->cancelled;
+		if (compressible && j->gate_needed)
+			compressible = lz4_compresses_decision(j->ref.len, sz.threshold, [&](int, int) { return j->lz4_size; }) != 0;
+		if (compressible) {
+			enc_queue.push_back(j);
+			cv_enc.notify_one();
+			return 0;
+		}
+		return 1;
 	}
 
 	// reference lzma_compress_buf(), src/stream.c:429-494, host half
@@ -154,35 +252,60 @@ struct Pipeline {
 				j = enc_queue.front();
 				enc_queue.pop_front();
 			}
-			LzmaParams p;
-			lzma_normalize(p, sz.level, sz.dict_size, 3, 0, 2, sz.level < 7 ? 32 : 64);
-			MatchLists ml;
-			ml.counts = j->counts.data();
-			ml.pairs = j->pairs.data();
-			// dlen = round_up_page(s_len * 1.02), src/stream.c:443
-			size_t cap = (size_t)((double)j->ref.len * 1.02);
-			cap = (cap + kPage - 1) / kPage * kPage;
-			std::vector<uint8_t> dst(cap);
-			size_t out_len = 0;
-			int r = lzma_encode_block(p, j->bytes.data(), (size_t)j->ref.len, ml, dst.data(), cap, &out_len);
-			if (r == LZ_OK && (int64_t)out_len < j->ref.len) {
-				dst.resize(out_len);
-				j->done.c_type = CTYPE_LZMA;
-				j->done.payload.swap(dst);
-			} else if (r == LZ_OK || r == LZ_ERROR_OUTPUT_EOF) {
-				store_raw(j); // incompressible: stays CTYPE_NONE
-			} else {
-				fail(LRZGPU_E_INTERNAL);
-				return;
+			if (!j->cancelled) {
+				LzmaParams p;
+				lzma_normalize(p, sz.level, sz.dict_size, 3, 0, 2, sz.level < 7 ? 32 : 64);
+				MatchLists ml;
+				ml.counts = j->counts.data();
+				ml.pairs = j->pairs.data();
+				ml.packed = j->packed;
+				// dlen = round_up_page(s_len * 1.02), src/stream.c:443
+				size_t cap = (size_t)((double)j->ref.len * 1.02);
+				cap = (cap + kPage - 1) / kPage * kPage;
+				RawBuf<uint8_t> dst;
+				dst.alloc(cap);
+				size_t out_len = 0;
+				int r = lzma_encode_block(p, j->bytes.data(), (size_t)j->ref.len, ml, dst.data(), cap, &out_len);
+				if (r == LZ_OK && (int64_t)out_len < j->ref.len) {
+					j->done.c_type = CTYPE_LZMA;
+					j->done.payload.assign(dst.data(), dst.data() + out_len);
+				} else if (r == LZ_OK || r == LZ_ERROR_OUTPUT_EOF) {
+					store_raw(j); // incompressible: stays CTYPE_NONE
+				} else {
+					fail(LRZGPU_E_INTERNAL);
+					return;
+				}
 			}
 			{
 				std::lock_guard<std::mutex> lk(mu);
-				enc_inflight--;
 				t_last_enc = now_s();
-				cv_jobs.notify_all();
 			}
-			finish_job(j);
+			mark_finished(j, true);
 		}
+	}
+
+	// device -> host through the worker's pinned staging pair (pageable hipMemcpy is ~1 GB/s here)
+	static int d2h_staged(void *dst, const void *d_src, size_t bytes, uint8_t *stage[2], hipStream_t s)
+	{
+		size_t off = 0, prev_off = 0, prev_len = 0;
+		int k = 0;
+		while (off < bytes || prev_len) {
+			size_t len = 0;
+			if (off < bytes) {
+				len = bytes - off < STAGE_BYTES ? bytes - off : STAGE_BYTES;
+				if (hipMemcpyAsync(stage[k], (const uint8_t *)d_src + off, len, hipMemcpyDeviceToHost, s) != hipSuccess)
+					return -1;
+			}
+			if (prev_len)
+				memcpy((uint8_t *)dst + prev_off, stage[k ^ 1], prev_len);
+			if (hipStreamSynchronize(s) != hipSuccess)
+				return -1;
+			prev_off = off;
+			prev_len = len;
+			off += len;
+			k ^= 1;
+		}
+		return 0;
 	}
 
 	void gpu_worker_main()
@@ -192,25 +315,38 @@ struct Pipeline {
 			return;
 		}
 		hipStream_t s;
-		if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+		if (make_stream(&s, mask_words, rest_mask) != hipSuccess) {
 			fail(LRZGPU_E_HIP);
 			return;
 		}
 		MfWorkspace *ws = nullptr;
 		uint8_t *d_stage = nullptr;
+		uint8_t *stage[2] = {nullptr, nullptr};
 		double per_pos = 16;
 		const size_t bufsize = (size_t)sz.stream_bufsize;
 		auto cleanup = [&] {
 			mf_workspace_destroy(ws);
 			if (d_stage)
 				(void)hipFree(d_stage);
+			for (int k = 0; k < 2; k++)
+				if (stage[k])
+					(void)hipHostFree(stage[k]);
 			(void)hipStreamDestroy(s);
 		};
+		if (hipHostMalloc((void **)&stage[0], STAGE_BYTES, hipHostMallocDefault) != hipSuccess ||
+		    hipHostMalloc((void **)&stage[1], STAGE_BYTES, hipHostMallocDefault) != hipSuccess) {
+			fail(LRZGPU_E_NOMEM);
+			cleanup();
+			return;
+		}
+		LzmaParams lp;
+		const bool lzma_ok = lzma_normalize(lp, sz.level, sz.dict_size, 3, 0, 2, sz.level < 7 ? 32 : 64) == LZ_OK;
+		const bool pack = lzma_ok && lp.dict_size <= (1u << 25) && lp.fb <= 127;
 		for (;;) {
 			Job *j = nullptr;
 			{
 				std::unique_lock<std::mutex> lk(mu);
-				cv_jobs.wait(lk, [&] { return err || (!gpu_queue.empty() && enc_inflight < enc_limit) || (closing && gpu_queue.empty()); });
+				cv_jobs.wait(lk, [&] { return err || (!gpu_queue.empty() && held < held_limit) || (closing && gpu_queue.empty()); });
 				if (err || (gpu_queue.empty() && closing)) {
 					lk.unlock();
 					cleanup();
@@ -218,51 +354,45 @@ struct Pipeline {
 				}
 				j = gpu_queue.front();
 				gpu_queue.pop_front();
+				held++; // released in mark_finished
 			}
 			const double tw0 = now_s();
 			const int64_t n = j->ref.len;
 			j->done.streamno = j->ref.streamno;
 			j->done.s_len = n;
-			const bool try_backend = !sz.no_compress && n >= 64; // src/stream.c:1633
+			bool try_backend = !sz.no_compress && n >= 64 && !j->cancelled; // src/stream.c:1633
+			if (try_backend && !lzma_ok) {
+				fail(LRZGPU_E_PARAM);
+				cleanup();
+				return;
+			}
 			// block bytes: device view + host copy
 			const uint8_t *d_blk = nullptr;
-			j->bytes.resize((size_t)n);
+			j->bytes.alloc((size_t)n);
+			int rc = 0;
 			if (j->ref.streamno == 0) {
 				memcpy(j->bytes.data(), j->chunk->stream0.data() + j->ref.off, (size_t)n);
 				if (try_backend) {
-					if (!d_stage && hipMalloc(&d_stage, bufsize + 256) != hipSuccess) {
-						fail(LRZGPU_E_NOMEM);
-						cleanup();
-						return;
-					}
-					if (hipMemcpyAsync(d_stage, j->bytes.data(), (size_t)n, hipMemcpyHostToDevice, s) != hipSuccess) {
-						fail(LRZGPU_E_HIP);
-						cleanup();
-						return;
-					}
+					if (!d_stage && hipMalloc(&d_stage, bufsize + 256) != hipSuccess)
+						rc = LRZGPU_E_NOMEM;
+					else if (hipMemcpyAsync(d_stage, j->bytes.data(), (size_t)n, hipMemcpyHostToDevice, s) != hipSuccess ||
+						 hipStreamSynchronize(s) != hipSuccess)
+						rc = LRZGPU_E_HIP;
 					d_blk = d_stage;
 				}
 			} else {
 				d_blk = j->chunk->d_stream1 + j->ref.off;
-				if (n && hipMemcpyAsync(j->bytes.data(), d_blk, (size_t)n, hipMemcpyDeviceToHost, s) != hipSuccess) {
-					fail(LRZGPU_E_HIP);
-					cleanup();
-					return;
-				}
+				if (n && !j->cancelled && d2h_staged(j->bytes.data(), d_blk, (size_t)n, stage, s) != 0)
+					rc = LRZGPU_E_HIP;
 			}
-			if (!try_backend) {
-				(void)hipStreamSynchronize(s);
-				store_raw(j);
-				finish_job(j);
-				continue;
+			if (rc) {
+				fail(rc);
+				cleanup();
+				return;
 			}
-			// lz4 gate, src/stream.c:437-440.  Blocks whose gate result comes from the chunk-wide batch
-			// launch do not wait for it here: the finder below runs concurrently with that launch
-			// and its result is dropped if the gate says "incompressible".
-			bool compressible = true;
-			const bool gate_from_batch = sz.lz4_test && j->ref.streamno == 1 && n <= 100 * 1048576;
-			if (sz.lz4_test && !gate_from_batch) {
-				(void)hipStreamSynchronize(s);
+			// blocks outside the batched gate (stream 0, > 100 MiB) take the serial gate here
+			bool compressible = try_backend;
+			if (try_backend && sz.lz4_test && !j->gate_needed) {
 				int pct = lrzgpu_lz4_compresses_dev(d_blk, n, sz.threshold, device);
 				if (pct < 0) {
 					fail(pct);
@@ -271,76 +401,57 @@ struct Pipeline {
 				}
 				compressible = pct != 0;
 			}
-			if (!compressible) {
-				(void)hipStreamSynchronize(s);
-				store_raw(j);
-				finish_job(j);
-				continue;
-			}
-			// match finder on the GPU
-			LzmaParams p;
-			if (lzma_normalize(p, sz.level, sz.dict_size, 3, 0, 2, sz.level < 7 ? 32 : 64) != LZ_OK) {
-				fail(LRZGPU_E_PARAM);
-				cleanup();
-				return;
-			}
 			const double tw1 = now_s();
-			unsigned long long total = 0;
-			for (int attempt = 0;; attempt++) {
-				if (!ws && mf_workspace_create(&ws, bufsize, per_pos) != 0) {
-					fail(LRZGPU_E_NOMEM);
+			double tw2 = tw1;
+			if (compressible) {
+				// match finder on the GPU (runs concurrently with the gate launch of this block)
+				unsigned long long total = 0;
+				for (int attempt = 0;; attempt++) {
+					if (!ws && mf_workspace_create(&ws, bufsize, per_pos) != 0) {
+						fail(LRZGPU_E_NOMEM);
+						cleanup();
+						return;
+					}
+					int r = mf_run_device(ws, d_blk, (size_t)n, lp.dict_size, (uint32_t)lp.fb, lp.cut(), s, &total, pack);
+					if (r == 0)
+						break;
+					if (r == -4 && attempt < 3) { // pool too small for this data: grow and retry
+						mf_workspace_destroy(ws);
+						ws = nullptr;
+						per_pos *= 3;
+						continue;
+					}
+					fail(LRZGPU_E_INTERNAL);
 					cleanup();
 					return;
 				}
-				int r = mf_run_device(ws, d_blk, (size_t)n, p.dict_size, (uint32_t)p.fb, p.cut(), s, &total);
-				if (r == 0)
-					break;
-				if (r == -4 && attempt < 3) { // pool too small for this data: grow and retry
-					mf_workspace_destroy(ws);
-					ws = nullptr;
-					per_pos *= 3;
-					continue;
-				}
-				fail(LRZGPU_E_INTERNAL);
-				cleanup();
-				return;
-			}
-			if (gate_from_batch) {
-				std::unique_lock<std::mutex> lk(mu);
-				cv_lz4.wait(lk, [&] { return j->lz4_ready || err; });
-				if (err) {
-					lk.unlock();
+				tw2 = now_s();
+				const size_t words = pack ? (size_t)(total / 2) : (size_t)total;
+				j->counts.alloc((size_t)n);
+				j->pairs.alloc(words);
+				j->packed = pack;
+				if (d2h_staged(j->counts.data(), ws->counts, (size_t)n, stage, s) != 0 ||
+				    (words && d2h_staged(j->pairs.data(), ws->pool_out, words * 4, stage, s) != 0)) {
+					fail(LRZGPU_E_HIP);
 					cleanup();
 					return;
 				}
-				const int r = j->lz4_size;
-				lk.unlock();
-				if (lz4_compresses_decision(n, sz.threshold, [&](int, int) { return r; }) == 0) {
-					(void)hipStreamSynchronize(s);
-					store_raw(j);
-					finish_job(j);
-					continue;
-				}
 			}
-			const double tw2 = now_s();
-			j->counts.resize((size_t)n);
-			j->pairs.resize((size_t)total ? (size_t)total : 1);
-			if (hipMemcpyAsync(j->counts.data(), ws->counts, (size_t)n, hipMemcpyDeviceToHost, s) != hipSuccess ||
-			    (total && hipMemcpyAsync(j->pairs.data(), ws->pool_out, (size_t)total * 4, hipMemcpyDeviceToHost, s) != hipSuccess) ||
-			    hipStreamSynchronize(s) != hipSuccess) {
-				fail(LRZGPU_E_HIP);
-				cleanup();
-				return;
-			}
+			int act;
 			{
 				std::lock_guard<std::mutex> lk(mu);
-				enc_queue.push_back(j);
-				enc_inflight++;
+				j->mf_done = true;
+				j->compressible_mf = compressible;
+				act = route(j);
 				t_last_mf = now_s();
 				blk_busy += tw1 - tw0;
 				mf_busy += tw2 - tw1;
 				d2h_busy += t_last_mf - tw2;
-				cv_enc.notify_one();
+			}
+			if (act == 1) {
+				if (!j->cancelled)
+					store_raw(j);
+				mark_finished(j, true);
 			}
 		}
 	}
@@ -373,6 +484,123 @@ struct Input {
 	int64_t n = 0;
 };
 
+// Everything the main thread needs to feed blocks to the pipeline while the scan is running.
+struct Feeder {
+	Pipeline &P;
+	hipStream_t ms, ls; // scan/gather stream, current lz4 gate stream
+	std::vector<hipStream_t> gate_streams; // gate launches last seconds each: they must overlap one another
+	size_t gate_rr = 0;
+	std::vector<std::unique_ptr<Job>> owned; // every job ever created (early, final, discarded)
+	std::vector<Lz4Batch> batches;
+	// gate job descriptors / results live in one arena allocated up front: hipMalloc/hipFree inside the
+	// scan would synchronise the whole device (and with it the multi-second gate launches)
+	Lz4Job *d_job_arena = nullptr;
+	int *d_res_arena = nullptr;
+	size_t arena_cap = 0, arena_used = 0;
+	int ret = 0;
+
+	Feeder(Pipeline &p) : P(p), ms(nullptr), ls(nullptr) {}
+
+	Job *new_job(ChunkCtx *cc, const BlockRef &br)
+	{
+		std::unique_ptr<Job> j(new Job());
+		j->chunk = cc;
+		j->ref = br;
+		j->gate_needed = P.sz.lz4_test && !P.sz.no_compress && br.streamno == 1 && br.len >= 64 && br.len <= 100 * 1048576;
+		Job *r = j.get();
+		owned.push_back(std::move(j));
+		return r;
+	}
+
+	// queue blocks for the finder and launch their lz4 gate (asynchronously, on `ls`)
+	int submit(const std::vector<Job *> &jobs)
+	{
+		if (jobs.empty())
+			return 0;
+		{
+			std::lock_guard<std::mutex> lk(P.mu);
+			for (Job *j : jobs)
+				P.gpu_queue.push_back(j);
+			P.cv_jobs.notify_all();
+		}
+		Lz4Batch b;
+		std::vector<Lz4Job> lj;
+		for (Job *j : jobs)
+			if (j->gate_needed) {
+				Lz4Job q;
+				q.src = j->chunk->d_stream1 + j->ref.off;
+				q.src_size = (int)j->ref.len;
+				q.dst_capacity = (int)j->ref.len + 1;
+				lj.push_back(q);
+				b.jobs.push_back(j);
+				b.bytes += j->ref.len;
+			}
+		if (lj.empty())
+			return 0;
+		if (arena_used + lj.size() > arena_cap)
+			return LRZGPU_E_INTERNAL;
+		b.d_jobs = d_job_arena + arena_used;
+		b.d_res = d_res_arena + arena_used;
+		arena_used += lj.size();
+		// descriptors go up on the (idle) scan stream: `ls` may still be busy with earlier gate launches
+		if (hipMemcpyAsync(b.d_jobs, lj.data(), lj.size() * sizeof(Lz4Job), hipMemcpyHostToDevice, ms) != hipSuccess ||
+		    hipStreamSynchronize(ms) != hipSuccess)
+			return LRZGPU_E_HIP;
+		ls = gate_streams[gate_rr++ % gate_streams.size()];
+		b.timer = new EventTimer(ls);
+		int lr = lz4_sizes_device(b.d_jobs, (int)lj.size(), b.d_res, ls);
+		b.timer->stop();
+		if (lr != 0 || hipEventCreate(&b.ev) != hipSuccess || hipEventRecord(b.ev, ls) != hipSuccess)
+			return LRZGPU_E_HIP;
+		batches.push_back(std::move(b));
+		return 0;
+	}
+
+	// collect finished gate launches (all of them when `wait`)
+	int poll(bool wait)
+	{
+		for (size_t k = 0; k < batches.size();) {
+			Lz4Batch &b = batches[k];
+			hipError_t q = wait ? hipEventSynchronize(b.ev) : hipEventQuery(b.ev);
+			if (q == hipErrorNotReady) {
+				k++;
+				continue;
+			}
+			if (q != hipSuccess)
+				return LRZGPU_E_HIP;
+			std::vector<int> res(b.jobs.size());
+			if (hipMemcpy(res.data(), b.d_res, res.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+				return LRZGPU_E_HIP;
+			{
+				ProfileStore &ps = ProfileStore::get();
+				std::lock_guard<std::mutex> lk(ps.mu);
+				ps.p.lz4_ms += b.timer->ms();
+				ps.p.lz4_launches++;
+				ps.p.lz4_bytes += b.bytes;
+			}
+			std::vector<Job *> raw;
+			{
+				std::lock_guard<std::mutex> lk(P.mu);
+				for (size_t i = 0; i < b.jobs.size(); i++) {
+					b.jobs[i]->lz4_size = res[i];
+					b.jobs[i]->lz4_ready = true;
+					if (P.route(b.jobs[i]) == 1)
+						raw.push_back(b.jobs[i]);
+				}
+			}
+			for (Job *j : raw) {
+				if (!j->cancelled)
+					P.store_raw(j);
+				P.mark_finished(j, true);
+			}
+			delete b.timer;
+			(void)hipEventDestroy(b.ev);
+			batches.erase(batches.begin() + (long)k);
+		}
+		return 0;
+	}
+};
+
 int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out, bool with_magic)
 {
 	int rc = select_device(ctl->device);
@@ -388,11 +616,12 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 		return LRZGPU_E_PARAM; // levels 1-4 use the HC5 fast path: outside this library
 	P.n_encoders = ctl->host_threads > 0 ? ctl->host_threads : (ctl->threads > 0 ? ctl->threads : 1);
 	P.n_gpu_workers = ctl->gpu_slots > 0 ? ctl->gpu_slots : 3;
-	P.enc_limit = (size_t)P.n_encoders + 2;
+	P.held_limit = (size_t)P.n_encoders + (size_t)P.n_gpu_workers + 2;
 	ctl->stream_bufsize = P.sz.stream_bufsize;
 	ctl->dictSize_used = P.sz.dict_size;
 	ctl->threads_used = P.sz.threads;
 	ctl->st_size = in.n;
+	const bool speculate = !getenv("LRZGPU_NO_OVERLAP");
 	if (ctl->verbose)
 		fprintf(stderr, "lrzgpu: threads %d bufsize %lld dict %u chunk %lld encoders %d gpu workers %d\n", P.sz.threads,
 			(long long)P.sz.stream_bufsize, P.sz.dict_size, (long long)P.sz.max_chunk, P.n_encoders, P.n_gpu_workers);
@@ -430,20 +659,68 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 		m.finish(digest);
 	});
 
+	P.mask_words = speculate ? scan_cu_words(P.scan_mask, P.rest_mask) : 0;
 	const double t0 = now_s();
-	double t_scan = 0, t_gather = 0, t_lz4 = 0;
+	double t_scan = 0, t_enq = 0;
+	int64_t n_early = 0, n_violations = 0;
 	P.start();
 
+	Feeder F(P);
 	std::vector<std::unique_ptr<ChunkCtx>> chunks;
+	std::vector<Job *> file_order; // every block of the file, in the order the reference writes them
 	ScanWorkspace *sw = nullptr;
 	int64_t victim_round = 0;
 	int64_t len = in.n;
 	int ret = 0;
-	hipStream_t ms;
-	if (hipStreamCreateWithFlags(&ms, hipStreamNonBlocking) != hipSuccess)
+	if (make_stream(&F.ms, P.mask_words, P.scan_mask, true) != hipSuccess)
 		ret = LRZGPU_E_HIP;
+	for (int k = 0; k < 6 && !ret; k++) {
+		hipStream_t gs;
+		if (make_stream(&gs, P.mask_words, P.rest_mask) != hipSuccess)
+			ret = LRZGPU_E_HIP;
+		else
+			F.gate_streams.push_back(gs);
+	}
+	hipStream_t ms = F.ms;
+	{
+		const int64_t per_chunk = (P.sz.max_chunk < in.n ? P.sz.max_chunk : in.n) / P.sz.stream_bufsize + 8;
+		const int64_t nchunks = in.n / (P.sz.max_chunk > 0 ? P.sz.max_chunk : 1) + 2;
+		F.arena_cap = (size_t)(per_chunk * nchunks * 2);
+		if (!ret && (hipMalloc(&F.d_job_arena, F.arena_cap * sizeof(Lz4Job)) != hipSuccess || hipMalloc(&F.d_res_arena, F.arena_cap * sizeof(int)) != hipSuccess))
+			ret = LRZGPU_E_NOMEM;
+	}
 	uint8_t *d_upload = nullptr; // chunk staging when the input is on the host
+	CopyRun *d_runs = nullptr;
+	size_t d_runs_cap = 0;
 	int pass = 0;
+	const int64_t bufsize = P.sz.stream_bufsize;
+
+	// gathers stream-1 bytes [S0, S1) from `runs` (absolute dst offsets)
+	auto gather = [&](const uint8_t *d_chunk, ChunkCtx *cc, const std::vector<CopyRun> &runs, int64_t S0, int64_t S1) -> int {
+		if (runs.empty() || S1 <= S0)
+			return 0;
+		if (runs.size() > d_runs_cap) {
+			if (d_runs)
+				(void)hipFree(d_runs);
+			d_runs_cap = runs.size() * 2 + 64;
+			if (hipMalloc(&d_runs, d_runs_cap * sizeof(CopyRun)) != hipSuccess)
+				return LRZGPU_E_NOMEM;
+		}
+		if (hipMemcpyAsync(d_runs, runs.data(), runs.size() * sizeof(CopyRun), hipMemcpyHostToDevice, ms) != hipSuccess)
+			return LRZGPU_E_HIP;
+		EventTimer tg(ms);
+		int gr = gather_runs_device(d_chunk, cc->d_stream1, d_runs, (int)runs.size(), S0, S1, ms);
+		tg.stop();
+		if (gr != 0 || hipStreamSynchronize(ms) != hipSuccess)
+			return LRZGPU_E_HIP;
+		ProfileStore &ps = ProfileStore::get();
+		std::lock_guard<std::mutex> lk(ps.mu);
+		ps.p.gather_ms += tg.ms();
+		ps.p.gather_launches++;
+		ps.p.gather_bytes += S1 - S0;
+		return 0;
+	};
+
 	while (!ret && (!pass || len > 0)) { // src/rzip.c:1041
 		pass++;
 		const int64_t offset = in.n - len;
@@ -454,7 +731,6 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 		cc->chunk_bytes = chunk_bytes_for(chunk_size);
 
 		const uint8_t *d_chunk = nullptr;
-		bool own_chunk = false;
 		if (in.dev && ((uintptr_t)(in.dev + offset) & 15) == 0 && offset + chunk_size < in.n) {
 			d_chunk = in.dev + offset; // interior chunk of a resident buffer: readable past its end
 		} else {
@@ -477,18 +753,99 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 				break;
 			}
 			d_chunk = d_upload;
-			own_chunk = true;
 		}
-		(void)own_chunk;
-
+		if (hipMalloc(&cc->d_stream1, (size_t)chunk_size + 256) != hipSuccess) {
+			ret = LRZGPU_E_NOMEM;
+			break;
+		}
 		if (!sw && scan_workspace_create(&sw, P.sz.rzip_level, P.sz.max_chunk < in.n ? P.sz.max_chunk : in.n) != 0) {
 			ret = LRZGPU_E_NOMEM;
 			break;
 		}
+
+		// ---- speculative early emission while the scan runs -----------------------------------
+		int64_t E = 0;          // chunk position up to which stream-1 bytes have been gathered
+		int64_t S = 0;          // stream-1 bytes gathered so far
+		int64_t seen = 0;       // match records consumed
+		int64_t blocks_out = 0; // full stream-1 blocks already submitted
+		bool violated = false;
+		std::map<int64_t, Job *> early; // stream-1 offset -> job
+		std::vector<MatchRec> rec_buf;
+		ChunkCtx *ccp = cc.get();
+
+		auto advance = [&](const ScanState &h, int64_t upto, bool final_call, const std::vector<MatchRec> *final_recs) -> int {
+			// new records
+			const int64_t nrec = final_recs ? (int64_t)final_recs->size() : h.n_records;
+			std::vector<CopyRun> runs;
+			const int64_t S_before = S;
+			if (nrec > seen) {
+				const MatchRec *rp;
+				if (final_recs)
+					rp = final_recs->data() + seen;
+				else {
+					rec_buf.resize((size_t)(nrec - seen));
+					if (hipMemcpy(rec_buf.data(), sw->records + seen, (size_t)(nrec - seen) * sizeof(MatchRec), hipMemcpyDeviceToHost) != hipSuccess)
+						return LRZGPU_E_HIP;
+					rp = rec_buf.data();
+				}
+				for (int64_t k = 0; k < nrec - seen && !violated; k++) {
+					const MatchRec &r = rp[k];
+					if (r.p < E) {
+						violated = true; // a match reaches back over bytes already emitted as literals
+						break;
+					}
+					if (E < r.p) {
+						runs.push_back(CopyRun{E, S, r.p - E});
+						S += r.p - E;
+					}
+					E = r.p + r.len;
+				}
+				seen = nrec;
+			}
+			if (violated)
+				return 0;
+			int64_t Fp = final_call ? chunk_size : upto - SPEC_MARGIN;
+			if (!final_call && h.cur_len > 0 && h.cur_p < Fp)
+				Fp = h.cur_p;
+			if (Fp > chunk_size)
+				Fp = chunk_size;
+			if (Fp > E) {
+				if (!runs.empty() && runs.back().src_off + runs.back().len == E)
+					runs.back().len += Fp - E;
+				else
+					runs.push_back(CopyRun{E, S, Fp - E});
+				S += Fp - E;
+				E = Fp;
+			}
+			if (S > S_before) {
+				int g = gather(d_chunk, ccp, runs, S_before, S);
+				if (g)
+					return g;
+			}
+			if (final_call)
+				return 0;
+			std::vector<Job *> fresh;
+			while ((blocks_out + 1) * bufsize <= S) {
+				Job *j = F.new_job(ccp, BlockRef{1, blocks_out * bufsize, bufsize});
+				early[blocks_out * bufsize] = j;
+				fresh.push_back(j);
+				blocks_out++;
+				n_early++;
+			}
+			int sr2 = F.submit(fresh);
+			if (sr2)
+				return sr2;
+			return F.poll(false);
+		};
+
+		ScanProgressFn progress = nullptr;
+		if (speculate)
+			progress = [&](const ScanState &h, int64_t upto) -> int { return advance(h, upto, false, nullptr); };
+
 		ScanResult sr;
-		int r = scan_chunk_device(sw, d_chunk, chunk_size, P.sz.rzip_level, &victim_round, &sr, ms);
+		int r = scan_chunk_device(sw, d_chunk, chunk_size, P.sz.rzip_level, &victim_round, &sr, ms, progress);
 		if (r) {
-			ret = r == -4 ? LRZGPU_E_NOMEM : LRZGPU_E_INTERNAL;
+			ret = r < -50 ? r : (r == -4 ? LRZGPU_E_NOMEM : LRZGPU_E_INTERNAL);
 			break;
 		}
 		t_scan = now_s();
@@ -496,133 +853,97 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 		emit_streams(sr.records, chunk_size, cc->chunk_bytes, sr.crc, &er);
 		cc->stream0.swap(er.stream0);
 		cc->stream1_len = er.stream1_len;
-		if (hipMalloc(&cc->d_stream1, (size_t)er.stream1_len + 256) != hipSuccess) {
-			ret = LRZGPU_E_NOMEM;
-			break;
-		}
-		if (!er.runs.empty()) {
-			CopyRun *d_runs = nullptr;
-			if (hipMalloc(&d_runs, er.runs.size() * sizeof(CopyRun)) != hipSuccess) {
-				ret = LRZGPU_E_NOMEM;
+		if (speculate && !violated) {
+			int a = advance(sr.final_state, chunk_size, true, &sr.records);
+			if (a) {
+				ret = a;
 				break;
 			}
-			if (hipMemcpyAsync(d_runs, er.runs.data(), er.runs.size() * sizeof(CopyRun), hipMemcpyHostToDevice, ms) != hipSuccess) {
-				(void)hipFree(d_runs);
-				ret = LRZGPU_E_HIP;
-				break;
-			}
-			EventTimer tg(ms);
-			int gr = gather_runs_device(d_chunk, cc->d_stream1, d_runs, (int)er.runs.size(), er.stream1_len, ms);
-			tg.stop();
-			if (gr != 0 || hipMemsetAsync(cc->d_stream1 + er.stream1_len, 0, 256, ms) != hipSuccess || hipStreamSynchronize(ms) != hipSuccess) {
-				(void)hipFree(d_runs);
-				ret = LRZGPU_E_HIP;
-				break;
-			}
-			(void)hipFree(d_runs);
-			{
-				ProfileStore &ps = ProfileStore::get();
-				std::lock_guard<std::mutex> lk(ps.mu);
-				ps.p.gather_ms += tg.ms();
-				ps.p.gather_launches++;
-				ps.p.gather_bytes += er.stream1_len;
-			}
 		}
-		t_gather = now_s();
-		// block list in flush order
-		std::vector<BlockRef> refs;
-		block_order(cc->stream0, cc->chunk_bytes, cc->stream1_len, P.sz.stream_bufsize, &refs);
-		cc->pending = (int)refs.size();
-		std::vector<Job *> new_jobs;
-		{
-			std::lock_guard<std::mutex> lk(P.mu);
-			for (const BlockRef &br : refs) {
-				std::unique_ptr<Job> j(new Job());
-				j->chunk = cc.get();
-				j->ref = br;
-				new_jobs.push_back(j.get());
-				P.all_jobs.push_back(std::move(j));
-			}
-		}
-		// lz4 gate for all stream-1 blocks of the chunk in one launch (one wavefront per block)
-		if (P.sz.lz4_test) {
-			std::vector<Lz4Job> lj;
-			std::vector<Job *> lz_jobs;
-			for (Job *j : new_jobs)
-				if (j->ref.streamno == 1 && j->ref.len >= 64 && j->ref.len <= 100 * 1048576) {
-					Lz4Job q;
-					q.src = cc->d_stream1 + j->ref.off;
-					q.src_size = (int)j->ref.len;
-					q.dst_capacity = (int)j->ref.len + 1;
-					lj.push_back(q);
-					lz_jobs.push_back(j);
-				}
-			if (!lj.empty()) {
-				Lz4Job *d_jobs = nullptr;
-				int *d_res = nullptr;
-				if (hipMalloc(&d_jobs, lj.size() * sizeof(Lz4Job)) != hipSuccess || hipMalloc(&d_res, lj.size() * sizeof(int)) != hipSuccess) {
-					ret = LRZGPU_E_NOMEM;
-					break;
-				}
-				// enqueue the blocks for the finder first: it runs concurrently with the gate
+		if (!speculate || violated || S != er.stream1_len) {
+			// (re)build stream 1 from the final run table; early blocks, if any, are void
+			if (!early.empty()) {
+				n_violations++;
 				{
 					std::lock_guard<std::mutex> lk(P.mu);
-					for (Job *j : new_jobs)
-						P.gpu_queue.push_back(j);
-					P.cv_jobs.notify_all();
+					for (auto &kv : early)
+						kv.second->cancelled = true;
 				}
-				new_jobs.clear();
-				std::vector<int> res(lj.size());
-				if (hipMemcpyAsync(d_jobs, lj.data(), lj.size() * sizeof(Lz4Job), hipMemcpyHostToDevice, ms) != hipSuccess) {
-					ret = LRZGPU_E_HIP;
+				int pr = F.poll(true);
+				if (pr) {
+					ret = pr;
 					break;
 				}
-				EventTimer tl(ms);
-				int lr = lz4_sizes_device(d_jobs, (int)lj.size(), d_res, ms);
-				tl.stop();
-				if (lr != 0 || hipMemcpyAsync(res.data(), d_res, lj.size() * sizeof(int), hipMemcpyDeviceToHost, ms) != hipSuccess ||
-				    hipStreamSynchronize(ms) != hipSuccess) {
-					ret = LRZGPU_E_HIP;
-					break;
-				}
-				{
-					ProfileStore &ps = ProfileStore::get();
-					std::lock_guard<std::mutex> lk(ps.mu);
-					ps.p.lz4_ms += tl.ms();
-					ps.p.lz4_launches++;
-					for (const Lz4Job &q : lj)
-						ps.p.lz4_bytes += q.src_size;
-				}
-				(void)hipFree(d_jobs);
-				(void)hipFree(d_res);
-				std::lock_guard<std::mutex> lk(P.mu);
-				for (size_t k = 0; k < lz_jobs.size(); k++) {
-					lz_jobs[k]->lz4_size = res[k];
-					lz_jobs[k]->lz4_ready = true;
-				}
-				P.cv_lz4.notify_all();
+				std::unique_lock<std::mutex> lk(P.mu);
+				P.cv_done.wait(lk, [&] {
+					if (P.err)
+						return true;
+					for (auto &kv : early)
+						if (!kv.second->finished)
+							return false;
+					return true;
+				});
+				early.clear();
+			}
+			int g = gather(d_chunk, ccp, er.runs, 0, er.stream1_len);
+			if (g) {
+				ret = g;
+				break;
 			}
 		}
-		if (!new_jobs.empty()) {
-			std::lock_guard<std::mutex> lk(P.mu);
-			for (Job *j : new_jobs)
-				P.gpu_queue.push_back(j);
-			P.cv_jobs.notify_all();
+		if (hipMemsetAsync(cc->d_stream1 + er.stream1_len, 0, 256, ms) != hipSuccess || hipStreamSynchronize(ms) != hipSuccess) {
+			ret = LRZGPU_E_HIP;
+			break;
 		}
-		t_lz4 = now_s();
+		// the chunk's blocks in the order the reference flushes them; early blocks are reused
+		std::vector<BlockRef> refs;
+		block_order(cc->stream0, cc->chunk_bytes, cc->stream1_len, bufsize, &refs);
+		std::vector<Job *> fresh;
+		for (const BlockRef &br : refs) {
+			Job *j = nullptr;
+			if (br.streamno == 1 && br.len == bufsize) {
+				auto it = early.find(br.off);
+				if (it != early.end()) {
+					j = it->second;
+					early.erase(it);
+				}
+			}
+			if (!j) {
+				j = F.new_job(ccp, br);
+				fresh.push_back(j);
+			}
+			file_order.push_back(j);
+		}
+		if (!early.empty()) { // cannot happen: every early block is a full stream-1 block of the final layout
+			ret = LRZGPU_E_INTERNAL;
+			break;
+		}
+		int s2 = F.submit(fresh);
+		if (s2) {
+			ret = s2;
+			break;
+		}
+		t_enq = now_s();
 		chunks.push_back(std::move(cc));
 		len -= chunk_size;
 	}
 	if (ret)
 		P.fail(ret);
+	else {
+		int pr = F.poll(true);
+		if (pr) {
+			ret = pr;
+			P.fail(ret);
+		}
+	}
 
-	// wait for every block
+	// wait for every block (discarded early ones included: they reference device buffers)
 	{
 		std::unique_lock<std::mutex> lk(P.mu);
 		P.cv_done.wait(lk, [&] {
 			if (P.err)
 				return true;
-			for (auto &j : P.all_jobs)
+			for (auto &j : F.owned)
 				if (!j->finished)
 					return false;
 			return true;
@@ -639,7 +960,21 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 	scan_workspace_destroy(sw);
 	if (d_upload)
 		(void)hipFree(d_upload);
-	(void)hipStreamDestroy(ms);
+	if (d_runs)
+		(void)hipFree(d_runs);
+	for (Lz4Batch &b : F.batches) {
+		delete b.timer;
+		if (b.ev)
+			(void)hipEventDestroy(b.ev);
+	}
+	if (F.d_job_arena)
+		(void)hipFree(F.d_job_arena);
+	if (F.d_res_arena)
+		(void)hipFree(F.d_res_arena);
+	if (F.ms)
+		(void)hipStreamDestroy(F.ms);
+	for (hipStream_t gs : F.gate_streams)
+		(void)hipStreamDestroy(gs);
 	for (auto &c : chunks)
 		if (c->d_stream1) {
 			(void)hipFree(c->d_stream1);
@@ -654,8 +989,8 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 	size_t ji = 0;
 	for (size_t ci = 0; ci < chunks.size(); ci++) {
 		std::vector<DoneBlock> blocks;
-		while (ji < P.all_jobs.size() && P.all_jobs[ji]->chunk == chunks[ci].get()) {
-			blocks.push_back(std::move(P.all_jobs[ji]->done));
+		while (ji < file_order.size() && file_order[ji]->chunk == chunks[ci].get()) {
+			blocks.push_back(std::move(file_order[ji]->done));
 			ji++;
 		}
 		write_chunk(out, chunks[ci]->chunk_bytes, ci + 1 == chunks.size(), chunks[ci]->size, blocks);
@@ -663,8 +998,9 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 	out->insert(out->end(), digest, digest + 16);
 	memcpy(ctl->hash_resblock, digest, 16);
 	if (tracing())
-		fprintf(stderr, "lrzgpu driver: scan %.2f  gather %.2f  lz4+enqueue %.2f  last finder %.2f  last encode %.2f  all blocks %.2f  md5 joined %.2f  assembled %.2f s (since start; last chunk); worker sums: block copy+gate %.2f finder %.2f lists D2H %.2f s\n",
-			t_scan - t0, t_gather - t0, t_lz4 - t0, P.t_last_mf - t0, P.t_last_enc - t0, t_blocks - t0, t_md5 - t0, now_s() - t0, P.blk_busy, P.mf_busy, P.d2h_busy);
+		fprintf(stderr, "lrzgpu driver: scan done %.2f  blocks queued %.2f  last finder %.2f  last encode %.2f  all blocks %.2f  md5 joined %.2f  assembled %.2f s (since start; last chunk); early blocks %lld, redone chunks %lld; worker sums: block copy+gate %.2f finder %.2f lists D2H %.2f s\n",
+			t_scan - t0, t_enq - t0, P.t_last_mf - t0, P.t_last_enc - t0, t_blocks - t0, t_md5 - t0, now_s() - t0,
+			(long long)n_early, (long long)n_violations, P.blk_busy, P.mf_busy, P.d2h_busy);
 	if (with_magic) {
 		uint8_t magic[21];
 		write_magic(magic, P.sz, in.n);

@@ -463,7 +463,15 @@ struct Encoder {
 		if (ml.wait_ready)
 			ml.wait_ready(ml.ctx, mf_pos);
 		unsigned np = ml.counts[mf_pos];
-		memcpy(matches, ml.pairs + mf_off, (size_t)np * 4);
+		if (ml.packed) {
+			const uint32_t *src = ml.pairs + (mf_off >> 1);
+			for (unsigned k = 0; k < np; k += 2) {
+				const uint32_t v = src[k >> 1];
+				matches[k] = v >> 25;
+				matches[k + 1] = v & 0x1FFFFFFu;
+			}
+		} else
+			memcpy(matches, ml.pairs + mf_off, (size_t)np * 4);
 		mf_off += np;
 		mf_pos++;
 		*num_pairs_res = np;

@@ -18,6 +18,7 @@ namespace lrzgpu {
 struct MatchLists {
 	const uint8_t *counts = nullptr; // n entries
 	const uint32_t *pairs = nullptr;
+	bool packed = false; // pairs[] holds one u32 per pair: len << 25 | dist-1 (counts[] still counts 2 per pair)
 	// Optional streaming hook: called before position `upto` is first read, so a producer that is
 	// still filling the arrays can block the consumer.  May be null.
 	void (*wait_ready)(void *ctx, size_t upto) = nullptr;

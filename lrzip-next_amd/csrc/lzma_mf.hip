@@ -235,9 +235,11 @@ struct CountToU64 {
 	__host__ __device__ unsigned long long operator()(const uint8_t &c) const { return (unsigned long long)c; }
 };
 
+// pack != 0: one u32 per (len, dist-1) pair = len << 25 | dist-1 (dictionaries up to 32 MiB, len < 128):
+// halves the PCIe volume of the lists; the host parser unpacks on the fly.
 __global__ void __launch_bounds__(256) k_gather(const uint8_t *__restrict__ counts, const uint64_t *__restrict__ tmp_start,
 						const unsigned long long *__restrict__ offsets, const uint32_t *__restrict__ pool,
-						uint32_t *__restrict__ out, uint32_t n, unsigned long long pool_cap)
+						uint32_t *__restrict__ out, uint32_t n, unsigned long long pool_cap, int pack)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	uint32_t stride = gridDim.x * blockDim.x;
@@ -246,9 +248,15 @@ __global__ void __launch_bounds__(256) k_gather(const uint8_t *__restrict__ coun
 		if (!c || tmp_start[i] + c > pool_cap || offsets[i] + c > pool_cap)
 			continue;
 		const uint32_t *s = pool + tmp_start[i];
-		uint32_t *d = out + offsets[i];
-		for (uint32_t k = 0; k < c; k++)
-			d[k] = s[k];
+		if (pack) {
+			uint32_t *d = out + (offsets[i] >> 1);
+			for (uint32_t k = 0; k < c; k += 2)
+				d[k >> 1] = (s[k] << 25) | s[k + 1];
+		} else {
+			uint32_t *d = out + offsets[i];
+			for (uint32_t k = 0; k < c; k++)
+				d[k] = s[k];
+		}
 	}
 }
 
@@ -330,8 +338,10 @@ static inline int grid_for(size_t n, int block) // ~8 blocks per CU, grid-stride
 // Runs the finder on d_src[0..n) (device). Results stay on the device in w->counts / w->pool_out;
 // *total_entries receives the number of u32 entries.
 int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict, uint32_t fb, uint32_t cut,
-		  hipStream_t s, unsigned long long *total_entries)
+		  hipStream_t s, unsigned long long *total_entries, bool pack)
 {
+	if (pack && (dict > (1u << 25) || fb > 127))
+		return -3;
 	if (n > w->max_n || n >= 0xFFFFFFF0ull)
 		return -2;
 	if (2 * (cut + 2) > (uint32_t)kMaxRec || 2 * (cut + 2) > 255)
@@ -392,7 +402,7 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 		hipcub::TransformInputIterator<unsigned long long, CountToU64, const uint8_t *> it(w->counts, CountToU64());
 		HIPCHK(hipcub::DeviceScan::ExclusiveSum(w->cub_tmp, tb, it, (unsigned long long *)w->offsets, (int)n, s));
 		hipLaunchKernelGGL(k_gather, dim3(grid_for(n, 256)), dim3(256), 0, s, w->counts, w->tmp_start,
-				   (const unsigned long long *)w->offsets, w->pool_tmp, w->pool_out, (uint32_t)n, w->pool_cap);
+				   (const unsigned long long *)w->offsets, w->pool_tmp, w->pool_out, (uint32_t)n, w->pool_cap, pack ? 1 : 0);
 		hipLaunchKernelGGL(k_total, dim3(1), dim3(1), 0, s, w->counts, (const unsigned long long *)w->offsets, (uint32_t)n, d_total);
 	}
 	t_all.stop();

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 namespace lrzgpu {
@@ -62,15 +63,21 @@ struct ScanResult {
 int scan_workspace_create(ScanWorkspace **out, int rzip_level, int64_t max_chunk);
 void scan_workspace_destroy(ScanWorkspace *w);
 
+// Called after every resolver segment (stream already synchronised): `h` is the automaton state,
+// `scanned_upto` the last position examined; records [0, h.n_records) in w->records are final.
+// A non-zero return aborts the scan with that code.
+typedef std::function<int(const ScanState &h, int64_t scanned_upto)> ScanProgressFn;
+
 // Scans d_chunk[0..chunk_size) (device). victim_round in/out.
 int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_size, int rzip_level,
-		      int64_t *victim_round, ScanResult *res, hipStream_t s);
+		      int64_t *victim_round, ScanResult *res, hipStream_t s, const ScanProgressFn &progress = nullptr);
 
 // literal gather: dst[dst_off + k] = src[src_off + k] for each run (device pointers)
 struct CopyRun {
 	int64_t src_off, dst_off, len;
 };
-int gather_runs_device(const uint8_t *d_src, uint8_t *d_dst, const CopyRun *d_runs, int nruns, int64_t total_len, hipStream_t s);
+// writes destination bytes [dst_lo, dst_hi) only (runs must cover that range, sorted by dst_off)
+int gather_runs_device(const uint8_t *d_src, uint8_t *d_dst, const CopyRun *d_runs, int nruns, int64_t dst_lo, int64_t dst_hi, hipStream_t s);
 
 // CRC-32/IEEE of a device buffer
 int crc32_device(ScanWorkspace *w, const uint8_t *d_buf, int64_t n, uint32_t *crc, hipStream_t s);

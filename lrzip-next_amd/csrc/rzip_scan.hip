@@ -1329,13 +1329,13 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 // K4: literal gather (stream 1)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_gather_runs(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
-						     const CopyRun *__restrict__ runs, int nruns, i64 total)
+						     const CopyRun *__restrict__ runs, int nruns, i64 dst_lo, i64 dst_hi)
 {
-	// each workgroup owns 64 KiB of destination
-	const i64 tile0 = (i64)blockIdx.x * 65536;
+	// each workgroup owns one 64 KiB-aligned tile of the destination, clipped to [dst_lo, dst_hi)
+	const i64 tile0 = (dst_lo & ~(i64)65535) + (i64)blockIdx.x * 65536;
 	i64 tile1 = tile0 + 65536;
-	if (tile1 > total)
-		tile1 = total;
+	if (tile1 > dst_hi)
+		tile1 = dst_hi;
 	// binary search: last run with dst_off <= tile0
 	int lo = 0, hi = nruns - 1;
 	while (lo < hi) {
@@ -1351,7 +1351,7 @@ __global__ void __launch_bounds__(256) k_gather_runs(const uint8_t *__restrict__
 			r++;
 		CopyRun cr = runs[r];
 		i64 in_run = d - cr.dst_off;
-		if (in_run + 16 <= cr.len && d + 16 <= tile1) {
+		if (d >= dst_lo && in_run >= 0 && in_run + 16 <= cr.len && d + 16 <= tile1) {
 			U128u v = *reinterpret_cast<const U128u *>(src + cr.src_off + in_run);
 			uint4 o;
 			o.x = (uint32_t)v.a;
@@ -1363,20 +1363,25 @@ __global__ void __launch_bounds__(256) k_gather_runs(const uint8_t *__restrict__
 			int rr = r;
 			for (int k = 0; k < 16 && d + k < tile1; k++) {
 				i64 dd = d + k;
+				if (dd < dst_lo)
+					continue;
 				while (rr + 1 < nruns && runs[rr + 1].dst_off <= dd)
 					rr++;
-				dst[dd] = src[runs[rr].src_off + (dd - runs[rr].dst_off)];
+				const i64 ir = dd - runs[rr].dst_off;
+				if (ir >= 0 && ir < runs[rr].len)
+					dst[dd] = src[runs[rr].src_off + ir];
 			}
 		}
 	}
 }
 
-int gather_runs_device(const uint8_t *d_src, uint8_t *d_dst, const CopyRun *d_runs, int nruns, int64_t total_len, hipStream_t s)
+int gather_runs_device(const uint8_t *d_src, uint8_t *d_dst, const CopyRun *d_runs, int nruns, int64_t dst_lo, int64_t dst_hi, hipStream_t s)
 {
-	if (total_len <= 0 || nruns <= 0)
+	if (dst_hi <= dst_lo || nruns <= 0)
 		return 0;
-	int64_t tiles = (total_len + 65535) / 65536;
-	hipLaunchKernelGGL(k_gather_runs, dim3((unsigned)tiles), dim3(256), 0, s, d_src, d_dst, d_runs, nruns, (i64)total_len);
+	const int64_t first = dst_lo & ~(int64_t)65535;
+	int64_t tiles = (dst_hi - first + 65535) / 65536;
+	hipLaunchKernelGGL(k_gather_runs, dim3((unsigned)tiles), dim3(256), 0, s, d_src, d_dst, d_runs, nruns, (i64)dst_lo, (i64)dst_hi);
 	return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -1588,7 +1593,7 @@ void scan_workspace_destroy(ScanWorkspace *w)
 }
 
 int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_size, int rzip_level,
-		      int64_t *victim_round, ScanResult *res, hipStream_t s)
+		      int64_t *victim_round, ScanResult *res, hipStream_t s, const ScanProgressFn &progress)
 {
 	unsigned mb, freq, chain;
 	rzip_level_params(rzip_level, &mb, &freq, &chain);
@@ -1651,6 +1656,11 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 			return h.error == 1 ? -4 : -5;
 		p_skip = h.p_skip > seg_hi - 1 ? h.p_skip : seg_hi - 1;
 		min_mask = h.min_mask;
+		if (progress) {
+			int pr = progress(h, p_skip);
+			if (pr)
+				return pr;
+		}
 	}
 	if (chunk_size > 0 && end > 0) {
 		// state already in h from the last segment

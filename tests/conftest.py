@@ -4,6 +4,11 @@ import sys
 
 import pytest
 
+try:  # torch bundles its own HIP runtime: it has to be the first one loaded in the process
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, HERE)
