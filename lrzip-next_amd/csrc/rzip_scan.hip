@@ -283,7 +283,28 @@ struct Resolver {
 			if (done >= total)
 				return total;
 		}
-		// phase 2: 16 KiB per step (16 x 16 B per lane, all loads in flight together)
+		// phase 2a: whole 16 KiB steps while everything is equal: 32 unconditional 16-byte loads per
+		// lane in flight, one ballot per step (a multi-GiB copy streams at wave bandwidth)
+		while (done + 16384 <= total) {
+			const uint8_t *pa = buf + p + done + (i64)lane * 16;
+			const uint8_t *pb = buf + op + done + (i64)lane * 16;
+			U128u va[16], vb[16];
+#pragma unroll
+			for (int c = 0; c < 16; c++) {
+				va[c] = *reinterpret_cast<const U128u *>(pa + c * 1024);
+				vb[c] = *reinterpret_cast<const U128u *>(pb + c * 1024);
+			}
+			u64 diff = 0;
+#pragma unroll
+			for (int c = 0; c < 16; c++)
+				diff |= (va[c].a ^ vb[c].a) | (va[c].b ^ vb[c].b);
+			if (__ballot(diff != 0))
+				break; // locate the byte with the exact step below
+			done += 16384;
+		}
+		if (done >= total)
+			return total;
+		// phase 2b: 16 KiB per step with exact mismatch location
 		for (;;) {
 			int mism_chunk = 16; // first differing 16-byte piece among my 16
 			int mism_byte = 0;
