@@ -35,6 +35,7 @@ struct ScanState {
 	uint64_t sink; // keeps prefetch loads alive
 	// resolver diagnostics: batches, committed lanes, serial steps, first-stop reasons
 	// (complex, real match, conflict, no victim in reach, insert inside swept range)
+	int64_t dbg2[16]; // experiment counters, printed under LRZGPU_TRACE
 	int64_t dbg[16]; // [8..15]: shader-clock cycles per phase (refill, simulate, victims, conflict, apply, tail)
 };
 

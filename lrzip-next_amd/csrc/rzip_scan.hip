@@ -49,8 +49,8 @@ constexpr int PER_THREAD = 16;
 constexpr int WALK = 16;     // table slots a speculative lookup reads per step (one HBM round trip)
 constexpr int MAX_EQS = 32;  // round-robin eviction handled in the batch up to this max_chain_len
 constexpr int MAX_HITS = 24; // tag hits one speculative lookup may verify (more -> serial path)
-constexpr int CT_BITS = 10; // conflict map: 1024 granule entries for <= 320 writes per round
-constexpr int CT_SIZE = 1 << CT_BITS;
+constexpr int CF_BITS = 13; // conflict filter: 16-bit write counters per hashed 8-slot granule (<= 320 writes per round)
+constexpr int CF_WORDS = (1 << CF_BITS) / 2;
 
 typedef unsigned long long u64;
 typedef long long i64;
@@ -646,8 +646,7 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 	__shared__ u64 ring_tag[256];
 	__shared__ i64 hit_lds[MAX_HITS * 64];
 	__shared__ uint32_t eqs_lds[MAX_EQS * 64]; // per window ticket: slots of the first equal tags of the insert walk
-	__shared__ uint32_t ct_key[CT_SIZE];
-	__shared__ uint32_t ct_val[CT_SIZE];
+	__shared__ uint32_t cf_bits[CF_WORDS]; // all zero between rounds
 
 	Resolver R;
 	R.buf = buf;
@@ -668,6 +667,8 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 	R.stk_t = stk_t;
 	R.stk_off = stk_off;
 	R.stk_h = stk_h;
+	for (int k = threadIdx.x; k < CF_WORDS; k += 64)
+		cf_bits[k] = 0;
 
 	i64 p_skip = st->p_skip;
 	i64 cur_p = st->cur_p, cur_ofs = st->cur_ofs, cur_len = st->cur_len;
@@ -676,9 +677,14 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 	i64 inserts = st->inserts, lookups = st->lookups;
 	int error = st->error;
 	u64 sink = 0;
+	i64 miss_acc = 0; // tag_misses of committed batch lanes, per lane
 	i64 dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	i64 dbg2[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 	u64 tclk = __builtin_amdgcn_s_memtime();
+	const bool prof = (batch_mode & 2) != 0; // per-phase cycle laps cost ~2 SMEM round trips each: opt-in
 	auto lap = [&](int slot) {
+		if (!prof)
+			return;
 		const u64 now = __builtin_amdgcn_s_memtime();
 		dbg[slot] += (i64)(now - tclk);
 		tclk = now;
@@ -841,7 +847,7 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		const bool alive = has && w_pos > p_skip && (w_tag & R.min_mask) == R.min_mask;
 
 		// ---- serial path: pending lazy match, or batching disabled ----
-		if (!batch_mode || cur_len > 0) {
+		if (!(batch_mode & 1) || cur_len > 0) {
 			const i64 P = (i64)bcast64((u64)w_pos, 0);
 			const u64 T = bcast64(w_tag, 0);
 			const bool a0 = __shfl((int)alive, 0) != 0;
@@ -853,6 +859,19 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		}
 
 		const u64 better = mask_up(R.min_mask);
+		// the sweep of clean_one_from_hash() continues at clean_ptr: fetch its next 128 slots now so
+		// that the round trip overlaps the simulations (nothing writes the table before phase D)
+		const bool may_clean = R.hash_count + 64 > R.hash_limit;
+		Slot pre0, pre1;
+		pre0.offset = pre1.offset = 0;
+		pre0.t = pre1.t = 0;
+		if (may_clean) {
+			const i64 q0 = R.clean_ptr + lane;
+			if (q0 < tbl_size)
+				pre0 = tbl[q0];
+			if (q0 + 64 < tbl_size)
+				pre1 = tbl[q0 + 64];
+		}
 		lap(8);
 
 		// Phase A/B: lanes without a valid simulation run one against the table as it stands.
@@ -876,7 +895,6 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 				uint32_t neq = 0;
 				int steps = 0;
 				bool fin = !need_sim;
-				const uint32_t T_lo = (uint32_t)T, T_hi = (uint32_t)(T >> 32);
 				const uint32_t b_lo = (uint32_t)better;
 				const int t_ones = my_rank - 1; // trailing one bits of T
 				const uint32_t m_lo = t_ones >= 32 ? 0xFFFFFFFFu : ((1u << t_ones) - 1);
@@ -893,82 +911,93 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 					if (L.complex_)
 						fin = true;
 				}
+				const uint32_t s_lo = b_lo | m_lo; // a slot stops the insert when its tag lacks any of these bits
+				const u64 T64 = T;
+				// one step: the 16 slots at idx.. are in c8; the next 16 are fetched into n8 meanwhile
+				// (double buffering: later steps of a long walk do not expose the load latency again)
+#define A1_STEP(c8, n8) \
+				if (!fin) { \
+_Pragma("unroll") \
+					for (int q = 0; q < WALK; q++) \
+						n8[q] = *reinterpret_cast<const uint4 *>(&tbl[idx + WALK + q]); \
+ \
+					uint32_t E = 0, Bm = 0, S = 0, Q = 0; \
+_Pragma("unroll") \
+					for (int q = WALK - 1; q >= 0; q--) { \
+						const uint32_t tl = c8[q].z; \
+						const u64 t64 = ((u64)c8[q].w << 32) | tl; \
+						E = (E << 1) | (uint32_t)(t64 == 0); \
+						Bm = (Bm << 1) | (uint32_t)((tl & b_lo) != b_lo); \
+						S = (S << 1) | (uint32_t)((tl & s_lo) != s_lo); \
+						Q = (Q << 1) | (uint32_t)(t64 == T64); \
+					} \
+					steps += WALK; \
+					if (idx + WALK > tbl_size || steps > 512) { \
+						L.complex_ = true; \
+						L.hi = (uint32_t)(idx + WALK - 1 < tbl_size - 1 ? idx + WALK - 1 : tbl_size - 1); \
+						fin = true; \
+					} else { \
+						const int fe = E ? __ffs((int)E) - 1 : WALK; \
+						if (kind < 0 && L.ins) { \
+							const int s1 = S ? __ffs((int)S) - 1 : WALK; \
+							uint32_t eqb = Q & ((1u << s1) - 1); \
+							while (eqb) { \
+								const int q = __ffs((int)eqb) - 1; \
+								eqb &= eqb - 1; \
+								if (neq < MAX_EQS) \
+									eqs_lds[neq * 64 + w_ticket] = (uint32_t)(idx + q); \
+								if (++neq >= R.max_chain) { \
+									if (R.max_chain <= MAX_EQS) \
+										kind = 3; \
+									else \
+										L.complex_ = true; \
+									eqb = 0; \
+								} \
+							} \
+							if (kind < 0 && !L.complex_ && s1 < WALK) { \
+								kind = ((E >> s1) & 1) ? 0 : ((Bm >> s1) & 1) ? 1 : 2; \
+								sidx = idx + s1; \
+							} \
+						} \
+						uint32_t hm = Q & ((1u << fe) - 1); \
+						while (hm) { \
+							const int q = __ffs((int)hm) - 1; \
+							hm &= hm - 1; \
+							uint4 o = c8[0]; \
+_Pragma("unroll") \
+							for (int qq = 1; qq < WALK; qq++) \
+								if (qq == q) \
+									o = c8[qq]; \
+							if (nhit < MAX_HITS) \
+								hit_lds[nhit * 64 + lane] = (i64)(((u64)o.y << 32) | o.x); \
+							else \
+								L.complex_ = true; \
+							nhit++; \
+						} \
+						if (fe < WALK) { \
+							L.hi = (uint32_t)(idx + fe); \
+							fin = true; \
+						} \
+					} \
+					idx += WALK; \
+				}
+
+				uint4 bufA[WALK], bufB[WALK];
+				if (!fin) {
+#pragma unroll
+					for (int q = 0; q < WALK; q++)
+						bufA[q] = *reinterpret_cast<const uint4 *>(&tbl[idx + q]);
+				}
 				while (__ballot(!fin)) {
-					if (!fin) {
-						uint4 c8[WALK];
-#pragma unroll
-						for (int q = 0; q < WALK; q++)
-							c8[q] = *reinterpret_cast<const uint4 *>(&tbl[idx + q]); // table padded by 64 slots
-						uint32_t E = 0, Bm = 0, Lm = 0, Q = 0;
-#pragma unroll
-						for (int q = 0; q < WALK; q++) {
-							const uint32_t tl = c8[q].z, th = c8[q].w;
-							E |= (uint32_t)((c8[q].x | c8[q].y | tl | th) == 0) << q;
-							Bm |= (uint32_t)((tl & b_lo) != b_lo) << q;
-							Lm |= (uint32_t)((tl & m_lo) != m_lo) << q;
-							Q |= (uint32_t)(tl == T_lo && th == T_hi) << q;
-						}
-						steps += WALK;
-						if (idx + WALK > tbl_size || steps > 512) {
-							L.complex_ = true;
-							L.hi = (uint32_t)(idx + WALK - 1 < tbl_size - 1 ? idx + WALK - 1 : tbl_size - 1);
-							fin = true;
-						} else {
-							const int fe = E ? __ffs((int)E) - 1 : WALK; // first empty slot of the step
-							if (kind < 0 && L.ins) {
-								const uint32_t S = E | Bm | Lm;
-								const int s1 = S ? __ffs((int)S) - 1 : WALK;
-								uint32_t eqb = Q & ((1u << s1) - 1);
-								while (eqb) {
-									const int q = __ffs((int)eqb) - 1;
-									eqb &= eqb - 1;
-									if (neq < MAX_EQS)
-										eqs_lds[neq * 64 + w_ticket] = (uint32_t)(idx + q);
-									if (++neq >= R.max_chain) {
-										if (R.max_chain <= MAX_EQS)
-											kind = 3; // round-robin eviction among these equal tags
-										else
-											L.complex_ = true;
-										eqb = 0;
-									}
-								}
-								if (kind < 0 && !L.complex_ && s1 < WALK) {
-									kind = ((E >> s1) & 1) ? 0 : ((Bm >> s1) & 1) ? 1 : 2;
-									sidx = idx + s1;
-									uint4 o = c8[0];
-#pragma unroll
-									for (int q = 1; q < WALK; q++)
-										if (q == s1)
-											o = c8[q];
-									occ.offset = (i64)(((u64)o.y << 32) | o.x);
-									occ.t = ((u64)o.w << 32) | o.z;
-								}
-							}
-							uint32_t hm = Q & ((1u << fe) - 1);
-							while (hm) {
-								const int q = __ffs((int)hm) - 1;
-								hm &= hm - 1;
-								uint4 o = c8[0];
-#pragma unroll
-								for (int qq = 1; qq < WALK; qq++)
-									if (qq == q)
-										o = c8[qq];
-								if (nhit < MAX_HITS)
-									hit_lds[nhit * 64 + lane] = (i64)(((u64)o.y << 32) | o.x);
-								else
-									L.complex_ = true;
-								nhit++;
-							}
-							if (fe < WALK) {
-								L.hi = (uint32_t)(idx + fe);
-								fin = true;
-							}
-						}
-						idx += WALK;
-					}
+					A1_STEP(bufA, bufB)
+					if (!__ballot(!fin))
+						break;
+					A1_STEP(bufB, bufA)
 				}
 			}
 
+			if (need_sim && kind == 2 && !L.complex_)
+				occ = tbl[sidx]; // just read by the walk: an L2 hit, and only displacing inserts pay for it
 			lap(9);
 			// ---- A2: are the tag hits real matches (>= MINIMUM_MATCH)? ----
 			{
@@ -1103,13 +1132,7 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		// one clean (src/rzip.c:665-671).
 		const bool live = alive; // dead lanes (inside a match / mask tightened) commit as no-ops
 		const int x = (live && L.ins && !L.dec && !L.complex_ && !L.match) ? 1 : 0;
-		int px = x;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			int o = __shfl_up(px, d);
-			if (lane >= d)
-				px += o;
-		}
+		const int px = x + __popcll(__ballot(x != 0) & lanes_below); // inclusive prefix count
 		const i64 hc_before = R.hash_count + (px - x) < R.hash_limit ? R.hash_count + (px - x) : R.hash_limit;
 		const bool cleans = x && hc_before + 1 > R.hash_limit;
 		const u64 clean_m = __ballot(cleans);
@@ -1133,7 +1156,7 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 				const i64 q = ptr + lane;
 				bool cand = false;
 				if (q < tbl_size) {
-					const Slot s = tbl[q];
+					const Slot s = (may_clean && rounds == 0) ? pre0 : (may_clean && rounds == 1) ? pre1 : tbl[q];
 					cand = (s.offset | (i64)s.t) && (s.t & better) != better;
 				}
 				const u64 m = __ballot(cand);
@@ -1181,58 +1204,78 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 					why = 7;
 				}
 		// conflicts: the EARLIEST lane whose write (insert, displacement or clean) lies inside my
-		// read interval.  Writes are published as 8-slot granules in a small LDS hash map
-		// (granule -> lowest writing lane); every lane then looks up the granules its interval covers.
-		for (int k = lane; k < CT_SIZE; k += 64) {
-			ct_key[k] = 0xFFFFFFFFu;
-			ct_val[k] = 64;
-		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-		if (live) {
+		// read interval (at 8-slot granule resolution).  Filter first: every writer counts its written
+		// granules into a small LDS table of hashed counters, every reader looks up the granules of
+		// its interval (minus its own writes); the few lanes that see a foreign write get the exact
+		// answer from the writers' registers.
+		uint32_t wr[5], wh[5];
 #pragma unroll
-			for (int k = 0; k < 5; k++) {
-				uint32_t wslot = 0xFFFFFFFFu;
+		for (int k = 0; k < 5; k++) {
+			wr[k] = 0xFFFFFFFFu;
+			if (live) {
 				if (k < 4) {
 					if (k < L.nw)
-						wslot = L.w_slot[k];
+						wr[k] = L.w_slot[k];
 				} else
-					wslot = my_vict;
-				if (wslot != 0xFFFFFFFFu) {
-					const uint32_t g = wslot >> 3;
-					uint32_t h = (g * 2654435761u) >> (32 - CT_BITS);
-					for (;;) {
-						const uint32_t old = atomicCAS(&ct_key[h], 0xFFFFFFFFu, g);
-						if (old == 0xFFFFFFFFu || old == g) {
-							atomicMin(&ct_val[h], (uint32_t)lane);
-							break;
-						}
-						h = (h + 1) & (CT_SIZE - 1);
-					}
+					wr[k] = my_vict;
+			}
+			wh[k] = wr[k] != 0xFFFFFFFFu ? ((wr[k] >> 3) * 2654435761u) >> (32 - CF_BITS) : 0xFFFFFFFFu;
+		}
+#pragma unroll
+		for (int k = 0; k < 5; k++)
+			if (wh[k] != 0xFFFFFFFFu)
+				__hip_atomic_fetch_add(&cf_bits[wh[k] >> 1], 1u << (16 * (wh[k] & 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		const bool reads = live && !L.complex_ && !L.match; // lanes that stop anyway need no conflict test
+		const uint32_t r_lo = L.lo & ~7u, r_hi = L.hi | 7u;
+		bool flagged = false;
+		if (reads) {
+			const uint32_t g1 = L.hi >> 3;
+			for (uint32_t g = L.lo >> 3; g <= g1; g += 4) {
+				uint32_t acc = 0;
+#pragma unroll
+				for (uint32_t u = 0; u < 4; u++) {
+					const uint32_t gg = g + u <= g1 ? g + u : g1;
+					const uint32_t hb = (gg * 2654435761u) >> (32 - CF_BITS);
+					uint32_t cnt = (cf_bits[hb >> 1] >> (16 * (hb & 1))) & 0xFFFFu;
+#pragma unroll
+					for (int q = 0; q < 5; q++)
+						cnt -= wh[q] == hb;
+					acc |= cnt;
 				}
+				if (acc)
+					flagged = true;
+			}
+		}
+		int first_conf = 64;
+		{
+			u64 fm = __ballot(flagged);
+			int budget = 16;
+			while (fm) {
+				const int k = __ffsll((long long)fm) - 1;
+				fm &= fm - 1;
+				if (budget-- <= 0) { // too many suspects: call the rest conflicting (they re-simulate)
+					if (flagged && lane >= k)
+						first_conf = 0;
+					break;
+				}
+				const uint32_t klo = __shfl(r_lo, k), khi = __shfl(r_hi, k);
+				bool hit = false;
+#pragma unroll
+				for (int q = 0; q < 5; q++)
+					hit |= wr[q] != 0xFFFFFFFFu && wr[q] >= klo && wr[q] <= khi;
+				const u64 hm = __ballot(hit && lane < k);
+				if (lane == k && hm)
+					first_conf = __ffsll((long long)hm) - 1;
 			}
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-		int first_conf = 64;
-		if (live && !L.complex_ && !L.match) { // lanes that stop anyway need no conflict test
-			const uint32_t g1 = L.hi >> 3;
-			for (uint32_t g = L.lo >> 3; g <= g1; g++) {
-				uint32_t h = (g * 2654435761u) >> (32 - CT_BITS);
-				for (;;) {
-					const uint32_t k = ct_key[h];
-					if (k == 0xFFFFFFFFu)
-						break;
-					if (k == g) {
-						const int v = (int)ct_val[h];
-						if (v < lane && v < first_conf)
-							first_conf = v;
-						break;
-					}
-					h = (h + 1) & (CT_SIZE - 1);
-				}
-			}
-		}
+#pragma unroll
+		for (int k = 0; k < 5; k++)
+			if (wh[k] != 0xFFFFFFFFu)
+				cf_bits[wh[k] >> 1] = 0;
 		const bool conflict = first_conf < 64;
 		lap(11);
 		if (!stop && conflict)
@@ -1245,6 +1288,17 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		const int why_f = f < 64 ? __shfl(why, f) : 0;
 		if (f < wcount && why_f >= 3 && why_f <= 7)
 			dbg[why_f]++;
+		if (f < wcount && why_f == 5) {
+			const int fc = __shfl(first_conf, f);
+			const u64 tf = bcast64(w_tag, f), tc = bcast64(w_tag, fc & 63);
+			const i64 pf = (i64)bcast64((u64)w_pos, f), pc = (i64)bcast64((u64)w_pos, fc & 63);
+			dbg2[0] += tf == tc;
+			dbg2[1] += fc == f - 1;
+			dbg2[2] += (tf == tc) && (pf - pc == 1);
+			dbg2[3] += ((tf ^ tc) & R.hmask) == 0;
+			dbg2[4] += __shfl((int)L.nw, fc & 63) == 1 && __shfl((int)L.dec, fc & 63) == 0;
+			dbg2[5] += f;
+		}
 		const bool committed = lane < f && live;
 
 		// Phase D: apply the committed prefix
@@ -1266,19 +1320,13 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		{
 			const u64 cm = __ballot(committed);
 			const int n_commit = __popcll(cm);
-			int my_miss = committed ? L.misses : 0;
-			int my_ins = (committed && L.ins) ? 1 : 0;
-			int my_x = committed ? x : 0;
-#pragma unroll
-			for (int d = 32; d >= 1; d >>= 1) {
-				my_miss += __shfl_xor(my_miss, d);
-				my_ins += __shfl_xor(my_ins, d);
-				my_x += __shfl_xor(my_x, d);
-			}
+			if (committed)
+				miss_acc += L.misses; // per lane, summed when the kernel ends
+			const int my_ins = __popcll(__ballot(committed && L.ins));
+			const int my_x = __popcll(__ballot(committed && x));
 			lookups += n_commit;
 			dbg[1] += n_commit;
 			inserts += my_ins;
-			R.tag_misses += my_miss;
 			const i64 hc = R.hash_count + my_x;
 			R.hash_count = hc < R.hash_limit ? hc : R.hash_limit;
 			R.victim_round = (R.victim_round + __popcll(evict_m & cm)) % (i64)R.max_chain;
@@ -1317,6 +1365,10 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		}
 	}
 
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1)
+		miss_acc += (i64)bcast64((u64)miss_acc, lane ^ d);
+	R.tag_misses += miss_acc;
 	if (lane == 0) {
 		st->p_skip = p_skip;
 		st->last_match = R.last_match;
@@ -1336,6 +1388,8 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		st->tag_misses = R.tag_misses;
 		for (int k = 0; k < 16; k++)
 			st->dbg[k] += dbg[k];
+		for (int k = 0; k < 16; k++)
+			st->dbg2[k] += dbg2[k];
 	}
 	// keep the prefetch loads observable
 	u64 any = sink;
@@ -1582,6 +1636,9 @@ int scan_workspace_create(ScanWorkspace **out, int rzip_level, int64_t max_chunk
 	{
 		const char *e = getenv("LRZGPU_RESOLVE_SERIAL");
 		w->batch_mode = (e && *e == '1') ? 0 : 1;
+		const char *pr = getenv("LRZGPU_RESOLVE_PROF"); // bit 1: per-phase cycle counters in the profile
+		if (pr && *pr == '1')
+			w->batch_mode |= 2;
 	}
 	w->seg_cap = (size_t)1 << 28; // up to 256 Mi positions per segment
 	if ((int64_t)w->seg_cap > max_chunk + TILE)
@@ -1698,6 +1755,12 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 	HIPCHK(hipStreamSynchronize(s));
 	res->crc = crc;
 	res->final_state = h;
+	if (getenv("LRZGPU_TRACE")) {
+		fprintf(stderr, "lrzgpu scan: batches %lld committed %lld  hash_count %lld  dbg2:", (long long)h.dbg[0], (long long)h.dbg[1], (long long)h.hash_count);
+		for (int k = 0; k < 16; k++)
+			fprintf(stderr, " %lld", (long long)h.dbg2[k]);
+		fprintf(stderr, "\n");
+	}
 	*victim_round = h.victim_round;
 	{
 		int64_t mb = 0;
