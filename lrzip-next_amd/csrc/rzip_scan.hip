@@ -593,6 +593,10 @@ struct LaneSim {
 	u64 w_t[4];
 	i64 w_off[4];
 	uint32_t lo, hi; // inclusive slot interval read
+	// twin successor: simulated on top of the insert its predecessor (same tag, previous lane) is
+	// expected to make: (tag, predecessor position) written to tw_slot, replacing a cleanable entry if tw_dec
+	bool twin, tw_dec;
+	uint32_t tw_slot;
 };
 
 // is there a match of at least MINIMUM_MATCH bytes between p0 and op? (single_match_len() != 0)
@@ -783,6 +787,8 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 	int next_ticket = 0;
 	LaneSim L;
 	L.complex_ = L.match = L.ins = L.victim = false;
+	L.twin = L.tw_dec = false;
+	L.tw_slot = 0;
 	L.dec = L.misses = L.nw = 0;
 	L.lo = L.hi = 0;
 	for (int k = 0; k < 4; k++) {
@@ -802,6 +808,9 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		L.complex_ = __shfl((int)L.complex_, src) != 0;
 		L.match = __shfl((int)L.match, src) != 0;
 		L.ins = __shfl((int)L.ins, src) != 0;
+		L.twin = __shfl((int)L.twin, src) != 0;
+		L.tw_dec = __shfl((int)L.tw_dec, src) != 0;
+		L.tw_slot = __shfl(L.tw_slot, src);
 		L.dec = __shfl(L.dec, src);
 		L.misses = __shfl(L.misses, src);
 		L.nw = __shfl(L.nw, src);
@@ -889,6 +898,20 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 			occ.offset = 0;
 			occ.t = 0;
 			int nhit = 0; // tag hits met by the lookup walk, offsets parked in LDS (hit_lds)
+			// Twins: consecutive candidates with the SAME tag (the byte leaving the 31-byte window
+			// equals the byte entering it) share a bucket, so the second always conflicts with the
+			// first one's insert.  The second of such a pair is simulated on top of the insert it can
+			// predict for the first from its own walk (same tag, same table); phase C checks the prediction.
+			// (cross-lane reads are made by all lanes: no short-circuit evaluation around them)
+			const int prev_alive = __shfl_up((int)alive, 1);
+			const u64 prev_tag = bcast64(w_tag, (lane + 63) & 63);
+			const i64 P_prev = (i64)bcast64((u64)w_pos, (lane + 63) & 63);
+			const bool tw_cand = lane > 0 && alive && prev_alive != 0 && prev_tag == w_tag;
+			const int prev_cand = __shfl_up((int)tw_cand, 1);
+			bool tw = tw_cand && prev_cand == 0; // a third twin in a row takes the conflict path
+			bool seek_pred = false, tw_hit = false;
+			dbg2[6] += __popcll(__ballot(need_sim && tw_cand));
+			dbg2[7] += __popcll(__ballot(need_sim && tw));
 			// ---- A1: lookup walk to the first empty slot, 16 slots per step, branch-free masks ----
 			{
 				i64 idx = (i64)(T & R.hmask);
@@ -910,6 +933,10 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 					L.hi = (uint32_t)idx;
 					if (L.complex_)
 						fin = true;
+					// (a tag that is itself due for cleaning -- only before the first clean of a chunk --
+					// would make the successor overwrite the twin's slot: left to the conflict path)
+					tw = tw && L.ins && !L.complex_ && (T & better) == better;
+					seek_pred = tw;
 				}
 				const uint32_t s_lo = b_lo | m_lo; // a slot stops the insert when its tag lacks any of these bits
 				const u64 T64 = T;
@@ -920,7 +947,6 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 _Pragma("unroll") \
 					for (int q = 0; q < WALK; q++) \
 						n8[q] = *reinterpret_cast<const uint4 *>(&tbl[idx + WALK + q]); \
- \
 					uint32_t E = 0, Bm = 0, S = 0, Q = 0; \
 _Pragma("unroll") \
 					for (int q = WALK - 1; q >= 0; q--) { \
@@ -937,28 +963,64 @@ _Pragma("unroll") \
 						L.hi = (uint32_t)(idx + WALK - 1 < tbl_size - 1 ? idx + WALK - 1 : tbl_size - 1); \
 						fin = true; \
 					} else { \
-						const int fe = E ? __ffs((int)E) - 1 : WALK; \
+						uint32_t Em = E; \
 						if (kind < 0 && L.ins) { \
-							const int s1 = S ? __ffs((int)S) - 1 : WALK; \
-							uint32_t eqb = Q & ((1u << s1) - 1); \
-							while (eqb) { \
-								const int q = __ffs((int)eqb) - 1; \
-								eqb &= eqb - 1; \
-								if (neq < MAX_EQS) \
-									eqs_lds[neq * 64 + w_ticket] = (uint32_t)(idx + q); \
-								if (++neq >= R.max_chain) { \
-									if (R.max_chain <= MAX_EQS) \
-										kind = 3; \
-									else \
-										L.complex_ = true; \
-									eqb = 0; \
+							uint32_t from = 0; \
+							for (int pass = 0; pass < 2; pass++) { \
+								const uint32_t Sm = S & ~((1u << from) - 1); \
+								const int s1 = Sm ? __ffs((int)Sm) - 1 : WALK; \
+								uint32_t eqb = Q & ((1u << s1) - 1) & ~((1u << from) - 1); \
+								while (eqb) { \
+									const int q = __ffs((int)eqb) - 1; \
+									eqb &= eqb - 1; \
+									if (neq < MAX_EQS) \
+										eqs_lds[neq * 64 + w_ticket] = (uint32_t)(idx + q); \
+									if (++neq >= R.max_chain) { \
+										if (R.max_chain <= MAX_EQS && !tw) \
+											kind = 3; \
+										else if (seek_pred) { \
+											tw = seek_pred = false; \
+											if (R.max_chain <= MAX_EQS) \
+												kind = 3; \
+											else \
+												L.complex_ = true; \
+										} else \
+											L.complex_ = true; \
+										eqb = 0; \
+									} \
 								} \
-							} \
-							if (kind < 0 && !L.complex_ && s1 < WALK) { \
-								kind = ((E >> s1) & 1) ? 0 : ((Bm >> s1) & 1) ? 1 : 2; \
-								sidx = idx + s1; \
+								if (kind >= 0 || L.complex_ || s1 >= WALK) \
+									break; \
+								const int k1 = ((E >> s1) & 1) ? 0 : ((Bm >> s1) & 1) ? 1 : 2; \
+								if (!seek_pred) { \
+									kind = k1; \
+									sidx = idx + s1; \
+									if (tw && k1 == 2) \
+										L.complex_ = true; \
+									break; \
+								} \
+								seek_pred = false; \
+								if (k1 == 2 || (k1 == 1 && ((Q >> s1) & 1))) { \
+									tw = false; \
+									kind = k1; \
+									sidx = idx + s1; \
+									break; \
+								} \
+								L.tw_slot = (uint32_t)(idx + s1); \
+								L.tw_dec = k1 == 1; \
+								tw_hit = true; \
+								if (k1 == 0) \
+									Em &= ~(1u << s1); \
+								if (neq < MAX_EQS) \
+									eqs_lds[neq * 64 + w_ticket] = (uint32_t)(idx + s1); \
+								if (++neq >= R.max_chain) { \
+									L.complex_ = true; \
+									break; \
+								} \
+								from = (uint32_t)s1 + 1; \
 							} \
 						} \
+						const int fe = Em ? __ffs((int)Em) - 1 : WALK; \
 						uint32_t hm = Q & ((1u << fe) - 1); \
 						while (hm) { \
 							const int q = __ffs((int)hm) - 1; \
@@ -981,7 +1043,6 @@ _Pragma("unroll") \
 					} \
 					idx += WALK; \
 				}
-
 				uint4 bufA[WALK], bufB[WALK];
 				if (!fin) {
 #pragma unroll
@@ -1023,6 +1084,20 @@ _Pragma("unroll") \
 					}
 				}
 			}
+			// the twin's entry is one more tag hit for its successor: a real match (a run of one byte
+			// value) goes to the serial path
+			if (__ballot(need_sim && tw && tw_hit && !L.complex_)) {
+				if (need_sim && tw && tw_hit && !L.complex_) {
+					if (lane_verify(buf, P, P_prev, R.end, R.last_match))
+						L.complex_ = true;
+					else
+						L.misses++;
+				}
+			}
+			if (need_sim)
+				L.twin = tw && tw_hit && !L.complex_;
+			dbg2[8] += __popcll(__ballot(need_sim && tw));
+			dbg2[9] += __popcll(__ballot(need_sim && L.twin));
 			lap(14);
 			// ---- A3: displacement chain of the insert, level by level ----
 			{
@@ -1203,6 +1278,18 @@ _Pragma("unroll") \
 					stop = true;
 					why = 7;
 				}
+		// twin successors: did the predecessor's simulation make exactly the predicted insert?
+		const bool tw_live = live && L.twin && !L.complex_ && !L.match;
+		if (__ballot(tw_live)) {
+			const uint32_t p_slot = __shfl_up(L.w_slot[0], 1);
+			const int p_nw = __shfl_up(L.nw, 1), p_dec = __shfl_up(L.dec, 1);
+			const int p_ok = __shfl_up((int)(live && L.ins && !L.complex_ && !L.match && !L.victim && !stop), 1);
+			if (tw_live && !stop && !(lane > 0 && p_ok && p_nw == 1 && p_slot == L.tw_slot && (p_dec != 0) == L.tw_dec)) {
+				stop = true;
+				why = 5; // re-simulated as the first lane of the next round
+				dbg2[10]++;
+			}
+		}
 		// conflicts: the EARLIEST lane whose write (insert, displacement or clean) lies inside my
 		// read interval (at 8-slot granule resolution).  Filter first: every writer counts its written
 		// granules into a small LDS table of hashed counters, every reader looks up the granules of
@@ -1261,10 +1348,11 @@ _Pragma("unroll") \
 					break;
 				}
 				const uint32_t klo = __shfl(r_lo, k), khi = __shfl(r_hi, k);
+				const bool k_twin = __shfl((int)tw_live, k) != 0; // its predecessor's insert is already part of its simulation
 				bool hit = false;
 #pragma unroll
 				for (int q = 0; q < 5; q++)
-					hit |= wr[q] != 0xFFFFFFFFu && wr[q] >= klo && wr[q] <= khi;
+					hit |= wr[q] != 0xFFFFFFFFu && wr[q] >= klo && wr[q] <= khi && !(q == 0 && k_twin && lane == k - 1);
 				const u64 hm = __ballot(hit && lane < k);
 				if (lane == k && hm)
 					first_conf = __ffsll((long long)hm) - 1;
