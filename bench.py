@@ -19,6 +19,7 @@ import importlib.util
 import json
 import os
 import sys
+import resource
 import time
 
 # one hardware queue per stream (scan, gate, finder workers): must be set before HIP initialises
@@ -118,6 +119,24 @@ def cpu_baseline(sample_bytes, ctl_kw, cores, alphabet="alnum"):
             "seconds": round(dt, 2)}
 
 
+def usable_cpus():
+    """CPUs this process can actually burn: affinity mask, capped by the cgroup CPU quota."""
+    n = float(len(os.sched_getaffinity(0)))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, float(txt[0]) / float(txt[1]))
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    n = min(n, q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1.0, n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,6 +147,8 @@ def main():
     ap.add_argument("--cpu-sample-mib", type=int, default=int(os.environ.get("LRZGPU_CPU_SAMPLE_MIB", "128")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--threads", type=int, default=0, help="-p (default: host cores)")
+    ap.add_argument("--host-threads", type=int, default=0,
+                    help="host LZMA encoder threads (default: the CPUs this process may use, cgroup quota included)")
     ap.add_argument("--alphabet", choices=sorted(ALPHABETS), default="alnum")
     ap.add_argument("--gpu-slots", type=int, default=8)
     args = ap.parse_args()
@@ -155,14 +176,16 @@ def main():
     threads = args.threads or max(1, cores // world)
     phys = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
     ctl_kw = dict(level=7, threads=threads, processors=cores, ramsize=phys)
+    usable = usable_cpus()
+    host_threads = args.host_threads or max(1, min(threads, int(usable + 0.5)))
     n_bytes = args.mib << 20
 
     buf = make_workload(n_bytes, 1 + rank, dev, args.alphabet)
     torch.cuda.synchronize()
 
     def one_step():
-        ctl = B.make_control(device=local_rank, host_threads=threads, gpu_slots=args.gpu_slots, **ctl_kw)
-        out, ctl = B.compress_device(buf.data_ptr(), n_bytes, ctl=ctl)
+        ctl = B.make_control(device=local_rank, host_threads=host_threads, gpu_slots=args.gpu_slots, **ctl_kw)
+        out, ctl = B.compress_device(buf.data_ptr(), n_bytes, ctl=ctl, copy=False)
         return out, ctl
 
     for _ in range(args.warmup):
@@ -176,12 +199,15 @@ def main():
 
     L.lrzgpu_profile_reset()
     fence()
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     out = ctl = None
     for _ in range(args.steps):
         out, ctl = one_step()
     fence()
     dt = time.perf_counter() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -203,7 +229,10 @@ def main():
             "k_crc32_tiles": (prof.crc_ms, prof.crc_launches, prof.crc_bytes),
             "k_gather_runs": (prof.gather_ms, prof.gather_launches, 2 * prof.gather_bytes),
         }
-        dom = max(kernels, key=lambda k: kernels[k][0])
+        # The dominant kernel is the one on the step's critical path.  k_lz4_size / k_bt run a hundred
+        # stream blocks concurrently on otherwise idle CUs, so their accumulated device time over-counts;
+        # k_resolve is a single wavefront launched back to back on the scan stream for scan_wall_ms.
+        dom = "k_resolve" if prof.resolve_ms > 0 else max(kernels, key=lambda k: kernels[k][0])
         ms, launches, alg_bytes = kernels[dom]
         avg_ms = ms / max(launches, 1)
         achieved = (alg_bytes / max(launches, 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -215,13 +244,15 @@ def main():
                     "per_kernel_GBps": {k: (round(v[2] / (v[0] * 1e-3) / 1e9, 3) if v[0] > 0 else 0.0)
                                         for k, v in kernels.items()},
                     "scan_wall_ms": round(prof.scan_wall_ms, 1),
+                    "critical_path_frac": round(prof.scan_wall_ms / (dt * 1000.0), 3),
                     "resolver": dict(zip(("batches", "committed", "serial_steps", "stop_complex", "stop_match",
                                           "stop_conflict", "stop_novictim", "stop_sweptrange", "cyc_refill",
                                           "cyc_simulate", "cyc_victims", "cyc_conflict", "cyc_apply", "cyc_tail", "cyc_verify", "cyc_displace"),
                                          [int(v) for v in prof.resolve_dbg]))}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(min(args.cpu_sample_mib << 20, n_bytes), ctl_kw, cores, args.alphabet)
+            # workers: each oracle block worker runs the reference LzmaCompress with numThreads=2
+            cpu = cpu_baseline(min(args.cpu_sample_mib << 20, n_bytes), ctl_kw, max(1, int(usable + 0.5)), args.alphabet)
         line = {
             "metric": "compress MB/s (input) at -L7 lzma", "value": round(value, 2), "unit": "MB/s (2^20 B/s)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1000 / args.steps, 1),
@@ -231,7 +262,8 @@ def main():
                                    "chunk per GPU, input resident in HBM" % (args.mib, len(ALPHABETS[args.alphabet]), args.alphabet),
                        "flags": "-L7 -p%d (PROCESSORS=%d, ramsize=%d)" % (threads, cores, phys),
                        "stream_bufsize": int(ctl.stream_bufsize), "dict_size": int(ctl.dictSize_used),
-                       "output_bytes": len(out), "host_threads": threads, "parallelism": "chunk-per-gpu x%d" % world},
+                       "output_bytes": len(out), "host_threads": host_threads, "host_cpus_usable": round(usable, 1),
+                       "host_cpu_seconds": round(cpu_s, 1), "parallelism": "chunk-per-gpu x%d" % world},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -173,6 +173,30 @@ def _take(out, olen):
     return res
 
 
+class LrzBuffer:
+    """The malloc()ed .lrz image a compress call returned, without a copy into Python bytes."""
+
+    def __init__(self, ptr, size):
+        self._ptr, self.size = ptr, size
+
+    def __len__(self):
+        return self.size
+
+    def view(self):
+        return memoryview((C.c_ubyte * self.size).from_address(C.addressof(self._ptr.contents))).cast("B")
+
+    def tobytes(self):
+        return C.string_at(self._ptr, self.size)
+
+    def free(self):
+        if self._ptr is not None:
+            C.CDLL(None).free(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        self.free()
+
+
 def compress_buffer(data: bytes, **kw):
     """Whole-file compress of a host buffer -> (.lrz bytes, Control)."""
     c = make_control(**kw)
@@ -184,14 +208,17 @@ def compress_buffer(data: bytes, **kw):
     return _take(out, olen), c
 
 
-def compress_device(ptr: int, n: int, ctl=None, **kw):
-    """Whole-file compress of a buffer resident in HBM (ptr = device address) -> (.lrz bytes, Control)."""
+def compress_device(ptr: int, n: int, ctl=None, copy=True, **kw):
+    """Whole-file compress of a buffer resident in HBM (ptr = device address) -> (.lrz bytes, Control);
+    copy=False returns the library's own buffer as an LrzBuffer instead of bytes."""
     c = ctl if ctl is not None else make_control(**kw)
     out = C.POINTER(C.c_ubyte)()
     olen = C.c_int64()
     rc = lib().lrzgpu_compress_buffer_dev(C.byref(c), C.c_void_p(ptr), n, C.byref(out), C.byref(olen))
     if rc != 0:
         raise RuntimeError("lrzgpu_compress_buffer_dev rc=%d" % rc)
+    if not copy:
+        return LrzBuffer(out, olen.value), c
     return _take(out, olen), c
 
 

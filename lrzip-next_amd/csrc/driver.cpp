@@ -18,6 +18,7 @@
 //
 // Output bytes depend only on (input, control parameters), never on thread counts or timing here.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -601,6 +602,39 @@ struct Feeder {
 	}
 };
 
+// CPUs this process may burn: the affinity mask, capped by a cgroup CPU quota (v2 cpu.max, v1 cfs_quota_us)
+static int usable_cpus()
+{
+	double n = (double)std::thread::hardware_concurrency();
+	cpu_set_t set;
+	if (sched_getaffinity(0, sizeof(set), &set) == 0)
+		n = (double)CPU_COUNT(&set);
+	if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+		char q[64];
+		double period = 0;
+		if (fscanf(f, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+			const double lim = atof(q) / period;
+			if (lim > 0 && lim < n)
+				n = lim;
+		}
+		fclose(f);
+	} else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+		double quota = -1, period = 0;
+		if (fscanf(g, "%lf", &quota) != 1)
+			quota = -1;
+		fclose(g);
+		if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+			if (fscanf(h, "%lf", &period) != 1)
+				period = 0;
+			fclose(h);
+		}
+		if (quota > 0 && period > 0 && quota / period < n)
+			n = quota / period;
+	}
+	const int r = (int)(n + 0.5);
+	return r < 1 ? 1 : r;
+}
+
 int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out, bool with_magic)
 {
 	int rc = select_device(ctl->device);
@@ -614,7 +648,14 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 		return rc;
 	if (!P.sz.no_compress && P.sz.level < 5)
 		return LRZGPU_E_PARAM; // levels 1-4 use the HC5 fast path: outside this library
+	// host encoders: as asked, else the -p threads capped by the CPUs this process can really use
+	// (more runnable threads than the cgroup quota only buys throttling)
 	P.n_encoders = ctl->host_threads > 0 ? ctl->host_threads : (ctl->threads > 0 ? ctl->threads : 1);
+	if (ctl->host_threads <= 0) {
+		const int usable = usable_cpus();
+		if (P.n_encoders > usable)
+			P.n_encoders = usable;
+	}
 	P.n_gpu_workers = ctl->gpu_slots > 0 ? ctl->gpu_slots : 3;
 	P.held_limit = (size_t)P.n_encoders + (size_t)P.n_gpu_workers + 2;
 	ctl->stream_bufsize = P.sz.stream_bufsize;

@@ -28,11 +28,16 @@ struct ScanState {
 	int64_t hash_count, clean_ptr, victim_round;
 	// outputs
 	int64_t n_records, rec_cap;
-	int32_t error; // 1 = record buffer full, 2 = internal
+	int32_t error; // 1 = record buffer full, 2 = internal, 3 = long forward extent wanted (ext_*), not an error
 	int32_t pad;
 	// statistics (reference st->stats)
 	int64_t inserts, lookups, tag_hits, tag_misses;
 	uint64_t sink; // keeps prefetch loads alive
+	// long matches: the single resolver wave hands a forward extent that is still equal after
+	// LONG_EXTENT bytes to a grid-wide compare kernel; ext_p/ext_op/ext_done is the request,
+	// hint_* the answer (equal bytes of chunk[hint_p..] and chunk[hint_op..], up to the chunk end)
+	int64_t ext_p, ext_op, ext_done;
+	int64_t hint_p, hint_op, hint_len;
 	// resolver diagnostics: batches, committed lanes, serial steps, first-stop reasons
 	// (complex, real match, conflict, no victim in reach, insert inside swept range)
 	int64_t dbg2[16]; // experiment counters, printed under LRZGPU_TRACE
@@ -43,15 +48,21 @@ struct ScanWorkspace {
 	int hash_bits;
 	int batch_mode;    // 1 = speculative batch resolver, 0 = serial reference path
 	void *table;       // 16 B slots
+	uint8_t *rank_bytes, *fp_bytes; // one rank / fingerprint byte per slot (see rzip_scan.hip)
 	ScanState *state;  // device
 	uint64_t *hx;      // device copy of hash_index[256]
 	uint32_t *cand_rel;
 	uint64_t *cand_tag;
 	uint32_t *tile_count;
+	uint32_t *tile_base;  // exclusive scan of tile_count (+ total)
+	uint32_t *comp_rel;   // the segment's candidates packed in position order
+	uint64_t *comp_tag;
+	size_t comp_cap;
 	size_t seg_cap;    // positions per segment the candidate arrays can hold
 	MatchRec *records;
 	int64_t rec_cap;
 	uint32_t *crc_partial;
+	unsigned long long *long_best; // k_long_compare result
 	size_t crc_cap;
 };
 

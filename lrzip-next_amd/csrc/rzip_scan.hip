@@ -46,7 +46,8 @@ constexpr int MINIMUM_MATCH = 31; // src/rzip.c:51
 constexpr int GREAT_MATCH = 1024; // src/rzip.c:50
 constexpr int TILE = 4096;        // positions per K1 workgroup
 constexpr int PER_THREAD = 16;
-constexpr int WALK = 16;     // table slots a speculative lookup reads per step (one HBM round trip)
+constexpr long long LONG_EXTENT = 4 << 20; // forward extents longer than this go to k_long_compare
+constexpr int A1_MAX_STEPS = 8192; // slots a speculative walk may cover (longer clusters: serial path)
 constexpr int MAX_EQS = 32;  // round-robin eviction handled in the batch up to this max_chain_len
 constexpr int MAX_HITS = 24; // tag hits one speculative lookup may verify (more -> serial path)
 constexpr int CF_BITS = 13; // conflict filter: 16-bit write counters per hashed 8-slot granule (<= 320 writes per round)
@@ -184,6 +185,56 @@ __global__ void __launch_bounds__(256) k_tag_scan(const uint8_t *__restrict__ bu
 		tile_count[blockIdx.x] = base + incl;
 }
 
+// K1b: exclusive scan of the per-tile candidate counts (one workgroup; a segment has <= 65536 tiles).
+// tile_base[t] = candidates before tile t, tile_base[ntiles] = all of them.
+__global__ void __launch_bounds__(1024) k_tile_scan(const uint32_t *__restrict__ tile_count, int ntiles, uint32_t *__restrict__ tile_base)
+{
+	__shared__ uint32_t wsum[16];
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int per = (ntiles + 1023) / 1024;
+	const int t0 = tid * per;
+	uint32_t mine = 0;
+	for (int k = 0; k < per; k++)
+		if (t0 + k < ntiles)
+			mine += tile_count[t0 + k];
+	uint32_t incl = mine;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t o = __shfl_up(incl, d);
+		if (lane >= d)
+			incl += o;
+	}
+	if (lane == 63)
+		wsum[wv] = incl;
+	__syncthreads();
+	uint32_t base = 0;
+	for (int w = 0; w < wv; w++)
+		base += wsum[w];
+	uint32_t run = base + incl - mine;
+	for (int k = 0; k < per; k++)
+		if (t0 + k < ntiles) {
+			tile_base[t0 + k] = run;
+			run += tile_count[t0 + k];
+		}
+	if (tid == 1023)
+		tile_base[ntiles] = base + incl;
+}
+
+// K1c: the per-tile candidate lists, packed into one list in position order (the resolver then
+// reads 64 candidates per load whatever their density; sparse masks leave ~8 per tile).
+__global__ void __launch_bounds__(256) k_compact_cands(const uint32_t *__restrict__ cand_rel, const u64 *__restrict__ cand_tag,
+						       const uint32_t *__restrict__ tile_count, const uint32_t *__restrict__ tile_base,
+						       uint32_t cap, uint32_t *__restrict__ comp_rel, u64 *__restrict__ comp_tag)
+{
+	const uint32_t cnt = tile_count[blockIdx.x], base = tile_base[blockIdx.x];
+	const size_t in0 = (size_t)blockIdx.x * TILE;
+	for (uint32_t i = threadIdx.x; i < cnt; i += 256)
+		if (base + i < cap) {
+			comp_rel[base + i] = cand_rel[in0 + i];
+			comp_tag[base + i] = cand_tag[in0 + i];
+		}
+}
+
 // ---------------------------------------------------------------------------------------------
 // K2: the resolver (one wavefront)
 // ---------------------------------------------------------------------------------------------
@@ -199,6 +250,37 @@ __device__ __forceinline__ int bitness_rank(u64 t) // ffsll(~t)
 	return v ? __ffsll((long long)v) : 0;
 }
 __device__ __forceinline__ u64 low_mask(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1); }
+
+// ---- side arrays of the hash table: one rank byte and one fingerprint byte per slot -------------
+// The walks of hash_search only ask three things of a slot: is it empty, does it stop an insert
+// (empty, due for cleaning, or of lesser bitness than the tag being inserted), and does it hold the
+// same tag.  With rank = min(ffsll(~t), 63) for an occupied slot and 0 for an empty one, the first
+// two are `rank == 0` and `rank < max(my_rank, popcount(better) + 1)`; the third is pre-filtered by a
+// fingerprint (tag bits 32..39) and confirmed on the 16-byte slot.  A walk then reads 2 bytes per
+// slot instead of 16 and tests 8 slots per 64-bit SWAR step.
+constexpr u64 B80 = 0x8080808080808080ull, B7F = 0x7F7F7F7F7F7F7F7Full, B01 = 0x0101010101010101ull;
+__device__ __forceinline__ uint8_t rank_byte(u64 t, i64 off)
+{
+	if (!(t | (u64)off))
+		return 0;
+	const int r = bitness_rank(t);
+	return (uint8_t)(r < 63 ? r : 63);
+}
+__device__ __forceinline__ uint8_t fp_byte(u64 t) { return (uint8_t)(t >> 32); }
+// 0x80 in every byte of x that is < the byte replicated in thr8 (all bytes < 128)
+__device__ __forceinline__ u64 bytes_lt(u64 x, u64 thr8) { return ~((x | B80) - thr8) & B80; }
+// 0x80 in every byte of x that equals the byte replicated in c8
+__device__ __forceinline__ u64 bytes_eq(u64 x, u64 c8)
+{
+	const u64 y = x ^ c8;
+	return ~(((y & B7F) + B7F) | y | B7F);
+}
+// the eight 0x80 flags of f as eight bits (flag of byte i -> bit i)
+__device__ __forceinline__ uint32_t flags_to_bits(u64 f)
+{
+	const uint32_t lo = (uint32_t)f >> 7, hi = (uint32_t)(f >> 32) >> 7;
+	return (((lo * 0x01020408u) >> 24) & 0xFu) | (((hi * 0x01020408u) >> 20) & 0xF0u);
+}
 // index of the k-th (0-based) set bit of m; m must have more than k bits set
 __device__ __forceinline__ int nth_set_bit(u64 m, int k)
 {
@@ -234,6 +316,7 @@ __device__ __forceinline__ bool quick_reject(const uint8_t *buf, i64 p0, i64 op,
 struct Resolver {
 	const uint8_t *buf;
 	Slot *tbl;
+	uint8_t *rk, *fpa; // rank / fingerprint byte per slot
 	u64 hmask;
 	i64 end, last_match;
 	u64 tag_mask, min_mask;
@@ -244,6 +327,23 @@ struct Resolver {
 	// LDS stack for displaced entries
 	u64 *stk_t;
 	i64 *stk_off, *stk_h;
+	// long forward extents are computed by the whole GPU (k_long_compare): hint = a finished one,
+	// ext_* = the request this launch ends with
+	i64 hint_p, hint_op, hint_len;
+	bool allow_abort;
+	mutable bool aborted;
+	mutable i64 ext_p, ext_op, ext_done;
+
+	// every table write goes through here: the slot and its two side bytes
+	__device__ __forceinline__ void store_slot(i64 slot, u64 t, i64 off) const
+	{
+		Slot w;
+		w.offset = off;
+		w.t = t;
+		tbl[slot] = w;
+		rk[slot] = rank_byte(t, off);
+		fpa[slot] = fp_byte(t);
+	}
 
 	// Forward extent: number of equal bytes of buf[p..] and buf[op..], p bounded by `end`.
 	__device__ i64 extent_fwd(i64 p, i64 op) const
@@ -285,7 +385,16 @@ struct Resolver {
 		}
 		// phase 2a: whole 16 KiB steps while everything is equal: 32 unconditional 16-byte loads per
 		// lane in flight, one ballot per step (a multi-GiB copy streams at wave bandwidth)
+		if (p == hint_p && op == hint_op)
+			return hint_len < total ? hint_len : total;
 		while (done + 16384 <= total) {
+			if (done >= LONG_EXTENT && allow_abort && total - done >= LONG_EXTENT) {
+				aborted = true; // the caller unwinds; the host runs the wide compare and relaunches
+				ext_p = p;
+				ext_op = op;
+				ext_done = done;
+				return done;
+			}
 			const uint8_t *pa = buf + p + done + (i64)lane * 16;
 			const uint8_t *pb = buf + op + done + (i64)lane * 16;
 			U128u va[16], vb[16];
@@ -518,24 +627,16 @@ struct Resolver {
 				cur_off = disp_off;
 				continue;
 			}
-			if (lane == 0) {
-				Slot w;
-				w.offset = cur_off;
-				w.t = cur_t;
-				tbl[write_h] = w;
-			}
+			if (lane == 0)
+				store_slot(write_h, cur_t, cur_off);
 			break;
 		}
 		// unwind: outer frames overwrite the displaced occupant's old slot
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		while (depth > 0) {
 			depth--;
-			if (lane == 0) {
-				Slot w;
-				w.offset = stk_off[depth];
-				w.t = stk_t[depth];
-				tbl[stk_h[depth]] = w;
-			}
+			if (lane == 0)
+				store_slot(stk_h[depth], stk_t[depth], stk_off[depth]);
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -558,12 +659,8 @@ struct Resolver {
 				u64 m = __ballot(cand);
 				if (m) {
 					int k = __ffsll((long long)m) - 1;
-					if (lane == k) {
-						Slot z;
-						z.offset = 0;
-						z.t = 0;
-						tbl[idx] = z;
-					}
+					if (lane == k)
+						store_slot(idx, 0, 0);
 					clean_ptr += k;
 					hash_count--;
 					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -640,7 +737,9 @@ fwd_done:
 __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf, Slot *__restrict__ tbl, ScanState *__restrict__ st,
 						i64 seg_lo, int ntiles, const uint32_t *__restrict__ cand_rel,
 						const u64 *__restrict__ cand_tag, const uint32_t *__restrict__ tile_count,
-						MatchRec *__restrict__ records, int batch_mode)
+						MatchRec *__restrict__ records, int batch_mode, const uint32_t *__restrict__ tile_base,
+						const uint32_t *__restrict__ comp_rel, const u64 *__restrict__ comp_tag, uint32_t comp_cap,
+						uint8_t *__restrict__ rank_bytes, uint8_t *__restrict__ fp_bytes)
 {
 	__shared__ u64 stk_t[64];
 	__shared__ i64 stk_off[64];
@@ -655,6 +754,8 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 	Resolver R;
 	R.buf = buf;
 	R.tbl = tbl;
+	R.rk = rank_bytes;
+	R.fpa = fp_bytes;
 	R.lane = threadIdx.x;
 	R.hmask = ((u64)1 << st->hash_bits) - 1;
 	R.end = st->end;
@@ -671,6 +772,12 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 	R.stk_t = stk_t;
 	R.stk_off = stk_off;
 	R.stk_h = stk_h;
+	R.hint_p = st->hint_p;
+	R.hint_op = st->hint_op;
+	R.hint_len = st->hint_len;
+	R.allow_abort = true;
+	R.aborted = false;
+	R.ext_p = R.ext_op = R.ext_done = 0;
 	for (int k = threadIdx.x; k < CF_WORDS; k += 64)
 		cf_bits[k] = 0;
 
@@ -705,11 +812,25 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		// emitted match ends BEFORE P -- the emission was delayed until this candidate -- P itself
 		// is examined a second time (it is the only candidate in (last_match, P]).
 		bool again;
+		R.allow_abort = true; // only the first examination of P can be replayed by a relaunch
 		do {
 			again = false;
 			i64 offset = 0, reverse = 0;
 			lookups++;
+			const i64 hits0 = R.tag_hits, misses0 = R.tag_misses;
 			i64 mlen = R.lookup(T, P, &offset, &reverse);
+			if (R.aborted) {
+				// nothing of this candidate has been applied yet: resume at P with the extent known
+				lookups--;
+				dbg[2]--;
+				R.tag_hits = hits0;
+				R.tag_misses = misses0;
+				if (P - 1 > p_skip)
+					p_skip = P - 1;
+				error = 3;
+				return;
+			}
+			R.allow_abort = false;
 
 			if ((T & R.tag_mask) == R.tag_mask) {
 				inserts++;
@@ -749,7 +870,44 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 	int tile = 0;
 	uint32_t tb0 = 0;
 	int ring_head = 0, ring_cnt = 0;
+	// packed candidate list of the segment (K1c); the per-tile lists remain the fallback when a
+	// pathological segment has more candidates than the packed buffers hold
+	const uint32_t ctotal = tile_base[ntiles];
+	const bool packed = ctotal <= comp_cap;
+	uint32_t cpos = 0;
+	i64 skip_seen = p_skip;
 	auto refill_ring = [&]() {
+		if (packed) {
+			if (p_skip != skip_seen) { // a match was emitted: jump over the candidates inside it
+				skip_seen = p_skip;
+				if (p_skip >= seg_lo) {
+					const i64 t = (p_skip + 1 - seg_lo) / TILE;
+					const uint32_t c0 = t < ntiles ? tile_base[t] : ctotal;
+					if (c0 > cpos)
+						cpos = c0;
+				}
+			}
+			while (ring_cnt <= 192 && cpos < ctotal) {
+				i64 pos = -1;
+				u64 tag = 0;
+				if (cpos + lane < ctotal) {
+					pos = seg_lo + (i64)comp_rel[cpos + lane];
+					tag = comp_tag[cpos + lane];
+				}
+				const bool ok = pos > p_skip && (tag & R.min_mask) == R.min_mask;
+				const u64 m = __ballot(ok);
+				if (ok) {
+					const int slot = (ring_head + ring_cnt + __popcll(m & lanes_below)) & 255;
+					ring_pos[slot] = pos;
+					ring_tag[slot] = tag;
+				}
+				ring_cnt += __popcll(m);
+				cpos += 64;
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			return;
+		}
 		while (ring_cnt <= 192 && tile < ntiles) {
 			const uint32_t cnt = tile_count[tile];
 			if (tb0 >= cnt || seg_lo + (i64)(tile + 1) * TILE - 1 <= p_skip) { // exhausted / inside a match
@@ -871,15 +1029,13 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		// the sweep of clean_one_from_hash() continues at clean_ptr: fetch its next 128 slots now so
 		// that the round trip overlaps the simulations (nothing writes the table before phase D)
 		const bool may_clean = R.hash_count + 64 > R.hash_limit;
-		Slot pre0, pre1;
-		pre0.offset = pre1.offset = 0;
-		pre0.t = pre1.t = 0;
+		uint32_t pre0 = 0, pre1 = 0; // rank bytes
 		if (may_clean) {
 			const i64 q0 = R.clean_ptr + lane;
 			if (q0 < tbl_size)
-				pre0 = tbl[q0];
+				pre0 = R.rk[q0];
 			if (q0 + 64 < tbl_size)
-				pre1 = tbl[q0 + 64];
+				pre1 = R.rk[q0 + 64];
 		}
 		lap(8);
 
@@ -892,6 +1048,7 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 			const u64 T = w_tag;
 			const i64 P = w_pos;
 			const int my_rank = bitness_rank(T);
+			const int nb1 = __popcll(better) + 1; // rank bytes below this are due for cleaning
 			int kind = -1; // insert stop: 0 empty, 1 due for cleaning, 2 lesser bitness
 			i64 sidx = 0;
 			Slot occ;
@@ -918,11 +1075,9 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 				uint32_t neq = 0;
 				int steps = 0;
 				bool fin = !need_sim;
-				const uint32_t b_lo = (uint32_t)better;
-				const int t_ones = my_rank - 1; // trailing one bits of T
-				const uint32_t m_lo = t_ones >= 32 ? 0xFFFFFFFFu : ((1u << t_ones) - 1);
+				const int thr = my_rank > nb1 ? my_rank : nb1; // ranks below this stop my insert
 				if (need_sim) {
-					L.complex_ = (better >> 32) != 0 || t_ones >= 32; // 32-bit predicate forms below
+					L.complex_ = nb1 >= 63 || my_rank >= 63; // rank bytes saturate at 63
 					L.match = false;
 					L.victim = false;
 					L.dec = 0;
@@ -938,122 +1093,110 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 					tw = tw && L.ins && !L.complex_ && (T & better) == better;
 					seek_pred = tw;
 				}
-				const uint32_t s_lo = b_lo | m_lo; // a slot stops the insert when its tag lacks any of these bits
-				const u64 T64 = T;
-				// one step: the 16 slots at idx.. are in c8; the next 16 are fetched into n8 meanwhile
-				// (double buffering: later steps of a long walk do not expose the load latency again)
-#define A1_STEP(c8, n8) \
-				if (!fin) { \
-_Pragma("unroll") \
-					for (int q = 0; q < WALK; q++) \
-						n8[q] = *reinterpret_cast<const uint4 *>(&tbl[idx + WALK + q]); \
-					uint32_t E = 0, Bm = 0, S = 0, Q = 0; \
-_Pragma("unroll") \
-					for (int q = WALK - 1; q >= 0; q--) { \
-						const uint32_t tl = c8[q].z; \
-						const u64 t64 = ((u64)c8[q].w << 32) | tl; \
-						E = (E << 1) | (uint32_t)(t64 == 0); \
-						Bm = (Bm << 1) | (uint32_t)((tl & b_lo) != b_lo); \
-						S = (S << 1) | (uint32_t)((tl & s_lo) != s_lo); \
-						Q = (Q << 1) | (uint32_t)(t64 == T64); \
-					} \
-					steps += WALK; \
-					if (idx + WALK > tbl_size || steps > 512) { \
-						L.complex_ = true; \
-						L.hi = (uint32_t)(idx + WALK - 1 < tbl_size - 1 ? idx + WALK - 1 : tbl_size - 1); \
-						fin = true; \
-					} else { \
-						uint32_t Em = E; \
-						if (kind < 0 && L.ins) { \
-							uint32_t from = 0; \
-							for (int pass = 0; pass < 2; pass++) { \
-								const uint32_t Sm = S & ~((1u << from) - 1); \
-								const int s1 = Sm ? __ffs((int)Sm) - 1 : WALK; \
-								uint32_t eqb = Q & ((1u << s1) - 1) & ~((1u << from) - 1); \
-								while (eqb) { \
-									const int q = __ffs((int)eqb) - 1; \
-									eqb &= eqb - 1; \
-									if (neq < MAX_EQS) \
-										eqs_lds[neq * 64 + w_ticket] = (uint32_t)(idx + q); \
-									if (++neq >= R.max_chain) { \
-										if (R.max_chain <= MAX_EQS && !tw) \
-											kind = 3; \
-										else if (seek_pred) { \
-											tw = seek_pred = false; \
-											if (R.max_chain <= MAX_EQS) \
-												kind = 3; \
-											else \
-												L.complex_ = true; \
-										} else \
-											L.complex_ = true; \
-										eqb = 0; \
-									} \
-								} \
-								if (kind >= 0 || L.complex_ || s1 >= WALK) \
-									break; \
-								const int k1 = ((E >> s1) & 1) ? 0 : ((Bm >> s1) & 1) ? 1 : 2; \
-								if (!seek_pred) { \
-									kind = k1; \
-									sidx = idx + s1; \
-									if (tw && k1 == 2) \
-										L.complex_ = true; \
-									break; \
-								} \
-								seek_pred = false; \
-								if (k1 == 2 || (k1 == 1 && ((Q >> s1) & 1))) { \
-									tw = false; \
-									kind = k1; \
-									sidx = idx + s1; \
-									break; \
-								} \
-								L.tw_slot = (uint32_t)(idx + s1); \
-								L.tw_dec = k1 == 1; \
-								tw_hit = true; \
-								if (k1 == 0) \
-									Em &= ~(1u << s1); \
-								if (neq < MAX_EQS) \
-									eqs_lds[neq * 64 + w_ticket] = (uint32_t)(idx + s1); \
-								if (++neq >= R.max_chain) { \
-									L.complex_ = true; \
-									break; \
-								} \
-								from = (uint32_t)s1 + 1; \
-							} \
-						} \
-						const int fe = Em ? __ffs((int)Em) - 1 : WALK; \
-						uint32_t hm = Q & ((1u << fe) - 1); \
-						while (hm) { \
-							const int q = __ffs((int)hm) - 1; \
-							hm &= hm - 1; \
-							uint4 o = c8[0]; \
-_Pragma("unroll") \
-							for (int qq = 1; qq < WALK; qq++) \
-								if (qq == q) \
-									o = c8[qq]; \
-							if (nhit < MAX_HITS) \
-								hit_lds[nhit * 64 + lane] = (i64)(((u64)o.y << 32) | o.x); \
-							else \
-								L.complex_ = true; \
-							nhit++; \
-						} \
-						if (fe < WALK) { \
-							L.hi = (uint32_t)(idx + fe); \
-							fin = true; \
-						} \
-					} \
-					idx += WALK; \
-				}
-				uint4 bufA[WALK], bufB[WALK];
-				if (!fin) {
-#pragma unroll
-					for (int q = 0; q < WALK; q++)
-						bufA[q] = *reinterpret_cast<const uint4 *>(&tbl[idx + q]);
-				}
+				const u64 thr8 = (u64)thr * B01, fp8 = (u64)fp_byte(T) * B01;
 				while (__ballot(!fin)) {
-					A1_STEP(bufA, bufB)
-					if (!__ballot(!fin))
-						break;
-					A1_STEP(bufB, bufA)
+					if (!fin) {
+						// 64 slots per step: their rank and fingerprint bytes (the arrays are padded)
+						U128u r4[4], f4[4];
+#pragma unroll
+						for (int c = 0; c < 4; c++) {
+							r4[c] = *reinterpret_cast<const U128u *>(R.rk + idx + 16 * c);
+							f4[c] = *reinterpret_cast<const U128u *>(R.fpa + idx + 16 * c);
+						}
+						u64 E = 0, S = 0, Q = 0; // bit q: slot idx + q is empty / stops my insert / may hold my tag
+#pragma unroll
+						for (int c = 3; c >= 0; c--) {
+							E = (E << 16) | (flags_to_bits(bytes_lt(r4[c].b, B01)) << 8) | flags_to_bits(bytes_lt(r4[c].a, B01));
+							S = (S << 16) | (flags_to_bits(bytes_lt(r4[c].b, thr8)) << 8) | flags_to_bits(bytes_lt(r4[c].a, thr8));
+							Q = (Q << 16) | (flags_to_bits(bytes_eq(f4[c].b, fp8)) << 8) | flags_to_bits(bytes_eq(f4[c].a, fp8));
+						}
+						steps += 64;
+						if (idx + 64 > tbl_size || steps > A1_MAX_STEPS) {
+							L.complex_ = true;
+							L.hi = (uint32_t)(idx + 63 < tbl_size - 1 ? idx + 63 : tbl_size - 1);
+							fin = true;
+						} else {
+							u64 Em = E;
+							if (kind < 0 && L.ins) {
+								int from = 0;
+								for (int pass = 0; pass < 2; pass++) {
+									const u64 Sm = S & ~low_mask(from);
+									const int s1 = Sm ? __ffsll((long long)Sm) - 1 : 64;
+									u64 eqb = Q & low_mask(s1) & ~low_mask(from);
+									while (eqb) {
+										const int q = __ffsll((long long)eqb) - 1;
+										eqb &= eqb - 1;
+										if (tbl[idx + q].t != T)
+											continue; // fingerprint false positive
+										if (neq < MAX_EQS)
+											eqs_lds[neq * 64 + w_ticket] = (uint32_t)(idx + q);
+										if (++neq >= R.max_chain) {
+											if (R.max_chain <= MAX_EQS && !tw)
+												kind = 3; // round-robin eviction among these equal tags
+											else if (seek_pred) {
+												tw = seek_pred = false;
+												if (R.max_chain <= MAX_EQS)
+													kind = 3;
+												else
+													L.complex_ = true;
+											} else
+												L.complex_ = true;
+											eqb = 0;
+										}
+									}
+									if (kind >= 0 || L.complex_ || s1 >= 64)
+										break;
+									const int rv = R.rk[idx + s1]; // just loaded: which kind of stop is it?
+									const int k1 = rv == 0 ? 0 : rv < nb1 ? 1 : 2;
+									if (!seek_pred) {
+										kind = k1;
+										sidx = idx + s1; // a lesser-bitness occupant (kind 2) is fetched after the walk
+										if (tw && k1 == 2)
+											L.complex_ = true;
+										break;
+									}
+									seek_pred = false;
+									if (k1 == 2 || (k1 == 1 && ((Q >> s1) & 1))) {
+										tw = false; // the predecessor displaces or replaces its own tag: conflict path
+										kind = k1;
+										sidx = idx + s1;
+										break;
+									}
+									L.tw_slot = (uint32_t)(idx + s1);
+									L.tw_dec = k1 == 1;
+									tw_hit = true;
+									if (k1 == 0)
+										Em &= ~(1ull << s1); // the twin fills the first empty slot: my lookup walks on
+									if (neq < MAX_EQS)
+										eqs_lds[neq * 64 + w_ticket] = (uint32_t)(idx + s1);
+									if (++neq >= R.max_chain) {
+										L.complex_ = true;
+										break;
+									}
+									from = s1 + 1;
+								}
+							}
+							const int fe = Em ? __ffsll((long long)Em) - 1 : 64; // first empty slot of the step
+							u64 hm = Q & low_mask(fe);
+							while (hm) {
+								const int q = __ffsll((long long)hm) - 1;
+								hm &= hm - 1;
+								const Slot sl = tbl[idx + q];
+								if (sl.t != T)
+									continue; // fingerprint false positive
+								if (nhit < MAX_HITS)
+									hit_lds[nhit * 64 + lane] = sl.offset;
+								else
+									L.complex_ = true;
+								nhit++;
+							}
+							if (fe < 64) {
+								L.hi = (uint32_t)(idx + fe);
+								fin = true;
+							}
+						}
+						idx += 64;
+					}
 				}
 			}
 
@@ -1151,44 +1294,50 @@ _Pragma("unroll") \
 					}
 					uint32_t neq2 = 0;
 					int st2 = 0;
+					const int thr2 = r2 > nb1 ? r2 : nb1;
+					const u64 thr2_8 = (u64)thr2 * B01, fp2_8 = (u64)fp_byte(cur_t) * B01;
 					while (__ballot(walk)) {
 						if (walk) {
-							Slot c8[8];
+							U128u r4[4], f4[4];
 #pragma unroll
-							for (int q = 0; q < 8; q++)
-								c8[q] = tbl[j + q];
+							for (int c = 0; c < 4; c++) {
+								r4[c] = *reinterpret_cast<const U128u *>(R.rk + j + 16 * c);
+								f4[c] = *reinterpret_cast<const U128u *>(R.fpa + j + 16 * c);
+							}
+							u64 S2 = 0, Q2 = 0;
 #pragma unroll
-							for (int q = 0; q < 8; q++) {
-								if (walk) {
-									if (j + q >= tbl_size || ++st2 > 192) {
+							for (int c = 3; c >= 0; c--) {
+								S2 = (S2 << 16) | (flags_to_bits(bytes_lt(r4[c].b, thr2_8)) << 8) | flags_to_bits(bytes_lt(r4[c].a, thr2_8));
+								Q2 = (Q2 << 16) | (flags_to_bits(bytes_eq(f4[c].b, fp2_8)) << 8) | flags_to_bits(bytes_eq(f4[c].a, fp2_8));
+							}
+							st2 += 64;
+							if (j + 64 > tbl_size || st2 > A1_MAX_STEPS || r2 >= 63) {
+								L.complex_ = true;
+								chain = false;
+								walk = false;
+							} else {
+								const int s2 = S2 ? __ffsll((long long)S2) - 1 : 64;
+								u64 eq2 = Q2 & low_mask(s2);
+								while (eq2) {
+									const int q = __ffsll((long long)eq2) - 1;
+									eq2 &= eq2 - 1;
+									if (tbl[j + q].t == cur_t && ++neq2 >= R.max_chain) {
 										L.complex_ = true;
 										chain = false;
 										walk = false;
-									} else {
-										const Slot sl = c8[q];
-										const bool empty = !(sl.offset | (i64)sl.t);
-										if (empty) {
-											kind = 0;
-										} else if ((sl.t & better) != better) {
-											kind = 1;
-										} else if (bitness_rank(sl.t) < r2) {
-											kind = 2;
-											occ = sl;
-										} else if (sl.t == cur_t) {
-											if (++neq2 >= R.max_chain) {
-												L.complex_ = true;
-												chain = false;
-												walk = false;
-											}
-										}
-										if (kind >= 0 && walk) {
-											sidx = j + q;
-											walk = false;
-										}
+										eq2 = 0;
 									}
 								}
+								if (walk && s2 < 64) {
+									sidx = j + s2;
+									const int rv = R.rk[sidx];
+									kind = rv == 0 ? 0 : rv < nb1 ? 1 : 2;
+									if (kind == 2)
+										occ = tbl[sidx];
+									walk = false;
+								}
 							}
-							j += 8;
+							j += 64;
 						}
 					}
 				}
@@ -1222,6 +1371,7 @@ _Pragma("unroll") \
 		}
 
 		// victim list: the next `want` entries the sweep would delete, in sweep order
+		const int vic_nb1 = __popcll(better) + 1;
 		int nv = 0;
 		i64 scan_end = R.clean_ptr;
 		if (want) {
@@ -1231,8 +1381,8 @@ _Pragma("unroll") \
 				const i64 q = ptr + lane;
 				bool cand = false;
 				if (q < tbl_size) {
-					const Slot s = (may_clean && rounds == 0) ? pre0 : (may_clean && rounds == 1) ? pre1 : tbl[q];
-					cand = (s.offset | (i64)s.t) && (s.t & better) != better;
+					const uint32_t rv = (may_clean && rounds == 0) ? pre0 : (may_clean && rounds == 1) ? pre1 : (uint32_t)R.rk[q];
+					cand = rv != 0 && rv < (uint32_t)vic_nb1; // occupied and due for cleaning
 				}
 				const u64 m = __ballot(cand);
 				const int r = nv + __popcll(m & lanes_below);
@@ -1295,6 +1445,9 @@ _Pragma("unroll") \
 		// granules into a small LDS table of hashed counters, every reader looks up the granules of
 		// its interval (minus its own writes); the few lanes that see a foreign write get the exact
 		// answer from the writers' registers.
+		// granule of the filter: clusters (and so read intervals) grow with the tag mask
+		int gsh = __popcll(R.min_mask) - 2;
+		gsh = gsh < 3 ? 3 : gsh > 16 ? 16 : gsh;
 		uint32_t wr[5], wh[5];
 #pragma unroll
 		for (int k = 0; k < 5; k++) {
@@ -1306,7 +1459,7 @@ _Pragma("unroll") \
 				} else
 					wr[k] = my_vict;
 			}
-			wh[k] = wr[k] != 0xFFFFFFFFu ? ((wr[k] >> 3) * 2654435761u) >> (32 - CF_BITS) : 0xFFFFFFFFu;
+			wh[k] = wr[k] != 0xFFFFFFFFu ? ((wr[k] >> gsh) * 2654435761u) >> (32 - CF_BITS) : 0xFFFFFFFFu;
 		}
 #pragma unroll
 		for (int k = 0; k < 5; k++)
@@ -1318,8 +1471,8 @@ _Pragma("unroll") \
 		const uint32_t r_lo = L.lo & ~7u, r_hi = L.hi | 7u;
 		bool flagged = false;
 		if (reads) {
-			const uint32_t g1 = L.hi >> 3;
-			for (uint32_t g = L.lo >> 3; g <= g1; g += 4) {
+			const uint32_t g1 = L.hi >> gsh;
+			for (uint32_t g = L.lo >> gsh; g <= g1; g += 4) {
 				uint32_t acc = 0;
 #pragma unroll
 				for (uint32_t u = 0; u < 4; u++) {
@@ -1392,18 +1545,10 @@ _Pragma("unroll") \
 		// Phase D: apply the committed prefix
 		if (committed) {
 			for (int k = 0; k < 4; k++)
-				if (k < L.nw) {
-					Slot w;
-					w.offset = L.w_off[k];
-					w.t = L.w_t[k];
-					tbl[L.w_slot[k]] = w;
-				}
-			if (cleans) {
-				Slot z;
-				z.offset = 0;
-				z.t = 0;
-				tbl[my_vict] = z;
-			}
+				if (k < L.nw)
+					R.store_slot(L.w_slot[k], L.w_t[k], L.w_off[k]);
+			if (cleans)
+				R.store_slot(my_vict, 0, 0);
 		}
 		{
 			const u64 cm = __ballot(committed);
@@ -1470,6 +1615,9 @@ _Pragma("unroll") \
 		st->victim_round = R.victim_round;
 		st->n_records = n_rec;
 		st->error = error;
+		st->ext_p = R.ext_p;
+		st->ext_op = R.ext_op;
+		st->ext_done = R.ext_done;
 		st->inserts = inserts;
 		st->lookups = lookups;
 		st->tag_hits = R.tag_hits;
@@ -1486,6 +1634,47 @@ _Pragma("unroll") \
 		any ^= bcast64(any, lane ^ d);
 	if (lane == 0 && any == 0x9E3779B97F4A7C15ull)
 		st->sink = any;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: grid-wide forward extent of one long match
+// ---------------------------------------------------------------------------------------------
+// Equal bytes of buf[p + start ..] and buf[op + start ..] (op < p), at most `limit` in total, for
+// a match the resolver wave found still equal after LONG_EXTENT bytes (a single wave compares at
+// ~1 GB/s; the whole chip streams the two operands at HBM speed).  *best holds the smallest
+// mismatch offset found so far (initialised to `limit`); tiles past it are skipped.
+constexpr int LC_TILE = 1 << 16;
+__global__ void __launch_bounds__(256) k_long_compare(const uint8_t *__restrict__ buf, i64 p, i64 op, i64 start, i64 limit,
+						      unsigned long long *__restrict__ best)
+{
+	const i64 ntiles = (limit - start + LC_TILE - 1) / LC_TILE;
+	for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+		const i64 t0 = start + t * LC_TILE;
+		if ((unsigned long long)t0 >= __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+			return; // tiles only grow from here
+		const i64 t1 = t0 + LC_TILE < limit ? t0 + LC_TILE : limit;
+		i64 mine = (i64)1 << 62;
+		for (i64 off = t0 + (i64)threadIdx.x * 16; off < t1; off += 256 * 16) {
+			if (off + 16 <= t1) {
+				const U128u a = *reinterpret_cast<const U128u *>(buf + p + off);
+				const U128u b = *reinterpret_cast<const U128u *>(buf + op + off);
+				const u64 x0 = a.a ^ b.a, x1 = a.b ^ b.b;
+				if (x0 | x1) {
+					mine = off + (x0 ? (__ffsll((long long)x0) - 1) >> 3 : 8 + ((__ffsll((long long)x1) - 1) >> 3));
+					break;
+				}
+			} else {
+				for (i64 k = off; k < t1; k++)
+					if (buf[p + k] != buf[op + k]) {
+						mine = k;
+						break;
+					}
+				break;
+			}
+		}
+		if (mine < ((i64)1 << 62))
+			atomicMin(best, (unsigned long long)mine);
+	}
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1719,6 +1908,8 @@ int scan_workspace_create(ScanWorkspace **out, int rzip_level, int64_t max_chunk
 	for (w->hash_bits = 0; ((int64_t)1 << w->hash_bits) < hashsize; w->hash_bits++)
 		;
 	HIPCHK(hipMalloc(&w->table, ((size_t)16 << w->hash_bits) + 64 * 16));
+	HIPCHK(hipMalloc(&w->rank_bytes, ((size_t)1 << w->hash_bits) + 256));
+	HIPCHK(hipMalloc(&w->fp_bytes, ((size_t)1 << w->hash_bits) + 256));
 	HIPCHK(hipMalloc(&w->state, sizeof(ScanState)));
 	HIPCHK(hipMalloc(&w->hx, 256 * 8));
 	{
@@ -1734,12 +1925,22 @@ int scan_workspace_create(ScanWorkspace **out, int rzip_level, int64_t max_chunk
 	HIPCHK(hipMalloc(&w->cand_rel, w->seg_cap * 4));
 	HIPCHK(hipMalloc(&w->cand_tag, w->seg_cap * 8));
 	HIPCHK(hipMalloc(&w->tile_count, (w->seg_cap / TILE + 2) * 4));
+	HIPCHK(hipMalloc(&w->tile_base, (w->seg_cap / TILE + 2) * 4));
+	w->comp_cap = w->seg_cap < ((size_t)1 << 25) ? w->seg_cap : (size_t)1 << 25; // segments aim at ~2M candidates
+	if (const char *e = getenv("LRZGPU_COMP_CAP")) { // test hook: small values force the per-tile fallback
+		const long long v = atoll(e);
+		if (v >= 0 && (size_t)v < w->comp_cap)
+			w->comp_cap = (size_t)v;
+	}
+	HIPCHK(hipMalloc(&w->comp_rel, (w->comp_cap + 64) * 4));
+	HIPCHK(hipMalloc(&w->comp_tag, (w->comp_cap + 64) * 8));
 	w->rec_cap = max_chunk / MINIMUM_MATCH + 16;
 	if (w->rec_cap > (int64_t)1 << 26)
 		w->rec_cap = (int64_t)1 << 26;
 	HIPCHK(hipMalloc(&w->records, (size_t)w->rec_cap * sizeof(MatchRec)));
 	w->crc_cap = (size_t)(max_chunk / CRC_TILE + 2);
 	HIPCHK(hipMalloc(&w->crc_partial, (w->crc_cap + 256) * 4));
+	HIPCHK(hipMalloc(&w->long_best, 8));
 	uint64_t hx[256];
 	hash_index_table(hx);
 	HIPCHK(hipMemcpy(w->hx, hx, sizeof(hx), hipMemcpyHostToDevice));
@@ -1751,7 +1952,8 @@ void scan_workspace_destroy(ScanWorkspace *w)
 {
 	if (!w)
 		return;
-	void *ptrs[] = {w->table, w->state, w->hx, w->cand_rel, w->cand_tag, w->tile_count, w->records, w->crc_partial};
+	void *ptrs[] = {w->table, w->state, w->hx, w->cand_rel, w->cand_tag, w->tile_count, w->records, w->crc_partial, w->long_best,
+			w->tile_base, w->comp_rel, w->comp_tag, w->rank_bytes, w->fp_bytes};
 	for (void *p : ptrs)
 		if (p)
 			(void)hipFree(p);
@@ -1774,7 +1976,10 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 	h.min_mask = h.tag_mask;
 	h.victim_round = *victim_round;
 	h.rec_cap = w->rec_cap;
+	h.hint_p = h.hint_op = -1;
 	HIPCHK(hipMemsetAsync(w->table, 0, ((size_t)16 << w->hash_bits) + 64 * 16, s));
+	HIPCHK(hipMemsetAsync(w->rank_bytes, 0, ((size_t)1 << w->hash_bits) + 256, s));
+	HIPCHK(hipMemsetAsync(w->fp_bytes, 0, ((size_t)1 << w->hash_bits) + 256, s));
 	HIPCHK(hipMemcpyAsync(w->state, &h, sizeof(h), hipMemcpyHostToDevice, s));
 
 	const auto wall0 = std::chrono::steady_clock::now();
@@ -1797,18 +2002,24 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 		EventTimer t1(s);
 		hipLaunchKernelGGL(k_tag_scan, dim3(ntiles), dim3(256), 0, s, d_chunk, (i64)seg_lo, (i64)seg_hi, (const u64 *)w->hx,
 				   (const ScanState *)w->state, w->cand_rel, (u64 *)w->cand_tag, w->tile_count);
+		hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, (const uint32_t *)w->tile_count, ntiles, w->tile_base);
+		hipLaunchKernelGGL(k_compact_cands, dim3(ntiles), dim3(256), 0, s, (const uint32_t *)w->cand_rel, (const u64 *)w->cand_tag,
+				   (const uint32_t *)w->tile_count, (const uint32_t *)w->tile_base, (uint32_t)w->comp_cap, w->comp_rel,
+				   (u64 *)w->comp_tag);
 		t1.stop();
 		EventTimer t2(s);
 		hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), 0, s, d_chunk, (Slot *)w->table, w->state, (i64)seg_lo, ntiles,
 				   (const uint32_t *)w->cand_rel, (const u64 *)w->cand_tag, (const uint32_t *)w->tile_count, w->records,
-				   w->batch_mode);
+				   w->batch_mode, (const uint32_t *)w->tile_base, (const uint32_t *)w->comp_rel, (const u64 *)w->comp_tag,
+				   (uint32_t)w->comp_cap, w->rank_bytes, w->fp_bytes);
 		t2.stop();
 		HIPCHK(hipMemcpyAsync(&h, w->state, sizeof(h), hipMemcpyDeviceToHost, s));
 		HIPCHK(hipStreamSynchronize(s));
 		if (getenv("LRZGPU_TRACE"))
-			fprintf(stderr, "lrzgpu scan: seg [%lld,%lld) tiles %d  k1 %.2f ms  k2 %.2f ms  p_skip %lld  mask %llx  lookups %lld recs %lld\n",
+			fprintf(stderr, "lrzgpu scan: seg [%lld,%lld) tiles %d  k1 %.2f ms  k2 %.2f ms  p_skip %lld  mask %llx  lookups %lld recs %lld  batches %lld committed %lld serial %lld complex %lld conflict %lld\n",
 				(long long)seg_lo, (long long)seg_hi, ntiles, t1.ms(), t2.ms(), (long long)h.p_skip,
-				(unsigned long long)h.min_mask, (long long)h.lookups, (long long)h.n_records);
+				(unsigned long long)h.min_mask, (long long)h.lookups, (long long)h.n_records, (long long)h.dbg[0],
+				(long long)h.dbg[1], (long long)h.dbg[2], (long long)h.dbg[3], (long long)h.dbg[5]);
 		{
 			ProfileStore &ps = ProfileStore::get();
 			std::lock_guard<std::mutex> lk(ps.mu);
@@ -1817,6 +2028,35 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 			ps.p.tag_scan_positions += seg_hi - seg_lo;
 			ps.p.resolve_ms += t2.ms();
 			ps.p.resolve_launches++;
+		}
+		if (h.error == 3) {
+			// the resolver met a match that is still equal after LONG_EXTENT bytes: finish the
+			// compare on the whole GPU, leave the answer as a hint and resume at that candidate
+			const int64_t limit = chunk_size - h.ext_p;
+			unsigned long long best = (unsigned long long)limit;
+			HIPCHK(hipMemcpyAsync(w->long_best, &best, 8, hipMemcpyHostToDevice, s));
+			EventTimer t3(s);
+			hipLaunchKernelGGL(k_long_compare, dim3(2048), dim3(256), 0, s, d_chunk, (i64)h.ext_p, (i64)h.ext_op, (i64)h.ext_done,
+					   (i64)limit, w->long_best);
+			t3.stop();
+			HIPCHK(hipMemcpyAsync(&best, w->long_best, 8, hipMemcpyDeviceToHost, s));
+			HIPCHK(hipStreamSynchronize(s));
+			h.hint_p = h.ext_p;
+			h.hint_op = h.ext_op;
+			h.hint_len = (int64_t)best;
+			h.error = 0;
+			HIPCHK(hipMemcpyAsync(w->state, &h, sizeof(h), hipMemcpyHostToDevice, s));
+			if (getenv("LRZGPU_TRACE"))
+				fprintf(stderr, "lrzgpu scan: long extent at %lld from %lld: %lld bytes, k3 %.2f ms\n", (long long)h.ext_p,
+					(long long)h.ext_op, (long long)best, t3.ms());
+			p_skip = h.p_skip;
+			min_mask = h.min_mask;
+			if (progress) {
+				int pr = progress(h, p_skip);
+				if (pr)
+					return pr;
+			}
+			continue;
 		}
 		if (h.error)
 			return h.error == 1 ? -4 : -5;

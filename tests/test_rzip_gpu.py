@@ -52,6 +52,26 @@ def test_long_range_copy(B, O):
     assert st.match_bytes > 11 * 1048576
 
 
+@pytest.mark.parametrize("break_at", [None, 9 * 1048576 + 12345, 4 * 1048576 + 1, 12 * 1048576 - 3])
+def test_long_match_extent_offload(B, O, break_at):
+    """A 12 MiB exact copy: the resolver hands forward extents that are still equal after 4 MiB to the
+    grid-wide compare (k_long_compare) and resumes; a single changed byte ends the match inside it."""
+    half = 12 * 1048576
+    base = bytearray(datagen.random_bytes(half, seed=31))
+    data = bytearray(base + base)
+    if break_at is not None:
+        data[half + break_at] ^= 0x5A
+    st = _check(B, O, bytes(data), level=7)
+    assert st.match_bytes > 11 * 1048576
+
+
+def test_per_tile_candidate_fallback(B, O, monkeypatch):
+    """Segments with more candidates than the packed list holds fall back to the per-tile lists."""
+    monkeypatch.setenv("LRZGPU_COMP_CAP", "1000")
+    _check(B, O, datagen.text_like(3 * 1048576 + 5, seed=41), level=7)
+    _check(B, O, datagen.long_range(2 * 1048576, seed=42), level=4)
+
+
 def test_victim_round_carry(B, O):
     """Many identical tags force the round-robin victim path; the static victim_round is carried in/out."""
     pat = (b"0123456789abcdefghijklmnopqrstu" * 40 + b"XYZ") * 3000
