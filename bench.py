@@ -45,7 +45,8 @@ class Profile(C.Structure):
                                           "lz4_launches", "mf_launches", "tag_scan_positions", "resolve_lookups",
                                           "resolve_inserts", "resolve_match_bytes", "crc_bytes", "gather_bytes",
                                           "lz4_bytes", "mf_positions", "mf_entries")] + \
-               [("scan_wall_ms", C.c_double), ("resolve_dbg", C.c_int64 * 16)]
+               [("scan_wall_ms", C.c_double), ("resolve_dbg", C.c_int64 * 16), ("long_compare_ms", C.c_double),
+                ("long_compare_launches", C.c_int64), ("long_compare_bytes", C.c_int64)]
 
 
 ALPHABETS = {
@@ -119,6 +120,21 @@ def cpu_baseline(sample_bytes, ctl_kw, cores, alphabet="alnum"):
             "seconds": round(dt, 2)}
 
 
+def pmc_traffic(kernel, args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r1_k_resolve_pmc.json; counters cannot be read from inside the process)."""
+    path = os.path.join(ROOT, "profiles", "r1_k_resolve_pmc.json")
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None, "no PMC summary committed"
+    if kernel != d.get("kernel") or args.mib != d.get("workload_mib") or args.alphabet != d.get("alphabet"):
+        return None, "PMC summary is for %s on the %s MiB workload" % (d.get("kernel"), d.get("workload_mib"))
+    b = (d["fetch_kb_per_launch"] + d["write_kb_per_launch"]) * 1024.0
+    return int(b), ("(FETCH_SIZE + WRITE_SIZE) x 1024 per launch from profiles/r1_bench4g_pmc_hbm.csv, raw; "
+                    "gfx950 FETCH_SIZE under-reports wide streams 2x, so reads are between 1x and 2x the fetch part")
+
+
 def usable_cpus():
     """CPUs this process can actually burn: affinity mask, capped by the cgroup CPU quota."""
     n = float(len(os.sched_getaffinity(0)))
@@ -144,7 +160,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=0)
     ap.add_argument("--mib", type=int, default=int(os.environ.get("LRZGPU_BENCH_MIB", "4096")),
                     help="workload size per GPU in MiB (default: the 4 GiB configuration)")
-    ap.add_argument("--cpu-sample-mib", type=int, default=int(os.environ.get("LRZGPU_CPU_SAMPLE_MIB", "128")))
+    ap.add_argument("--cpu-sample-mib", type=int, default=int(os.environ.get("LRZGPU_CPU_SAMPLE_MIB", "1024")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--threads", type=int, default=0, help="-p (default: host cores)")
     ap.add_argument("--host-threads", type=int, default=0,
@@ -221,8 +237,12 @@ def main():
         value = total_mib / dt
         # dominant kernel by accumulated device time
         kernels = {
+            # k_resolve: one 16-byte slot per probe and per insert + both operands of the match bytes it
+            # verifies itself (extents beyond 4 MiB are k_long_compare's)
             "k_resolve": (prof.resolve_ms, prof.resolve_launches,
-                          16 * (prof.resolve_lookups + prof.resolve_inserts) + 2 * prof.resolve_match_bytes),
+                          16 * (prof.resolve_lookups + prof.resolve_inserts) + 2 * prof.resolve_match_bytes
+                          - prof.long_compare_bytes),
+            "k_long_compare": (prof.long_compare_ms, prof.long_compare_launches, prof.long_compare_bytes),
             "k_bt": (prof.mf_bt_ms, prof.mf_launches, 13 * prof.mf_positions),
             "k_tag_scan": (prof.tag_scan_ms, prof.tag_scan_launches, prof.tag_scan_positions),
             "k_lz4_size": (prof.lz4_ms, prof.lz4_launches, prof.lz4_bytes),
@@ -236,8 +256,9 @@ def main():
         ms, launches, alg_bytes = kernels[dom]
         avg_ms = ms / max(launches, 1)
         achieved = (alg_bytes / max(launches, 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic, traffic_note = pmc_traffic(dom, args)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(achieved / 8000.0, 6), "traffic": None,
+                    "frac": round(achieved / 8000.0, 6), "traffic": traffic, "traffic_note": traffic_note,
                     "avg_launch_ms": round(avg_ms, 3), "launches": int(launches),
                     "algorithmic_bytes_per_launch": int(alg_bytes / max(launches, 1)),
                     "per_kernel_ms": {k: round(v[0], 2) for k, v in kernels.items()},

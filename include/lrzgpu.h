@@ -152,7 +152,11 @@ typedef struct lrzgpu_profile {
 	double scan_wall_ms;          /* host wall time inside scan_chunk_device              */
 	int64_t resolve_dbg[16];      /* batches, committed lanes, serial steps, stops: complex, match,
 	                                 conflict, no-victim, swept-range; [8..13] shader cycles in
-	                                 refill, simulate, victim scan, conflict test, apply, tail */
+	                                 refill, simulate, victim scan, conflict test, apply, tail
+	                                 (cycle laps only with LRZGPU_RESOLVE_PROF=1)              */
+	double long_compare_ms;       /* k_long_compare: forward extents of matches > 4 MiB    */
+	int64_t long_compare_launches;
+	int64_t long_compare_bytes;   /* bytes of both operands it compared                    */
 } lrzgpu_profile;
 void lrzgpu_profile_reset(void);
 void lrzgpu_profile_get(lrzgpu_profile *out);

@@ -2044,6 +2044,13 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 			h.hint_p = h.ext_p;
 			h.hint_op = h.ext_op;
 			h.hint_len = (int64_t)best;
+			{
+				ProfileStore &ps = ProfileStore::get();
+				std::lock_guard<std::mutex> lk(ps.mu);
+				ps.p.long_compare_ms += t3.ms();
+				ps.p.long_compare_launches++;
+				ps.p.long_compare_bytes += 2 * ((int64_t)best - h.ext_done);
+			}
 			h.error = 0;
 			HIPCHK(hipMemcpyAsync(w->state, &h, sizeof(h), hipMemcpyHostToDevice, s));
 			if (getenv("LRZGPU_TRACE"))
