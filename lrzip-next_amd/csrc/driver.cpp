@@ -126,20 +126,83 @@ struct ChunkCtx {
 	std::vector<uint8_t> stream0;
 };
 
-template <typename T> struct RawBuf { // uninitialised host buffer (std::vector would zero-fill)
-	std::unique_ptr<T[]> p;
-	size_t n = 0;
+// Recycled host buffers for block copies and match lists.  A 16 MiB block has ~450 MB of lists;
+// taking that from malloc() for every block means a fresh mmap, a page fault per 4 KiB and an
+// munmap -- seconds of kernel time per GiB of input that the encoders would rather have.
+struct HostPool {
+	std::mutex mu;
+	std::vector<std::pair<size_t, void *>> idle; // (capacity, pointer)
+	size_t idle_bytes = 0;
+	static HostPool &get()
+	{
+		static HostPool p;
+		return p;
+	}
+	void *take(size_t bytes, size_t *cap)
+	{
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			size_t best = idle.size();
+			for (size_t i = 0; i < idle.size(); i++)
+				if (idle[i].first >= bytes && (best == idle.size() || idle[i].first < idle[best].first))
+					best = i;
+			if (best != idle.size() && idle[best].first <= 2 * bytes + ((size_t)64 << 20)) {
+				void *p = idle[best].second;
+				*cap = idle[best].first;
+				idle_bytes -= idle[best].first;
+				idle[best] = idle.back();
+				idle.pop_back();
+				return p;
+			}
+		}
+		const size_t round = (size_t)8 << 20;
+		*cap = (bytes + round - 1) / round * round;
+		if (*cap == 0)
+			*cap = round;
+		return malloc(*cap);
+	}
+	void give(void *p, size_t cap)
+	{
+		if (!p)
+			return;
+		std::lock_guard<std::mutex> lk(mu);
+		if (idle.size() >= 96 || idle_bytes + cap > ((size_t)48 << 30)) {
+			free(p);
+			return;
+		}
+		idle.emplace_back(cap, p);
+		idle_bytes += cap;
+	}
+	~HostPool()
+	{
+		for (auto &e : idle)
+			free(e.second);
+	}
+};
+
+template <typename T> struct RawBuf { // uninitialised host buffer (std::vector would zero-fill), recycled
+	T *p = nullptr;
+	size_t n = 0, cap = 0;
+	RawBuf() = default;
+	RawBuf(const RawBuf &) = delete;
+	RawBuf &operator=(const RawBuf &) = delete;
 	void alloc(size_t k)
 	{
-		p.reset(new T[k ? k : 1]);
+		release();
+		p = (T *)HostPool::get().take((k ? k : 1) * sizeof(T), &cap);
+		if (!p)
+			throw std::bad_alloc();
 		n = k;
 	}
 	void release()
 	{
-		p.reset();
-		n = 0;
+		if (p)
+			HostPool::get().give(p, cap);
+		p = nullptr;
+		n = cap = 0;
 	}
-	T *data() { return p.get(); }
+	~RawBuf() { release(); }
+	T *data() { return p; }
 };
 
 struct Job {
@@ -299,7 +362,7 @@ struct Pipeline {
 			}
 			if (prev_len)
 				memcpy((uint8_t *)dst + prev_off, stage[k ^ 1], prev_len);
-			if (hipStreamSynchronize(s) != hipSuccess)
+			if (stream_wait(s) != hipSuccess)
 				return -1;
 			prev_off = off;
 			prev_len = len;
@@ -377,7 +440,7 @@ struct Pipeline {
 					if (!d_stage && hipMalloc(&d_stage, bufsize + 256) != hipSuccess)
 						rc = LRZGPU_E_NOMEM;
 					else if (hipMemcpyAsync(d_stage, j->bytes.data(), (size_t)n, hipMemcpyHostToDevice, s) != hipSuccess ||
-						 hipStreamSynchronize(s) != hipSuccess)
+						 stream_wait(s) != hipSuccess)
 						rc = LRZGPU_E_HIP;
 					d_blk = d_stage;
 				}
@@ -532,6 +595,9 @@ struct Feeder {
 				q.src = j->chunk->d_stream1 + j->ref.off;
 				q.src_size = (int)j->ref.len;
 				q.dst_capacity = (int)j->ref.len + 1;
+				// the container only depends on the verdict (src/stream.c:2325-2380 returns a percentage
+				// that is merely printed): let the kernel stop once "compressible" is certain
+				q.stop_below = (int)((double)j->ref.len * ((double)P.sz.threshold / 100.0));
 				lj.push_back(q);
 				b.jobs.push_back(j);
 				b.bytes += j->ref.len;
@@ -545,13 +611,13 @@ struct Feeder {
 		arena_used += lj.size();
 		// descriptors go up on the (idle) scan stream: `ls` may still be busy with earlier gate launches
 		if (hipMemcpyAsync(b.d_jobs, lj.data(), lj.size() * sizeof(Lz4Job), hipMemcpyHostToDevice, ms) != hipSuccess ||
-		    hipStreamSynchronize(ms) != hipSuccess)
+		    stream_wait(ms) != hipSuccess)
 			return LRZGPU_E_HIP;
 		ls = gate_streams[gate_rr++ % gate_streams.size()];
 		b.timer = new EventTimer(ls);
 		int lr = lz4_sizes_device(b.d_jobs, (int)lj.size(), b.d_res, ls);
 		b.timer->stop();
-		if (lr != 0 || hipEventCreate(&b.ev) != hipSuccess || hipEventRecord(b.ev, ls) != hipSuccess)
+		if (lr != 0 || hipEventCreateWithFlags(&b.ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess || hipEventRecord(b.ev, ls) != hipSuccess)
 			return LRZGPU_E_HIP;
 		batches.push_back(std::move(b));
 		return 0;
@@ -688,7 +754,7 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 			}
 			for (int64_t o = 0; o < in.n; o += (int64_t)piece) {
 				size_t k = (size_t)(in.n - o < (int64_t)piece ? in.n - o : (int64_t)piece);
-				if (hipMemcpyAsync(stage, in.dev + o, k, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+				if (hipMemcpyAsync(stage, in.dev + o, k, hipMemcpyDeviceToHost, s) != hipSuccess || stream_wait(s) != hipSuccess) {
 					md5_err = LRZGPU_E_HIP;
 					break;
 				}
@@ -752,7 +818,7 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 		EventTimer tg(ms);
 		int gr = gather_runs_device(d_chunk, cc->d_stream1, d_runs, (int)runs.size(), S0, S1, ms);
 		tg.stop();
-		if (gr != 0 || hipStreamSynchronize(ms) != hipSuccess)
+		if (gr != 0 || stream_wait(ms) != hipSuccess)
 			return LRZGPU_E_HIP;
 		ProfileStore &ps = ProfileStore::get();
 		std::lock_guard<std::mutex> lk(ps.mu);
@@ -932,7 +998,7 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 				break;
 			}
 		}
-		if (hipMemsetAsync(cc->d_stream1 + er.stream1_len, 0, 256, ms) != hipSuccess || hipStreamSynchronize(ms) != hipSuccess) {
+		if (hipMemsetAsync(cc->d_stream1 + er.stream1_len, 0, 256, ms) != hipSuccess || stream_wait(ms) != hipSuccess) {
 			ret = LRZGPU_E_HIP;
 			break;
 		}

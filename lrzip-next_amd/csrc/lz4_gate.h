@@ -10,6 +10,10 @@ struct Lz4Job {
 	const uint8_t *src; // device pointer
 	int src_size;
 	int dst_capacity;
+	// 0: exact size.  > 0: the caller only needs to know whether the size is below this value; the
+	// kernel may stop as soon as that is certain and then returns an upper bound of the size that is
+	// itself below stop_below (what is left of the block costs at most rest + rest/255 + 16 bytes).
+	int stop_below;
 };
 
 // results[j] = liblz4 1.9.3 LZ4_compress_default(src, dst, src_size, dst_capacity) return value.

@@ -340,6 +340,14 @@ __global__ void __launch_bounds__(64) k_lz4_size(const Lz4Job *__restrict__ jobs
 				op += (mc - ML_MASK) / 255 + 1;
 		}
 		anchor = ip;
+		if (job.stop_below > 0) {
+			const long long rest = (long long)iend - (long long)anchor;
+			const long long ub = op + rest + rest / 255 + 16;
+			if (ub < (long long)job.stop_below) {
+				result = (int)ub;
+				goto done;
+			}
+		}
 		if (ip >= mflimit_plus_one)
 			break;
 		ensure(ip);

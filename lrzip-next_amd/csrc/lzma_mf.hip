@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "common.h"
 #include "lzma_mf.h"
 #include "profile.h"
 
@@ -386,7 +387,7 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 		hipLaunchKernelGGL(k_seg_len, dim3(g), dim3(256), 0, s, w->seg_start, d_nseg, n4, w->seg_len);
 		uint32_t nseg = 0;
 		HIPCHK(hipMemcpyAsync(&nseg, d_nseg, 4, hipMemcpyDeviceToHost, s));
-		HIPCHK(hipStreamSynchronize(s));
+		HIPCHK(stream_wait(s));
 		// longest buckets first
 		tb = w->cub_bytes;
 		HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(w->cub_tmp, tb, w->seg_len, w->seg_len_s, w->seg_start,
@@ -408,7 +409,7 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 	t_all.stop();
 	unsigned long long host_sc[4];
 	HIPCHK(hipMemcpyAsync(host_sc, w->scalars, 32, hipMemcpyDeviceToHost, s));
-	HIPCHK(hipStreamSynchronize(s));
+	HIPCHK(stream_wait(s));
 	{
 		ProfileStore &ps = ProfileStore::get();
 		std::lock_guard<std::mutex> lk(ps.mu);

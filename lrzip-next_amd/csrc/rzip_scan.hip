@@ -29,6 +29,7 @@
 #include <chrono>
 
 #include "profile.h"
+#include "common.h"
 #include "rzip_scan.h"
 
 namespace lrzgpu {
@@ -1875,7 +1876,7 @@ int crc32_device(ScanWorkspace *w, const uint8_t *d_buf, int64_t n, uint32_t *cr
 	tc.stop();
 	std::vector<uint32_t> part(tiles);
 	HIPCHK(hipMemcpyAsync(part.data(), w->crc_partial, tiles * 4, hipMemcpyDeviceToHost, s));
-	HIPCHK(hipStreamSynchronize(s));
+	HIPCHK(stream_wait(s));
 	{
 		ProfileStore &ps = ProfileStore::get();
 		std::lock_guard<std::mutex> lk(ps.mu);
@@ -2014,7 +2015,7 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 				   (uint32_t)w->comp_cap, w->rank_bytes, w->fp_bytes);
 		t2.stop();
 		HIPCHK(hipMemcpyAsync(&h, w->state, sizeof(h), hipMemcpyDeviceToHost, s));
-		HIPCHK(hipStreamSynchronize(s));
+		HIPCHK(stream_wait(s));
 		if (getenv("LRZGPU_TRACE"))
 			fprintf(stderr, "lrzgpu scan: seg [%lld,%lld) tiles %d  k1 %.2f ms  k2 %.2f ms  p_skip %lld  mask %llx  lookups %lld recs %lld  batches %lld committed %lld serial %lld complex %lld conflict %lld\n",
 				(long long)seg_lo, (long long)seg_hi, ntiles, t1.ms(), t2.ms(), (long long)h.p_skip,
@@ -2040,7 +2041,7 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 					   (i64)limit, w->long_best);
 			t3.stop();
 			HIPCHK(hipMemcpyAsync(&best, w->long_best, 8, hipMemcpyDeviceToHost, s));
-			HIPCHK(hipStreamSynchronize(s));
+			HIPCHK(stream_wait(s));
 			h.hint_p = h.ext_p;
 			h.hint_op = h.ext_op;
 			h.hint_len = (int64_t)best;
@@ -2079,7 +2080,7 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 		// state already in h from the last segment
 	} else {
 		HIPCHK(hipMemcpyAsync(&h, w->state, sizeof(h), hipMemcpyDeviceToHost, s));
-		HIPCHK(hipStreamSynchronize(s));
+		HIPCHK(stream_wait(s));
 	}
 	res->records.resize((size_t)h.n_records);
 	if (h.n_records)
@@ -2087,7 +2088,7 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 	uint32_t crc = 0;
 	if (crc32_device(w, d_chunk, chunk_size, &crc, s) != 0)
 		return -6;
-	HIPCHK(hipStreamSynchronize(s));
+	HIPCHK(stream_wait(s));
 	res->crc = crc;
 	res->final_state = h;
 	if (getenv("LRZGPU_TRACE")) {
