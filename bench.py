@@ -193,7 +193,8 @@ def main():
     phys = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
     ctl_kw = dict(level=7, threads=threads, processors=cores, ramsize=phys)
     usable = usable_cpus()
-    host_threads = args.host_threads or max(1, min(threads, int(usable + 0.5)))
+    # the ranks of one node share the host: each gets its share of the usable CPUs for its encoders
+    host_threads = args.host_threads or max(1, min(threads, int(usable + 0.5) // world))
     n_bytes = args.mib << 20
 
     buf = make_workload(n_bytes, 1 + rank, dev, args.alphabet)
