@@ -110,6 +110,11 @@ constexpr int kMaxRec = 128; // u32 entries per position: 2 * (2 hash pairs + cu
 
 // One lane per hash bucket: replay the bucket's positions in order through the BT4 tree walk
 // (LzFindOpt.c GetMatchesSpecN_2 semantics), then the LZ-thread merge (MixMatches3).
+struct __attribute__((packed, aligned(1))) PackedU64 {
+	uint64_t v;
+};
+__device__ __forceinline__ uint64_t load_u64(const uint8_t *p) { return reinterpret_cast<const PackedU64 *>(p)->v; }
+
 __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint32_t n,
 					   const uint32_t *__restrict__ spos,
 					   const uint32_t *__restrict__ seg_len_sorted, const uint32_t *__restrict__ seg_start_sorted,
@@ -128,6 +133,13 @@ __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint
 	const uint32_t L = seg_len_sorted[g];
 	const uint32_t cyc_size = dict + 1;
 	uint32_t prev = 0; // 1-based position of the previous element of this bucket
+	// runs of one byte value put millions of consecutive positions into one bucket; each of them
+	// matches its predecessor over the full fb bytes at the first tree step and inherits its two
+	// sons.  Once that has happened for pos-1, pos only has to look at one new byte.
+	bool run_ok = false;
+	uint32_t run_s0 = 0, run_s1 = 0;
+	unsigned long long loc_base = 0;
+	uint32_t loc_free = 0;
 
 	for (uint32_t j = 0; j < L; j++) {
 		const uint32_t i = spos[k0 + j];
@@ -143,7 +155,15 @@ __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint
 		if (delta >= cbs) {
 			son[2 * (size_t)pos] = 0;
 			son[2 * (size_t)pos + 1] = 0;
+			run_ok = false;
+		} else if (run_ok && delta == 1 && len_limit == fb && cur[fb - 1] == cur[fb - 2]) {
+			son[2 * (size_t)pos] = run_s0;
+			son[2 * (size_t)pos + 1] = run_s1;
+			rec[0] = fb;
+			rec[1] = 0;
+			nrec = 2;
 		} else {
+			run_ok = false;
 			uint32_t *ptr0 = son + 2 * (size_t)pos + 1, *ptr1 = son + 2 * (size_t)pos;
 			uint32_t len0 = 0, len1 = 0, max_len = 3, cv = cut;
 			for (;;) {
@@ -153,9 +173,40 @@ __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint
 				uint32_t len = len0 < len1 ? len0 : len1;
 				const uint32_t pair0 = pair[0], pair1 = pair[1];
 				if (pb[len] == cur[len]) {
-					while (++len != len_limit)
-						if (pb[len] != cur[len])
-							break;
+					// eight bytes per step (unaligned loads stay inside [0, len_limit) <= avail)
+					++len;
+					if (len + 8 <= len_limit) {
+						const uint64_t x = load_u64(pb + len) ^ load_u64(cur + len);
+						if (x) {
+							len += (uint32_t)(__ffsll((long long)x) - 1) >> 3;
+							goto cmp_done;
+						}
+						len += 8;
+					}
+					while (len + 32 <= len_limit) { // long agreement: four words per round trip
+						uint64_t x[4];
+#pragma unroll
+						for (int w = 0; w < 4; w++)
+							x[w] = load_u64(pb + len + 8 * w) ^ load_u64(cur + len + 8 * w);
+#pragma unroll
+						for (int w = 0; w < 4; w++)
+							if (x[w]) {
+								len += 8 * w + ((uint32_t)(__ffsll((long long)x[w]) - 1) >> 3);
+								goto cmp_done;
+							}
+						len += 32;
+					}
+					while (len + 8 <= len_limit) {
+						const uint64_t x = load_u64(pb + len) ^ load_u64(cur + len);
+						if (x) {
+							len += (uint32_t)(__ffsll((long long)x) - 1) >> 3;
+							goto cmp_done;
+						}
+						len += 8;
+					}
+					while (len != len_limit && pb[len] == cur[len])
+						++len;
+				cmp_done:
 					if (max_len < len) {
 						max_len = len;
 						rec[nrec++] = len;
@@ -163,6 +214,11 @@ __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint
 						if (len == len_limit) {
 							*ptr1 = pair0;
 							*ptr0 = pair1;
+							if (delta == 1 && nrec == 2 && len_limit == fb && pos == prev + 1) {
+								run_ok = true; // first step, full length, distance 1
+								run_s0 = pair0;
+								run_s1 = pair1;
+							}
 							break;
 						}
 					}
@@ -217,7 +273,22 @@ __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint
 		const uint32_t cnt = nmix + nrec;
 		counts[i] = (uint8_t)cnt;
 		if (cnt) {
-			unsigned long long st = atomicAdd(cursor, (unsigned long long)cnt);
+			// output space: one returning atomic per position is a ~1 us round trip; a lane that walks a
+			// long bucket alone takes its space in pieces (a short bucket wastes nothing)
+			unsigned long long st;
+			if (L >= 64) {
+				if (cnt > loc_free) {
+					uint32_t take = (L - j) < 256 ? (L - j) * 4 : 1024;
+					if (take < cnt)
+						take = cnt;
+					loc_base = atomicAdd(cursor, (unsigned long long)take);
+					loc_free = take;
+				}
+				st = loc_base;
+				loc_base += cnt;
+				loc_free -= cnt;
+			} else
+				st = atomicAdd(cursor, (unsigned long long)cnt);
 			tmp_start[i] = st;
 			if (st + cnt > pool_cap) {
 				*err = 1;

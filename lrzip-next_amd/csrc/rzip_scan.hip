@@ -986,6 +986,7 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 			w_simd = false;
 	};
 
+	int poor_rounds = 0, serial_left = 0;
 	while (!error) {
 		lap(13);
 		refill_ring();
@@ -1014,8 +1015,12 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		const bool has = lane < wcount;
 		const bool alive = has && w_pos > p_skip && (w_tag & R.min_mask) == R.min_mask;
 
-		// ---- serial path: pending lazy match, or batching disabled ----
-		if (!(batch_mode & 1) || cur_len > 0) {
+		// ---- serial path: pending lazy match, batching disabled, or batching not paying off ----
+		// (inputs whose tags collapse onto a few buckets -- 4-symbol alphabets, long runs -- make
+		// every lane conflict with its predecessor; a failed round costs more than a serial step)
+		if (!(batch_mode & 1) || cur_len > 0 || serial_left > 0) {
+			if (serial_left > 0)
+				serial_left--;
 			const i64 P = (i64)bcast64((u64)w_pos, 0);
 			const u64 T = bcast64(w_tag, 0);
 			const bool a0 = __shfl((int)alive, 0) != 0;
@@ -1542,6 +1547,13 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 			dbg2[5] += f;
 		}
 		const bool committed = lane < f && live;
+		if (f < 4 && f < wcount) {
+			if (++poor_rounds >= 8) {
+				poor_rounds = 0;
+				serial_left = 256;
+			}
+		} else
+			poor_rounds = 0;
 
 		// Phase D: apply the committed prefix
 		if (committed) {

@@ -1,0 +1,56 @@
+"""Size-independent parity property of the whole path: decode(compress(x)) == x with an independent
+decoder (tests/lrz_decode.py: container walk, liblzma, rzip token replay, per-chunk CRC, MD5
+trailer), up to BASELINE.json's single-GPU configuration (4 GiB, -L7, input resident in HBM)."""
+import hashlib
+import importlib.util
+import os
+
+import pytest
+
+import datagen
+import lrz_decode
+
+pytestmark = pytest.mark.gpu
+RAM = 80 * 100 * 1048576
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("kind", ["text", "longrange", "random", "zeros", "phrases", "few"])
+@pytest.mark.parametrize("level", [5, 7, 9])
+def test_roundtrip_kinds(B, kind, level):
+    data = datagen.KINDS[kind](5 * 1048576 + 123, seed=level)
+    img, _ = B.compress_buffer(data, level=level, threads=4, processors=8, ramsize=RAM, host_threads=8)
+    assert bytes(lrz_decode.decode(img)) == data
+
+
+def test_roundtrip_multi_chunk(B):
+    data = datagen.long_range(250 * 1048576 + 4097, seed=14, base_frac=0.08, mutate_every=300007)
+    img, _ = B.compress_buffer(data, level=7, threads=4, processors=8, window=1, host_threads=16)
+    hdr, chunks = lrz_decode.parse(img)
+    assert len(chunks) == 3 and [c["eof"] for c in chunks] == [0, 0, 1]
+    assert bytes(lrz_decode.decode(img, threads=16)) == data
+
+
+def test_roundtrip_full_size_headline_workload(B):
+    """BASELINE.json configs[1]: 4 GiB synthetic 50%-long-range-redundant buffer, -L7, one chunk, input in HBM."""
+    import torch
+    spec = importlib.util.spec_from_file_location("lrz_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n = 4096 << 20
+    buf = bench.make_workload(n, 1, torch.device("cuda:0"), "alnum")
+    torch.cuda.synchronize()
+    cores = os.cpu_count() or 1
+    phys = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    usable = max(1, int(bench.usable_cpus() + 0.5))
+    ctl = B.make_control(level=7, threads=cores, processors=cores, ramsize=phys, host_threads=usable, gpu_slots=8)
+    img, ctl = B.compress_device(buf.data_ptr(), n, ctl=ctl, copy=False)
+    want_md5 = hashlib.md5(buf[:n].cpu().numpy()).digest()
+    del buf
+    view = img.view()
+    hdr, chunks = lrz_decode.parse(view)
+    assert hdr["st_size"] == n and len(chunks) == 1 and hdr["md5_digest"] == want_md5
+    assert len(chunks[0]["streams"][1]) >= 100  # ~128 literal blocks of stream_bufsize
+    out = lrz_decode.decode(view, threads=usable)  # checks the chunk CRC and md5(out) == trailer itself
+    assert out.shape[0] == n
+    img.free()
