@@ -62,7 +62,7 @@ extern "C" void lrzgpu_control_init(lrzgpu_control *c)
 
 namespace {
 
-constexpr int64_t SPEC_MARGIN = (int64_t)8 << 20; // literal bytes this far behind the scan count as decided
+constexpr int64_t SPEC_MARGIN = (int64_t)2 << 20; // literal bytes this far behind the scan count as decided
 constexpr size_t STAGE_BYTES = (size_t)32 << 20;  // pinned D2H staging piece (two per GPU worker)
 
 double now_s()
@@ -668,6 +668,24 @@ struct Feeder {
 	}
 };
 
+// memcpy of a result image: a few threads once it is large (one core moves ~5 GB/s)
+static void big_copy(uint8_t *dst, const uint8_t *src, size_t n)
+{
+	const size_t piece = (size_t)64 << 20;
+	if (n < 2 * piece) {
+		memcpy(dst, src, n);
+		return;
+	}
+	const int nt = n / piece < 8 ? (int)(n / piece) : 8;
+	std::vector<std::thread> th;
+	for (int t = 0; t < nt; t++) {
+		const size_t a = n / nt * t, b = t + 1 == nt ? n : n / nt * (t + 1);
+		th.emplace_back([=] { memcpy(dst + a, src + a, b - a); });
+	}
+	for (auto &x : th)
+		x.join();
+}
+
 // CPUs this process may burn: the affinity mask, capped by a cgroup CPU quota (v2 cpu.max, v1 cfs_quota_us)
 static int usable_cpus()
 {
@@ -1090,7 +1108,15 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 	if (ret)
 		return ret;
 
-	// ordered container assembly
+	// ordered container assembly (one allocation: headers + payloads are known now)
+	{
+		size_t total = 21 + 16;
+		for (auto &c : chunks)
+			total += 2 + (size_t)c->chunk_bytes * 7 + 2;
+		for (Job *j : file_order)
+			total += 1 + 3 * 8 + j->done.payload.size();
+		out->reserve(total);
+	}
 	if (with_magic)
 		out->assign(21, 0);
 	size_t ji = 0;
@@ -1166,7 +1192,7 @@ extern "C" int lrzgpu_compress_buffer(lrzgpu_control *control, const uint8_t *in
 	*out = (uint8_t *)malloc(o.size() ? o.size() : 1);
 	if (!*out)
 		return LRZGPU_E_NOMEM;
-	memcpy(*out, o.data(), o.size());
+	big_copy(*out, o.data(), o.size());
 	*out_len = (int64_t)o.size();
 	return 0;
 }
@@ -1190,7 +1216,7 @@ extern "C" int lrzgpu_compress_buffer_dev(lrzgpu_control *control, const void *d
 	*out = (uint8_t *)malloc(o.size() ? o.size() : 1);
 	if (!*out)
 		return LRZGPU_E_NOMEM;
-	memcpy(*out, o.data(), o.size());
+	big_copy(*out, o.data(), o.size());
 	*out_len = (int64_t)o.size();
 	return 0;
 }
@@ -1290,7 +1316,7 @@ extern "C" int lrzgpu_container_store(lrzgpu_control *control, int64_t st_size, 
 	*out = (uint8_t *)malloc(o.size());
 	if (!*out)
 		return LRZGPU_E_NOMEM;
-	memcpy(*out, o.data(), o.size());
+	big_copy(*out, o.data(), o.size());
 	*out_len = (int64_t)o.size();
 	return 0;
 }
