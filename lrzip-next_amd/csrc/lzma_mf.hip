@@ -254,7 +254,8 @@ __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint
 		uint32_t nmix = 0;
 		{
 			const uint32_t min_pos = nrec ? pos - rec[1] : (pos > dict ? pos - dict : 1);
-			const uint32_t c2 = prev2[i], c3 = prev3[i];
+			// (a first tree match at distance 1 leaves nothing nearer: no loads at all)
+			const uint32_t c2 = min_pos < pos ? prev2[i] : 0, c3 = min_pos < pos ? prev3[i] : 0;
 			bool done = false;
 			if (c2 >= min_pos && src[c2 - 1] == cur[0]) {
 				mix[1] = pos - c2 - 1;
@@ -299,6 +300,55 @@ __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint
 				for (uint32_t k = 0; k < nrec; k++)
 					o[nmix + k] = rec[k];
 			}
+		}
+
+		// Inside a run of one byte value every further position repeats this one: a full-length match
+		// at distance 1, no nearer h2/h3 candidate, the predecessor's two sons.  They need no tree
+		// reads, so a lane that owns a multi-million-position bucket of zeros writes them eight at a
+		// time (one load of the next bucket entries, one of the next bytes) instead of walking.
+		if (run_ok && L >= 64 && len_limit == fb) {
+			const uint32_t b = cur[fb - 1];
+			uint32_t t = 0; // positions done beyond this one
+			for (;;) {
+				if (j + 1 + t + 8 > L || (unsigned long long)i + t + 8 + fb > n)
+					break;
+				uint32_t sp[8];
+#pragma unroll
+				for (int q = 0; q < 8; q++)
+					sp[q] = spos[k0 + j + 1 + t + q];
+				const uint64_t by = load_u64(src + i + t + fb); // byte that position i+t+1+q adds to the window
+				uint32_t ok = 0;
+#pragma unroll
+				for (int q = 0; q < 8; q++)
+					if (ok == (uint32_t)q && sp[q] == i + t + 1 + q && ((by >> (8 * q)) & 0xFF) == b)
+						ok++;
+				for (uint32_t q = 0; q < ok; q++) {
+					const uint32_t iq = i + t + 1 + q;
+					son[2 * (size_t)(iq + 1)] = run_s0;
+					son[2 * (size_t)(iq + 1) + 1] = run_s1;
+					counts[iq] = 2;
+					if (loc_free < 2) {
+						uint32_t take = (L - j) < 256 ? (L - j) * 4 : 1024;
+						loc_base = atomicAdd(cursor, (unsigned long long)take);
+						loc_free = take;
+					}
+					const unsigned long long st = loc_base;
+					loc_base += 2;
+					loc_free -= 2;
+					tmp_start[iq] = st;
+					if (st + 2 > pool_cap)
+						*err = 1;
+					else {
+						pool[st] = fb;
+						pool[st + 1] = 0;
+					}
+				}
+				t += ok;
+				if (ok < 8)
+					break;
+			}
+			j += t;
+			prev = pos + t;
 		}
 	}
 }

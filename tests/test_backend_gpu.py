@@ -29,6 +29,27 @@ def test_match_lists_equal_oracle(B, O, kind):
             assert np.array_equal(gp, op), (kind, n, dict_size)
 
 
+def test_match_lists_runs(B, O):
+    """Runs of one byte value: all their positions fall into one hash bucket (the bulk run path of k_bt);
+    runs of several values and lengths, separated by text, one reaching the end of the block."""
+    import numpy as np
+    parts = []
+    rng = np.random.default_rng(5)
+    for k, (val, ln) in enumerate([(0, 300000), (0xFF, 70), (0, 64), (0x41, 65), (0, 100001), (7, 66000)]):
+        parts.append(datagen.text_like(int(rng.integers(50, 5000)), seed=100 + k))
+        parts.append(bytes([val]) * ln)
+    data = b"".join(parts)
+    for blk in (data, data + b"x", bytes(200000), b"ab" * 150000):
+        oc, op = _lists_from_oracle(O, blk, 1 << 25, 64, 48)
+        gc, gp = B.lzma_match_lists(blk, per_pos=110)
+        assert np.array_equal(gc, oc)
+        assert np.array_equal(gp, op)
+        if O.ref_lzma() is not None:
+            rc_r, ref, _ = O.lzma_compress_ref(blk, level=7, dict_size=1 << 25, fb=64, threads=2)
+            rc_g, got, _ = B.lzma_compress(blk, level=7, dict_size=1 << 25, fb=64)
+            assert rc_g == rc_r and got == ref
+
+
 def test_match_lists_small_dict_window(B, O):
     # dictionary smaller than the block: exercises the delta >= cyclicBufferSize cut-off
     data = datagen.phrase_mix(400000, seed=9)
