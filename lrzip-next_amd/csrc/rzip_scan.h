@@ -40,7 +40,6 @@ struct ScanState {
 	int64_t hint_p, hint_op, hint_len;
 	// resolver diagnostics: batches, committed lanes, serial steps, first-stop reasons
 	// (complex, real match, conflict, no victim in reach, insert inside swept range)
-	int64_t dbg2[16]; // experiment counters, printed under LRZGPU_TRACE
 	int64_t dbg[16]; // [8..15]: shader-clock cycles per phase (refill, simulate, victims, conflict, apply, tail)
 };
 

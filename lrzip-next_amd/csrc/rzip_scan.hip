@@ -791,7 +791,6 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 	u64 sink = 0;
 	i64 miss_acc = 0; // tag_misses of committed batch lanes, per lane
 	i64 dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-	i64 dbg2[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 	u64 tclk = __builtin_amdgcn_s_memtime();
 	const bool prof = (batch_mode & 2) != 0; // per-phase cycle laps cost ~2 SMEM round trips each: opt-in
 	auto lap = [&](int slot) {
@@ -1073,8 +1072,6 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 			const int prev_cand = __shfl_up((int)tw_cand, 1);
 			bool tw = tw_cand && prev_cand == 0; // a third twin in a row takes the conflict path
 			bool seek_pred = false, tw_hit = false;
-			dbg2[6] += __popcll(__ballot(need_sim && tw_cand));
-			dbg2[7] += __popcll(__ballot(need_sim && tw));
 			// ---- A1: lookup walk to the first empty slot, 16 slots per step, branch-free masks ----
 			{
 				i64 idx = (i64)(T & R.hmask);
@@ -1245,8 +1242,6 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 			}
 			if (need_sim)
 				L.twin = tw && tw_hit && !L.complex_;
-			dbg2[8] += __popcll(__ballot(need_sim && tw));
-			dbg2[9] += __popcll(__ballot(need_sim && L.twin));
 			lap(14);
 			// ---- A3: displacement chain of the insert, level by level ----
 			{
@@ -1443,7 +1438,6 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 			if (tw_live && !stop && !(lane > 0 && p_ok && p_nw == 1 && p_slot == L.tw_slot && (p_dec != 0) == L.tw_dec)) {
 				stop = true;
 				why = 5; // re-simulated as the first lane of the next round
-				dbg2[10]++;
 			}
 		}
 		// conflicts: the EARLIEST lane whose write (insert, displacement or clean) lies inside my
@@ -1535,17 +1529,6 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		const int why_f = f < 64 ? __shfl(why, f) : 0;
 		if (f < wcount && why_f >= 3 && why_f <= 7)
 			dbg[why_f]++;
-		if (f < wcount && why_f == 5) {
-			const int fc = __shfl(first_conf, f);
-			const u64 tf = bcast64(w_tag, f), tc = bcast64(w_tag, fc & 63);
-			const i64 pf = (i64)bcast64((u64)w_pos, f), pc = (i64)bcast64((u64)w_pos, fc & 63);
-			dbg2[0] += tf == tc;
-			dbg2[1] += fc == f - 1;
-			dbg2[2] += (tf == tc) && (pf - pc == 1);
-			dbg2[3] += ((tf ^ tc) & R.hmask) == 0;
-			dbg2[4] += __shfl((int)L.nw, fc & 63) == 1 && __shfl((int)L.dec, fc & 63) == 0;
-			dbg2[5] += f;
-		}
 		const bool committed = lane < f && live;
 		if (f < 4 && f < wcount) {
 			if (++poor_rounds >= 8) {
@@ -1637,8 +1620,6 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		st->tag_misses = R.tag_misses;
 		for (int k = 0; k < 16; k++)
 			st->dbg[k] += dbg[k];
-		for (int k = 0; k < 16; k++)
-			st->dbg2[k] += dbg2[k];
 	}
 	// keep the prefetch loads observable
 	u64 any = sink;
@@ -2104,10 +2085,8 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 	res->crc = crc;
 	res->final_state = h;
 	if (getenv("LRZGPU_TRACE")) {
-		fprintf(stderr, "lrzgpu scan: batches %lld committed %lld  hash_count %lld  dbg2:", (long long)h.dbg[0], (long long)h.dbg[1], (long long)h.hash_count);
-		for (int k = 0; k < 16; k++)
-			fprintf(stderr, " %lld", (long long)h.dbg2[k]);
-		fprintf(stderr, "\n");
+		fprintf(stderr, "lrzgpu scan: rounds %lld committed %lld serial steps %lld  hash_count %lld\n", (long long)h.dbg[0], (long long)h.dbg[1],
+			(long long)h.dbg[2], (long long)h.hash_count);
 	}
 	*victim_round = h.victim_round;
 	{
