@@ -251,7 +251,7 @@ struct Pipeline {
 	size_t held_limit = 4;
 	bool closing = false;
 	double t_last_mf = 0, t_last_enc = 0;
-	double mf_busy = 0, d2h_busy = 0, blk_busy = 0;
+	double mf_busy = 0, d2h_busy = 0, blk_busy = 0, enc_busy = 0, enc_wait = 0;
 	std::vector<std::thread> threads;
 
 	void fail(int e)
@@ -308,6 +308,7 @@ struct Pipeline {
 	{
 		for (;;) {
 			Job *j = nullptr;
+			const double tw0 = now_s();
 			{
 				std::unique_lock<std::mutex> lk(mu);
 				cv_enc.wait(lk, [&] { return !enc_queue.empty() || closing || err; });
@@ -316,6 +317,7 @@ struct Pipeline {
 				j = enc_queue.front();
 				enc_queue.pop_front();
 			}
+			const double te0 = now_s();
 			if (!j->cancelled) {
 				LzmaParams p;
 				lzma_normalize(p, sz.level, sz.dict_size, 3, 0, 2, sz.level < 7 ? 32 : 64);
@@ -343,6 +345,8 @@ struct Pipeline {
 			{
 				std::lock_guard<std::mutex> lk(mu);
 				t_last_enc = now_s();
+				enc_busy += t_last_enc - te0;
+				enc_wait += te0 - tw0;
 			}
 			mark_finished(j, true);
 		}
@@ -1131,9 +1135,9 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 	out->insert(out->end(), digest, digest + 16);
 	memcpy(ctl->hash_resblock, digest, 16);
 	if (tracing())
-		fprintf(stderr, "lrzgpu driver: scan done %.2f  blocks queued %.2f  last finder %.2f  last encode %.2f  all blocks %.2f  md5 joined %.2f  assembled %.2f s (since start; last chunk); early blocks %lld, redone chunks %lld; worker sums: block copy+gate %.2f finder %.2f lists D2H %.2f s\n",
+		fprintf(stderr, "lrzgpu driver: scan done %.2f  blocks queued %.2f  last finder %.2f  last encode %.2f  all blocks %.2f  md5 joined %.2f  assembled %.2f s (since start; last chunk); early blocks %lld, redone chunks %lld; worker sums: block copy+gate %.2f finder %.2f lists D2H %.2f, encoders busy %.2f idle %.2f s\n",
 			t_scan - t0, t_enq - t0, P.t_last_mf - t0, P.t_last_enc - t0, t_blocks - t0, t_md5 - t0, now_s() - t0,
-			(long long)n_early, (long long)n_violations, P.blk_busy, P.mf_busy, P.d2h_busy);
+			(long long)n_early, (long long)n_violations, P.blk_busy, P.mf_busy, P.d2h_busy, P.enc_busy, P.enc_wait);
 	if (with_magic) {
 		uint8_t magic[21];
 		write_magic(magic, P.sz, in.n);

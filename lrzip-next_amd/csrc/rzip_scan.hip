@@ -1985,8 +1985,8 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 		// size the segment for ~2M candidates under the current mask
 		int mbits = __builtin_popcountll(min_mask);
 		int64_t seg = (int64_t)(2 << 20) << (mbits > 9 ? 9 : mbits);
-		if (seg < (16 << 20))
-			seg = 16 << 20;
+		if (seg < (4 << 20)) // small early segments: the back end gets its first blocks sooner
+			seg = 4 << 20;
 		if (seg > (int64_t)w->seg_cap - TILE)
 			seg = (int64_t)w->seg_cap - TILE;
 		int64_t seg_hi = seg_lo + seg;
