@@ -1469,20 +1469,28 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 		const bool reads = live && !L.complex_ && !L.match; // lanes that stop anyway need no conflict test
 		const uint32_t r_lo = L.lo & ~7u, r_hi = L.hi | 7u;
+		// a twin successor expects exactly one foreign write in its interval: its predecessor's insert
+		const uint32_t tw_h = tw_live && !stop ? ((L.tw_slot >> gsh) * 2654435761u) >> (32 - CF_BITS) : 0xFFFFFFFFu;
 		bool flagged = false;
 		if (reads) {
 			const uint32_t g1 = L.hi >> gsh;
-			for (uint32_t g = L.lo >> gsh; g <= g1; g += 4) {
+			uint32_t expect = tw_h != 0xFFFFFFFFu ? 1u : 0u; // not yet seen
+			for (uint32_t g = L.lo >> gsh; g <= g1; g += 2) {
 				uint32_t acc = 0;
 #pragma unroll
-				for (uint32_t u = 0; u < 4; u++) {
-					const uint32_t gg = g + u <= g1 ? g + u : g1;
+				for (uint32_t u = 0; u < 2; u++) {
+					const bool dup = u && g + u > g1; // second probe past the interval: skip
+					const uint32_t gg = dup ? g : g + u;
 					const uint32_t hb = (gg * 2654435761u) >> (32 - CF_BITS);
 					uint32_t cnt = (cf_bits[hb >> 1] >> (16 * (hb & 1))) & 0xFFFFu;
 #pragma unroll
 					for (int q = 0; q < 5; q++)
 						cnt -= wh[q] == hb;
-					acc |= cnt;
+					if (!dup && expect && hb == tw_h && cnt) {
+						cnt--;
+						expect = 0;
+					}
+					acc |= dup ? 0 : cnt;
 				}
 				if (acc)
 					flagged = true;
@@ -1490,6 +1498,7 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		}
 		int first_conf = 64;
 		{
+			const u64 tw_live_m = __ballot(tw_live);
 			u64 fm = __ballot(flagged);
 			int budget = 16;
 			while (fm) {
@@ -1500,8 +1509,8 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 						first_conf = 0;
 					break;
 				}
-				const uint32_t klo = __shfl(r_lo, k), khi = __shfl(r_hi, k);
-				const bool k_twin = __shfl((int)tw_live, k) != 0; // its predecessor's insert is already part of its simulation
+				const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)r_lo, k), khi = (uint32_t)__builtin_amdgcn_readlane((int)r_hi, k);
+				const bool k_twin = (tw_live_m >> k) & 1; // its predecessor's insert is already part of its simulation
 				bool hit = false;
 #pragma unroll
 				for (int q = 0; q < 5; q++)
