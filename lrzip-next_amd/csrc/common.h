@@ -16,9 +16,10 @@ inline hipError_t stream_wait(hipStream_t s)
 		ev = nullptr;
 		return hipStreamSynchronize(s);
 	}
-	hipError_t e = hipEventRecord(ev, s);
-	if (e != hipSuccess)
-		return e;
+	if (hipEventRecord(ev, s) != hipSuccess) { // e.g. the thread moved to another device since
+		(void)hipGetLastError();
+		return hipStreamSynchronize(s);
+	}
 	return hipEventSynchronize(ev);
 }
 int select_device(int device); // 0 or LRZGPU_E_*

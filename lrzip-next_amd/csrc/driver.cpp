@@ -138,6 +138,16 @@ struct HostPool {
 		static HostPool p;
 		return p;
 	}
+	static size_t idle_limit() // keep at most 1/8 of physical memory (and at most 48 GiB) parked
+	{
+		static const size_t lim = [] {
+			const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
+			size_t phys = pages > 0 && psz > 0 ? (size_t)pages * (size_t)psz : (size_t)64 << 30;
+			size_t l = phys / 8;
+			return l > ((size_t)48 << 30) ? (size_t)48 << 30 : l;
+		}();
+		return lim;
+	}
 	void *take(size_t bytes, size_t *cap)
 	{
 		{
@@ -166,7 +176,7 @@ struct HostPool {
 		if (!p)
 			return;
 		std::lock_guard<std::mutex> lk(mu);
-		if (idle.size() >= 96 || idle_bytes + cap > ((size_t)48 << 30)) {
+		if (idle.size() >= 96 || idle_bytes + cap > idle_limit()) {
 			free(p);
 			return;
 		}
