@@ -108,8 +108,10 @@ int lrzgpu_lz4_compress_default_size(const uint8_t *src, int src_size, int dst_c
 /* ---- LZMA backend -----------------------------------------------------------------------------
  * LzmaCompress() -- src/lzma/include/LzmaLib.h:95-112, same arguments and SRes codes
  * (0 OK, 2 MEM, 5 PARAM, 7 OUTPUT_EOF).  GPU match finder + host parser/range coder.
- * Levels 5..9 (btMode=1, numHashBytes=4); numThreads is accepted and ignored (the output of the
- * reference does not depend on it). */
+ * Levels 5..9: BT4 finder (btMode=1, numHashBytes=4, as the reference's MT finder returns it) + optimal
+ * parser; levels 1..4: HC5 finder (btMode=0, numHashBytes=5, LzFind.c:1431-1502) + GetOptimumFast
+ * (LzmaEnc.c:1970-2098).  numThreads is accepted and ignored (the output of the reference does not
+ * depend on it). */
 int lrzgpu_LzmaCompress(unsigned char *dest, size_t *destLen, const unsigned char *src, size_t srcLen,
 			unsigned char *outProps, size_t *outPropsSize, int level, unsigned dictSize,
 			int lc, int lp, int pb, int fb, int numThreads);
@@ -119,6 +121,10 @@ int lrzgpu_LzmaCompress(unsigned char *dest, size_t *destLen, const unsigned cha
  * position i; pairs = (len, dist-1) couples of position 0, 1, ... ; returns total entries or <0. */
 int64_t lrzgpu_lzma_match_lists(const uint8_t *src, size_t n, uint32_t dictSize, unsigned fb, unsigned cutValue,
 				uint8_t *counts, uint32_t *pairs, size_t pairs_cap, int device);
+/* Same for the hash-chain finder of levels 1..4: the lists Hc5_MatchFinder_GetMatches
+ * (src/lzma/C/LzFind.c:1431-1502) returns position by position. */
+int64_t lrzgpu_lzma_match_lists_hc5(const uint8_t *src, size_t n, uint32_t dictSize, unsigned fb, unsigned cutValue,
+				    uint8_t *counts, uint32_t *pairs, size_t pairs_cap, int device);
 
 /* The host half alone: parser + range coder fed with match lists (any producer). */
 int lrzgpu_lzma_encode_with_lists(unsigned char *dest, size_t *destLen, const unsigned char *src, size_t srcLen,

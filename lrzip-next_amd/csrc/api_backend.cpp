@@ -119,8 +119,8 @@ extern "C" int lrzgpu_lz4_compress_default_size(const uint8_t *src, int src_size
 
 // ---- LZMA: src/lzma/include/LzmaLib.h:95-112 --------------------------------------------------
 
-extern "C" int64_t lrzgpu_lzma_match_lists(const uint8_t *src, size_t n, uint32_t dictSize, unsigned fb, unsigned cutValue,
-					   uint8_t *counts, uint32_t *pairs, size_t pairs_cap, int device)
+static int64_t match_lists_impl(const uint8_t *src, size_t n, uint32_t dictSize, unsigned fb, unsigned cutValue,
+				uint8_t *counts, uint32_t *pairs, size_t pairs_cap, int device, bool hc5)
 {
 	int rc = select_device(device);
 	if (rc)
@@ -137,7 +137,7 @@ extern "C" int64_t lrzgpu_lzma_match_lists(const uint8_t *src, size_t n, uint32_
 	int64_t ret = LRZGPU_E_HIP;
 	unsigned long long total = 0;
 	if (hipMalloc(&d_src, n + 16) == hipSuccess && (n == 0 || hipMemcpy(d_src, src, n, hipMemcpyHostToDevice) == hipSuccess)) {
-		int r = mf_run_device(w, d_src, n, dictSize, fb, cutValue, 0, &total);
+		int r = mf_run_device(w, d_src, n, dictSize, fb, cutValue, 0, &total, false, hc5);
 		if (r == 0) {
 			if (total > pairs_cap)
 				ret = LRZGPU_E_NOMEM;
@@ -153,6 +153,18 @@ extern "C" int64_t lrzgpu_lzma_match_lists(const uint8_t *src, size_t n, uint32_
 	return ret;
 }
 
+extern "C" int64_t lrzgpu_lzma_match_lists(const uint8_t *src, size_t n, uint32_t dictSize, unsigned fb, unsigned cutValue,
+					   uint8_t *counts, uint32_t *pairs, size_t pairs_cap, int device)
+{
+	return match_lists_impl(src, n, dictSize, fb, cutValue, counts, pairs, pairs_cap, device, false);
+}
+
+extern "C" int64_t lrzgpu_lzma_match_lists_hc5(const uint8_t *src, size_t n, uint32_t dictSize, unsigned fb, unsigned cutValue,
+					       uint8_t *counts, uint32_t *pairs, size_t pairs_cap, int device)
+{
+	return match_lists_impl(src, n, dictSize, fb, cutValue, counts, pairs, pairs_cap, device, true);
+}
+
 extern "C" int lrzgpu_lzma_encode_with_lists(unsigned char *dest, size_t *destLen, const unsigned char *src, size_t srcLen,
 					     const uint8_t *counts, const uint32_t *pairs, int level, unsigned dictSize,
 					     int lc, int lp, int pb, int fb)
@@ -164,6 +176,7 @@ extern "C" int lrzgpu_lzma_encode_with_lists(unsigned char *dest, size_t *destLe
 	p.lp = lp;
 	p.pb = pb;
 	p.fb = fb;
+	p.fast = level >= 0 && level < 5; // algo 0
 	MatchLists ml;
 	ml.counts = counts;
 	ml.pairs = pairs;
@@ -189,8 +202,7 @@ int lzma_normalize(LzmaParams &p, int level, unsigned dictSize, int lc, int lp, 
 	p.fb = fb < 0 ? (level < 7 ? 32 : 64) : fb;
 	if (p.lc > 8 || p.lp > 4 || p.pb > 4)
 		return LZ_ERROR_PARAM;
-	if (level < 5)
-		return LZ_ERROR_PARAM; // algo=0 / HC5: outside this path
+	p.fast = level < 5; // algo 0: HC5 finder + GetOptimumFast (LzmaEnc.c:95-99)
 	return LZ_OK;
 }
 } // namespace lrzgpu
@@ -221,7 +233,7 @@ extern "C" int lrzgpu_LzmaCompress(unsigned char *dest, size_t *destLen, const u
 		} catch (...) {
 			return LZ_ERROR_MEM;
 		}
-		int64_t total = lrzgpu_lzma_match_lists(src, srcLen, p.dict_size, (unsigned)p.fb, p.cut(), counts.data(), pairs.data(), cap, dev);
+		int64_t total = match_lists_impl(src, srcLen, p.dict_size, (unsigned)p.fb, p.cut(), counts.data(), pairs.data(), cap, dev, p.fast);
 		if (total == LRZGPU_E_NOMEM) {
 			cap *= 4;
 			continue;

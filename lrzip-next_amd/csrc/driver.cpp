@@ -490,7 +490,7 @@ struct Pipeline {
 						cleanup();
 						return;
 					}
-					int r = mf_run_device(ws, d_blk, (size_t)n, lp.dict_size, (uint32_t)lp.fb, lp.cut(), s, &total, pack);
+					int r = mf_run_device(ws, d_blk, (size_t)n, lp.dict_size, (uint32_t)lp.fb, lp.cut(), s, &total, pack, lp.fast);
 					if (r == 0)
 						break;
 					if (r == -4 && attempt < 3) { // pool too small for this data: grow and retry
@@ -744,8 +744,6 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 	rc = compute_sizing(ctl, in.n, &P.sz);
 	if (rc)
 		return rc;
-	if (!P.sz.no_compress && P.sz.level < 5)
-		return LRZGPU_E_PARAM; // levels 1-4 use the HC5 fast path: outside this library
 	// host encoders: as asked, else the -p threads capped by the CPUs this process can really use
 	// (more runnable threads than the cgroup quota only buys throttling)
 	P.n_encoders = ctl->host_threads > 0 ? ctl->host_threads : (ctl->threads > 0 ? ctl->threads : 1);

@@ -175,6 +175,7 @@ struct Encoder {
 
 	// parameters
 	unsigned lc, lp, pb, fast_bytes;
+	bool fast_mode = false;
 	uint32_t dict_size;
 	unsigned pb_mask, dist_table_size;
 	uint32_t lp_mask;
@@ -1045,6 +1046,104 @@ struct Encoder {
 		return backward(cur);
 	}
 
+	// ---- fast parser (algo 0, levels 1-4): GetOptimumFast, LzmaEnc.c:1970-2098 -------------------
+	// Greedy with one position of look-ahead: take a repeat match if it is nearly as long as the main
+	// match (nearer is cheaper), shorten the main match while the next shorter one is >128x nearer, and
+	// emit a literal instead when the next position offers something clearly better.
+	static inline bool change_pair(uint32_t small_dist, uint32_t big_dist) { return (big_dist >> 7) > small_dist; }
+	unsigned optimum_fast()
+	{
+		unsigned main_len, npairs;
+		if (add_offset == 0)
+			main_len = read_matches(&npairs);
+		else {
+			main_len = longest_len;
+			npairs = num_pairs;
+		}
+		uint32_t navail = num_avail;
+		back_res = kMarkLit;
+		if (navail < 2)
+			return 1;
+		if (navail > kMatchLenMax)
+			navail = kMatchLenMax;
+		const uint8_t *d = cur_ptr() - 1;
+		unsigned rep_len = 0, rep_index = 0;
+		for (unsigned i = 0; i < kNumReps; i++) {
+			const uint8_t *d2 = d - reps[i];
+			if (d[0] != d2[0] || d[1] != d2[1])
+				continue;
+			unsigned len;
+			for (len = 2; len < navail && d[len] == d2[len]; len++) {
+			}
+			if (len >= fast_bytes) {
+				back_res = i;
+				move_pos(len - 1);
+				return len;
+			}
+			if (len > rep_len) {
+				rep_index = i;
+				rep_len = len;
+			}
+		}
+		if (main_len >= fast_bytes) {
+			back_res = matches[npairs - 1] + kNumReps;
+			move_pos(main_len - 1);
+			return main_len;
+		}
+		uint32_t main_dist = 0;
+		if (main_len >= 2) {
+			main_dist = matches[npairs - 1];
+			while (npairs > 2) {
+				if (main_len != matches[npairs - 4] + 1)
+					break;
+				const uint32_t dist2 = matches[npairs - 3];
+				if (!change_pair(dist2, main_dist))
+					break;
+				npairs -= 2;
+				main_len--;
+				main_dist = dist2;
+			}
+			if (main_len == 2 && main_dist >= 0x80)
+				main_len = 1;
+		}
+		if (rep_len >= 2)
+			if (rep_len + 1 >= main_len || (rep_len + 2 >= main_len && main_dist >= (1u << 9)) ||
+			    (rep_len + 3 >= main_len && main_dist >= (1u << 15))) {
+				back_res = rep_index;
+				move_pos(rep_len - 1);
+				return rep_len;
+			}
+		if (main_len < 2 || navail <= 2)
+			return 1;
+		{
+			const unsigned len1 = read_matches(&num_pairs);
+			longest_len = len1;
+			if (len1 >= 2) {
+				const uint32_t new_dist = matches[num_pairs - 1];
+				if ((len1 >= main_len && new_dist < main_dist) || (len1 == main_len + 1 && !change_pair(main_dist, new_dist)) ||
+				    (len1 > main_len + 1) || (len1 + 1 >= main_len && main_len >= 3 && change_pair(new_dist, main_dist)))
+					return 1;
+			}
+		}
+		d = cur_ptr() - 1;
+		for (unsigned i = 0; i < kNumReps; i++) {
+			const uint8_t *d2 = d - reps[i];
+			if (d[0] != d2[0] || d[1] != d2[1])
+				continue;
+			const unsigned limit = main_len - 1;
+			for (unsigned len = 2;; len++) {
+				if (len >= limit)
+					return 1;
+				if (d[len] != d2[len])
+					break;
+			}
+		}
+		back_res = main_dist + kNumReps;
+		if (main_len != 2)
+			move_pos(main_len - 2);
+		return main_len;
+	}
+
 	// ---- init / main loop -------------------------------------------
 	void init(const LzmaParams &prm)
 	{
@@ -1055,6 +1154,7 @@ struct Encoder {
 		if (fb < 5) fb = 5;
 		if (fb > kMatchLenMax) fb = kMatchLenMax;
 		fast_bytes = fb;
+		fast_mode = prm.fast;
 		dict_size = prm.dict_size;
 		unsigned i;
 		for (i = kEndPosModelIndex / 2; i < 32; i++)
@@ -1114,7 +1214,9 @@ struct Encoder {
 		if (avail_now() != 0)
 			for (;;) {
 				unsigned len;
-				if (opt_end == opt_cur)
+				if (fast_mode)
+					len = optimum_fast();
+				else if (opt_end == opt_cur)
 					len = optimum(now_pos);
 				else {
 					const Opt *o = &opt[opt_cur];
@@ -1217,12 +1319,12 @@ struct Encoder {
 				add_offset -= len;
 
 				if (add_offset == 0) {
-					if (match_price_count >= 64) {
+					if (!fast_mode && match_price_count >= 64) {
 						fill_align_prices();
 						fill_distance_prices();
 						update_len_prices(len_prices, len_probs);
 					}
-					if (rep_len_counter <= 0) {
+					if (!fast_mode && rep_len_counter <= 0) {
 						rep_len_counter = kRepLenCount;
 						update_len_prices(rep_len_prices, rep_len_probs);
 					}
@@ -1259,6 +1361,29 @@ uint32_t lzma_hash_mask(uint32_t dict_size, uint64_t expected_size)
 	return res[1] > res[0] ? res[0] : res[1];
 }
 
+// same for the 5-byte hash of the HC5 finder (levels 1-4): the low 18 bits are always set
+uint32_t lzma_hash_mask5(uint32_t dict_size, uint64_t expected_size)
+{
+	uint32_t res[2];
+	uint64_t in[2] = {dict_size, expected_size < dict_size ? expected_size : dict_size};
+	for (int k = 0; k < 2; k++) {
+		uint32_t hs = (uint32_t)in[k];
+		if (hs != 0)
+			hs--;
+		hs |= hs >> 1;
+		hs |= hs >> 2;
+		hs |= hs >> 4;
+		hs |= hs >> 8;
+		hs >>= 1;
+		if (hs >= (1u << 24))
+			hs >>= 1;
+		hs |= 0xFFFF;
+		hs |= (256u << 10) - 1; // kLzHash_CrcShift_2
+		res[k] = hs;
+	}
+	return res[1] > res[0] ? res[0] : res[1];
+}
+
 void lzma_write_props(const LzmaParams &prm, uint8_t props[5])
 {
 	uint32_t dict = prm.dict_size, v;
@@ -1286,7 +1411,7 @@ int lzma_encode_block(const LzmaParams &prm, const uint8_t *src, size_t n, const
 {
 	if (prm.lc > 8 || prm.lp > 4 || prm.pb > 4 || prm.lc < 0 || prm.lp < 0 || prm.pb < 0)
 		return LZ_ERROR_PARAM;
-	if (prm.level < 5) // fast parser + HC5 finder: outside this path (SURVEY 8f "next" #3)
+	if ((prm.level < 5) != prm.fast) // algo 0 <=> levels 1-4 here (LzmaEncProps_Normalize)
 		return LZ_ERROR_PARAM;
 	if (n >= 0xFFFFFFFFu)
 		return LZ_ERROR_PARAM;

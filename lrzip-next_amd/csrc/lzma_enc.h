@@ -30,7 +30,8 @@ struct LzmaParams {
 	uint32_t dict_size = 1u << 25;
 	int lc = 3, lp = 0, pb = 2;
 	int fb = 64;
-	uint32_t cut() const { return 16u + ((uint32_t)fb >> 1); } // btMode=1 (LzmaEnc.c:99)
+	bool fast = false; // algo 0 (levels 1-4): GetOptimumFast + the HC5 finder (LzmaEnc.c:95-99)
+	uint32_t cut() const { return (16u + ((uint32_t)fb >> 1)) >> (fast ? 1 : 0); } // mc, LzmaEnc.c:99
 };
 
 enum : int { LZ_OK = 0, LZ_ERROR_MEM = 2, LZ_ERROR_PARAM = 5, LZ_ERROR_OUTPUT_EOF = 7 };
@@ -46,5 +47,6 @@ void lzma_write_props(const LzmaParams &prm, uint8_t props[5]);
 
 // Hash mask the reference derives for a block (LzFind.c:347-373, 432-442).
 uint32_t lzma_hash_mask(uint32_t dict_size, uint64_t expected_size);
+uint32_t lzma_hash_mask5(uint32_t dict_size, uint64_t expected_size); // HC5 finder (levels 1-4)
 
 } // namespace lrzgpu

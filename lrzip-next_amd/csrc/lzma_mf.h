@@ -32,6 +32,6 @@ int mf_workspace_create(MfWorkspace **out, size_t max_n, double pool_per_pos);
 void mf_workspace_destroy(MfWorkspace *w);
 // pack: pool_out holds one u32 per pair (len << 25 | dist-1), total_entries/2 words; needs dict <= 32 MiB
 int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict, uint32_t fb, uint32_t cut,
-		  hipStream_t s, unsigned long long *total_entries, bool pack = false);
+		  hipStream_t s, unsigned long long *total_entries, bool pack = false, bool hc5 = false);
 
 } // namespace lrzgpu

@@ -48,7 +48,7 @@ __device__ __forceinline__ uint32_t crc_byte(uint32_t b)
 	return r;
 }
 
-// keys for the three hash tables; which: 4 = main hash (GetHeads4 / GetHeads4b), 3 = h3, 2 = h2
+// keys for the hash tables; which: 4 = BT4 main hash (GetHeads4 / GetHeads4b), 5 = HC5 main hash, 3 = h3, 2 = h2
 template <int WHICH>
 __global__ void __launch_bounds__(256) k_keys(const uint8_t *__restrict__ src, uint32_t n4, uint32_t mask, int big,
 					      uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
@@ -64,6 +64,8 @@ __global__ void __launch_bounds__(256) k_keys(const uint8_t *__restrict__ src, u
 				k = (c0 & mask) ^ (b1 | (b2 << 8) | (b3 << 16));
 			else
 				k = (c0 & mask) ^ ((crc_byte(b3) << 5) & mask) ^ (b1 | (b2 << 8));
+		} else if (WHICH == 5) { // HASH5_CALC, LzFind.c:56-63 (positions with >= 5 bytes only)
+			k = ((c0 ^ b1) ^ (b2 << 8) ^ (crc_byte(b3) << 5) ^ (crc_byte(src[i + 4]) << 10)) & mask;
 		} else if (WHICH == 3) {
 			k = ((c0 ^ b1) ^ (b2 << 8)) & 0xFFFF;
 		} else {
@@ -353,6 +355,109 @@ __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint
 	}
 }
 
+// ---------------------------------------------------------------------------------------------
+// HC5: the hash-chain finder of LZMA levels 1-4 (algo 0: btMode 0, 5 hash bytes, single-threaded in
+// the reference: Hc5_MatchFinder_GetMatches / _Skip, LzFind.c:1431-1502, 1619-1649, and
+// Hc_GetMatchesSpec, LzFind.c:880-958).  GetMatches and Skip update the three hash tables and the
+// chain identically at every position that still has 5 bytes, so the chain link of a position is
+// simply "the previous position with the same 5-byte hash" and its h2/h3 candidates "the previous
+// position with the same 10/16-bit hash": all of them come from stable sorts, and, unlike the binary
+// tree, nothing a position does changes what a later one sees.  One thread per position.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_hc5(const uint8_t *__restrict__ src, uint32_t n, const uint32_t *__restrict__ prev2,
+					     const uint32_t *__restrict__ prev3, const uint32_t *__restrict__ prev5, uint32_t dict,
+					     uint32_t fb, uint32_t cut, uint8_t *__restrict__ counts, uint64_t *__restrict__ tmp_start,
+					     uint32_t *__restrict__ pool, unsigned long long *__restrict__ cursor,
+					     unsigned long long pool_cap, int *__restrict__ err)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	const uint32_t avail = n - i;
+	const uint32_t len_limit = avail < fb ? avail : fb;
+	if (len_limit < 5) // GET_MATCHES_HEADER(5): the position is skipped, no table is touched
+		return;
+	const uint32_t pos = i + 1;
+	const uint8_t *cur = src + i;
+	const uint32_t cbs = dict + 1;
+	const uint32_t mmm = pos < cbs ? pos : cbs; // SET_mmm
+	uint32_t d2 = pos - prev2[i], d3 = pos - prev3[i];
+	uint32_t rec[2 * 2 + 2 * 32];
+	uint32_t nrec = 0;
+	uint32_t max_len = 4;
+	bool chain = true;
+	{
+		bool have = false; // a pair whose length is still to be written sits at rec[nrec-2]
+		if (d2 < mmm && cur[-(int64_t)d2] == cur[0]) {
+			rec[nrec++] = 2;
+			rec[nrec++] = d2 - 1;
+			if (cur[2 - (int64_t)d2] == cur[2]) {
+				have = true;
+			} else if (d3 < mmm && cur[-(int64_t)d3] == cur[0]) {
+				rec[nrec++] = 0;
+				rec[nrec++] = d3 - 1;
+				d2 = d3;
+				have = true;
+			}
+		} else if (d3 < mmm && cur[-(int64_t)d3] == cur[0]) {
+			rec[nrec++] = 0;
+			rec[nrec++] = d3 - 1;
+			d2 = d3;
+			have = true;
+		}
+		if (have) {
+			rec[nrec - 2] = 3;
+			if (cur[3 - (int64_t)d2] == cur[3]) {
+				uint32_t l = max_len; // UPDATE_maxLen: from byte 4 on
+				while (l != len_limit && cur[l - (int64_t)d2] == cur[l])
+					l++;
+				max_len = l;
+				rec[nrec - 2] = max_len;
+				if (max_len == len_limit)
+					chain = false;
+			}
+		}
+	}
+	if (chain) {
+		uint32_t cm = prev5[i], cv = cut;
+		do {
+			if (cm == 0)
+				break;
+			const uint32_t delta = pos - cm;
+			if (delta >= cbs)
+				break;
+			const uint32_t next = prev5[cm - 1]; // the chain link that position stored
+			const uint8_t *pb = cur - delta;
+			if (cur[max_len] == pb[max_len]) {
+				uint32_t len = 0;
+				while (len != len_limit && cur[len] == pb[len])
+					len++;
+				if (len == len_limit) {
+					rec[nrec++] = len_limit;
+					rec[nrec++] = delta - 1;
+					break;
+				}
+				if (max_len < len) {
+					max_len = len;
+					rec[nrec++] = len;
+					rec[nrec++] = delta - 1;
+				}
+			}
+			cm = next;
+		} while (--cv);
+	}
+	counts[i] = (uint8_t)nrec;
+	if (nrec) {
+		const unsigned long long st = atomicAdd(cursor, (unsigned long long)nrec);
+		tmp_start[i] = st;
+		if (st + nrec > pool_cap)
+			*err = 1;
+		else
+			for (uint32_t k = 0; k < nrec; k++)
+				pool[st + k] = rec[k];
+	}
+}
+
 struct CountToU64 {
 	__host__ __device__ unsigned long long operator()(const uint8_t &c) const { return (unsigned long long)c; }
 };
@@ -460,7 +565,7 @@ static inline int grid_for(size_t n, int block) // ~8 blocks per CU, grid-stride
 // Runs the finder on d_src[0..n) (device). Results stay on the device in w->counts / w->pool_out;
 // *total_entries receives the number of u32 entries.
 int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict, uint32_t fb, uint32_t cut,
-		  hipStream_t s, unsigned long long *total_entries, bool pack)
+		  hipStream_t s, unsigned long long *total_entries, bool pack, bool hc5)
 {
 	if (pack && (dict > (1u << 25) || fb > 127))
 		return -3;
@@ -479,7 +584,34 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 	if (n == 0)
 		return 0;
 	HIPCHK(hipMemsetAsync(w->counts, 0, n, s));
-	if (n >= 4) {
+	if (hc5) {
+		if (cut > 32)
+			return -3;
+		if (n >= 5) {
+			const uint32_t n5 = (uint32_t)(n - 4);
+			const uint32_t mask = lzma_hash_mask5(dict, n);
+			const int bits = 32 - __builtin_clz(mask);
+			size_t tb;
+			const int g = grid_for(n5, 256);
+			uint32_t *prev5 = w->son; // the tree array is free in this mode
+			hipLaunchKernelGGL(k_keys<2>, dim3(g), dim3(256), 0, s, d_src, n5, mask, 0, w->key_a, w->val_a);
+			tb = w->cub_bytes;
+			HIPCHK(hipcub::DeviceRadixSort::SortPairs(w->cub_tmp, tb, w->key_a, w->key_b, w->val_a, w->val_b, (int)n5, 0, 10, s));
+			hipLaunchKernelGGL(k_link_prev, dim3(g), dim3(256), 0, s, w->key_b, w->val_b, n5, w->prev2);
+			hipLaunchKernelGGL(k_keys<3>, dim3(g), dim3(256), 0, s, d_src, n5, mask, 0, w->key_a, w->val_a);
+			tb = w->cub_bytes;
+			HIPCHK(hipcub::DeviceRadixSort::SortPairs(w->cub_tmp, tb, w->key_a, w->key_b, w->val_a, w->val_b, (int)n5, 0, 16, s));
+			hipLaunchKernelGGL(k_link_prev, dim3(g), dim3(256), 0, s, w->key_b, w->val_b, n5, w->prev3);
+			hipLaunchKernelGGL(k_keys<5>, dim3(g), dim3(256), 0, s, d_src, n5, mask, 0, w->key_a, w->val_a);
+			tb = w->cub_bytes;
+			HIPCHK(hipcub::DeviceRadixSort::SortPairs(w->cub_tmp, tb, w->key_a, w->key_b, w->val_a, w->val_b, (int)n5, 0, bits, s));
+			hipLaunchKernelGGL(k_link_prev, dim3(g), dim3(256), 0, s, w->key_b, w->val_b, n5, prev5);
+			t_bt = new EventTimer(s);
+			hipLaunchKernelGGL(k_hc5, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_src, (uint32_t)n, w->prev2, w->prev3, prev5, dict, fb,
+					   cut, w->counts, w->tmp_start, w->pool_tmp, d_cursor, w->pool_cap, d_err);
+			t_bt->stop();
+		}
+	} else if (n >= 4) {
 		const uint32_t n4 = (uint32_t)(n - 3);
 		const uint32_t mask = lzma_hash_mask(dict, n);
 		const int big = mask >= 0xFFFFFF;

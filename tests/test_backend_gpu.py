@@ -66,7 +66,8 @@ def test_lzma_compress_equals_reference(B, O, kind):
         pytest.skip("oracle/_ref/liblzma_ref.so not present")
     for n in [0, 1, 5, 100, 5000, 70000, 1200000]:
         data = datagen.KINDS[kind](n, seed=n % 89 + 3)
-        for level, dict_size, fb in ((7, 1 << 25, 64), (5, 1 << 24, 32), (9, 1 << 27, 64)):
+        for level, dict_size, fb in ((7, 1 << 25, 64), (5, 1 << 24, 32), (9, 1 << 27, 64),
+                                     (1, 1 << 18, 32), (2, 1 << 20, 32), (3, 1 << 22, 32), (4, 1 << 23, 32)):
             rc_r, ref, props_r = O.lzma_compress_ref(data, level=level, dict_size=dict_size, fb=fb, threads=2)
             rc_g, got, props_g = B.lzma_compress(data, level=level, dict_size=dict_size, fb=fb)
             assert rc_g == rc_r and props_g == props_r, (kind, n, level)

@@ -44,6 +44,14 @@ def test_levels_and_threads(B, O):
     _both(B, O, data, level=7, threads=16, processors=16)
 
 
+@pytest.mark.parametrize("level", [1, 2, 3, 4])
+def test_fast_levels(B, O, level):
+    """-L1..4: LZMA algo 0 (HC5 hash-chain finder on the GPU + GetOptimumFast on the host), smaller
+    dictionaries and rzip tables."""
+    for kind, n in (("text", 3 * 1048576 + 5), ("longrange", 6 * 1048576), ("phrases", 2 * 1048576 + 77), ("zeros", 300000)):
+        _both(B, O, datagen.KINDS[kind](n, seed=30 + level), level=level, threads=2, processors=8)
+
+
 def test_no_compress_mode(B, O):
     _both(B, O, datagen.long_range(4 * 1048576 + 9, seed=13), no_compress=True, threads=1)
 

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("kind", ["text", "longrange", "random", "zeros", "phrases", "few"])
-@pytest.mark.parametrize("level", [5, 7, 9])
+@pytest.mark.parametrize("level", [2, 5, 7, 9])
 def test_roundtrip_kinds(B, kind, level):
     data = datagen.KINDS[kind](5 * 1048576 + 123, seed=level)
     img, _ = B.compress_buffer(data, level=level, threads=4, processors=8, ramsize=RAM, host_threads=8)
