@@ -114,6 +114,21 @@ def lzma_match_lists(data: bytes, dict_size=1 << 25, fb=64, cut=48, device=0, pe
     return counts[:n], pairs[:total]
 
 
+def lzma_match_lists_hc5(data: bytes, dict_size=1 << 22, fb=32, cut=16, device=0, per_pos=40):
+    import numpy as np
+    n = len(data)
+    counts = np.zeros(max(n, 1), dtype=np.uint8)
+    cap = n * per_pos + 4096
+    pairs = np.zeros(cap, dtype=np.uint32)
+    f = lib().lrzgpu_lzma_match_lists_hc5
+    f.argtypes = lib().lrzgpu_lzma_match_lists.argtypes
+    f.restype = C.c_int64
+    total = f(data, n, dict_size, fb, cut, counts.ctypes.data, pairs.ctypes.data, cap, device)
+    if total < 0:
+        raise RuntimeError("lrzgpu_lzma_match_lists_hc5 rc=%d" % total)
+    return counts[:n], pairs[:total]
+
+
 def lzma_encode_with_lists(data: bytes, counts, pairs, level=7, dict_size=1 << 25, fb=64, lc=3, lp=0, pb=2, cap=None):
     import numpy as np
     n = len(data)

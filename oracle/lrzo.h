@@ -96,6 +96,11 @@ i64 lrzo_lzma_mf_bt4(const uchar *src, size_t n, uint32_t dict_size, unsigned fb
 		     uint64_t *offsets /* n+1 */, uint32_t *pairs, size_t pairs_cap);
 /* hash mask the reference derives (LzFind.c:347-373,432-442) and bigHash flag */
 uint32_t lrzo_lzma_hash_mask(uint32_t dict_size, uint64_t expected_size);
+/* HC5 (levels 1-4, single-threaded hash chains, numHashBytes=5): the lists
+ * Hc5_MatchFinder_GetMatches (reference LzFind.c:1431-1502) returns, same layout as above. */
+i64 lrzo_lzma_mf_hc5(const uchar *src, size_t n, uint32_t dict_size, unsigned fb, unsigned cut,
+		     uint64_t *offsets /* n+1 */, uint32_t *pairs, size_t pairs_cap);
+uint32_t lrzo_lzma_hash_mask5(uint32_t dict_size, uint64_t expected_size);
 
 /* ---- container / whole-file driver --------------------------------- */
 typedef struct {

@@ -69,6 +69,9 @@ def lib():
         L.lrzo_lzma_mf_bt4.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint, C.c_uint,
                                        C.c_void_p, C.c_void_p, C.c_size_t]
         L.lrzo_lzma_mf_bt4.restype = C.c_int64
+        L.lrzo_lzma_mf_hc5.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint, C.c_uint,
+                                       C.c_void_p, C.c_void_p, C.c_size_t]
+        L.lrzo_lzma_mf_hc5.restype = C.c_int64
         L.lrzo_lzma_hash_mask.argtypes = [C.c_uint32, C.c_uint64]
         L.lrzo_lzma_hash_mask.restype = C.c_uint32
         L.lrzo_params_default.argtypes = [C.POINTER(Params)]
@@ -193,6 +196,19 @@ def compress_buffer(data: bytes, **kw):
     res = C.string_at(out, olen.value)
     C.CDLL(None).free(out)
     return res, fs
+
+
+def mf_hc5(data: bytes, dict_size=1 << 22, fb=32, cut=16):
+    """Per-position match lists of the HC5 finder (levels 1-4) -> (offsets u64[n+1], pairs u32[])."""
+    import numpy as np
+    n = len(data)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    total = lib().lrzo_lzma_mf_hc5(data, n, dict_size, fb, cut, offs.ctypes.data, None, 0)
+    if total < 0:
+        raise RuntimeError("hc5 oracle failed %d" % total)
+    pairs = np.zeros(max(total, 1), dtype=np.uint32)
+    lib().lrzo_lzma_mf_hc5(data, n, dict_size, fb, cut, offs.ctypes.data, pairs.ctypes.data, int(total))
+    return offs, pairs[:total]
 
 
 def mf_bt4(data: bytes, dict_size=1 << 25, fb=64, cut=48):

@@ -29,6 +29,18 @@ def test_match_lists_equal_oracle(B, O, kind):
             assert np.array_equal(gp, op), (kind, n, dict_size)
 
 
+@pytest.mark.parametrize("kind", ["text", "random", "few", "phrases", "sparse", "zeros"])
+def test_hc5_match_lists_equal_oracle(B, O, kind):
+    """Levels 1-4: the GPU hash-chain finder against the serial restatement of Hc5_MatchFinder_GetMatches."""
+    for n in SIZES_SMALL + [900000]:
+        data = datagen.KINDS[kind](n, seed=n % 83 + 2)
+        for dict_size in (1 << 18, 1 << 22):
+            offs, op = O.mf_hc5(data, dict_size=dict_size, fb=32, cut=16)
+            gc, gp = B.lzma_match_lists_hc5(data, dict_size=dict_size, fb=32, cut=16)
+            assert np.array_equal(gc, np.diff(offs).astype(np.uint8)), (kind, n, dict_size)
+            assert np.array_equal(gp, op), (kind, n, dict_size)
+
+
 def test_match_lists_runs(B, O):
     """Runs of one byte value: all their positions fall into one hash bucket (the bulk run path of k_bt);
     runs of several values and lengths, separated by text, one reaching the end of the block."""

@@ -98,7 +98,10 @@ def test_ref_lzma_fixtures_and_mf_oracle(O, B, case):
     if O.ref_lzma() is not None:
         rc, comp, props = O.lzma_compress_ref(data, level=case["level"], dict_size=case["dict"], fb=case["fb"])
         assert rc == case["rc"] and sha(comp) == case["sha256"] and props.hex() == case["props"]
-    offs, pairs = O.mf_bt4(data, dict_size=case["dict"], fb=case["fb"], cut=16 + case["fb"] // 2)
+    if case["level"] < 5:  # algo 0: hash chains, cut value halved (LzmaEnc.c:95-99)
+        offs, pairs = O.mf_hc5(data, dict_size=case["dict"], fb=case["fb"], cut=(16 + case["fb"] // 2) >> 1)
+    else:
+        offs, pairs = O.mf_bt4(data, dict_size=case["dict"], fb=case["fb"], cut=16 + case["fb"] // 2)
     counts = np.diff(offs).astype(np.uint8)
     rc, mine = B.lzma_encode_with_lists(data, counts, pairs, level=case["level"], dict_size=case["dict"], fb=case["fb"])
     assert rc == case["rc"] and len(mine) == case["size"] and sha(mine) == case["sha256"]
