@@ -23,6 +23,7 @@ extern "C" {
 #define LRZGPU_E_HIP (-103)
 #define LRZGPU_E_IO (-104)
 #define LRZGPU_E_INTERNAL (-105)
+#define LRZGPU_E_FORMAT (-106) /* not a .lrz this library can read, or a failed CRC/MD5/size check */
 
 /* rzip_control.flags bits this path reads (src/include/lrzip_private.h:257-370) */
 #define LRZGPU_FLAG_NO_COMPRESS (1u << 5)  /* FLAG_NO_COMPRESS, -n */
@@ -166,6 +167,14 @@ typedef struct lrzgpu_profile {
 } lrzgpu_profile;
 void lrzgpu_profile_reset(void);
 void lrzgpu_profile_get(lrzgpu_profile *out);
+
+/* ---- round-trip verifier ----------------------------------------------------------------------
+ * The read side of the same subset of the format (lrzip-next 0.14 magic, stored + LZMA blocks, MD5 or
+ * no hash, no encryption/filters): container walk (src/stream.c:1352-1506, 2023-2195), LzmaDec,
+ * runzip token replay (src/runzip.c:146-260), chunk CRC and MD5 checks (src/runzip.c:352-440).
+ * Host code -- decompression is outside the accelerated path; it lets a GPU box check
+ * decode(compress(x)) == x through this ABI.  *out is malloc()ed. */
+int lrzgpu_decompress_buffer(const uint8_t *lrz, int64_t n, uint8_t **out, int64_t *out_len, int host_threads);
 
 /* ---- misc ------------------------------------------------------------------------------------- */
 int lrzgpu_device_count(void);

@@ -237,6 +237,22 @@ def compress_device(ptr: int, n: int, ctl=None, copy=True, **kw):
     return _take(out, olen), c
 
 
+def decompress_buffer(img, host_threads=0):
+    """The library's own round-trip verifier: .lrz image (bytes or LrzBuffer) -> original bytes."""
+    if isinstance(img, LrzBuffer):
+        ptr, n = C.cast(img._ptr, C.c_void_p), img.size
+    else:
+        ptr, n = C.cast(C.c_char_p(img), C.c_void_p), len(img)
+    out = C.POINTER(C.c_ubyte)()
+    olen = C.c_int64()
+    f = lib().lrzgpu_decompress_buffer
+    f.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.POINTER(C.c_ubyte)), C.POINTER(C.c_int64), C.c_int]
+    rc = f(ptr, n, C.byref(out), C.byref(olen), host_threads)
+    if rc != 0:
+        raise RuntimeError("lrzgpu_decompress_buffer rc=%d" % rc)
+    return _take(out, olen)
+
+
 def plan(st_size, **kw):
     c = make_control(**kw)
     chunk = C.c_int64()

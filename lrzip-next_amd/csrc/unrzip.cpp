@@ -1,0 +1,267 @@
+// unrzip.cpp -- the read side of the path as an in-library round-trip verifier (SURVEY 8f "next" #1):
+// .lrz container walk (reference src/stream.c:1352-1506 open_stream_in, 2023-2195 fill_buffer),
+// per-block LZMA decode (lzma_dec.cpp), rzip token replay (src/runzip.c:146-260 unzip_literal /
+// unzip_match), chunk CRC-32 and MD5 trailer checks (src/runzip.c:352-440).  Host code: decompression
+// is outside the accelerated path; this exists so that a GPU box can check decode(compress(x)) == x
+// through the C ABI without the reference.  Subset: what lrzgpu_compress_* writes (lrzip-next 0.14
+// magic, no encryption/filters, stored and LZMA blocks, MD5 or no hash).
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <future>
+#include <thread>
+#include <vector>
+
+#include "../../include/lrzgpu.h"
+#include "lzma_dec.h"
+#include "md5.h"
+
+using namespace lrzgpu;
+
+namespace {
+
+struct Block {
+	int c_type;
+	size_t off, c_len, u_len;
+};
+
+// CRC-32/IEEE, slice-by-8 (the chunk trailer of src/rzip.c:741-761)
+uint32_t crc32_host(uint32_t crc, const uint8_t *p, size_t n)
+{
+	static uint32_t T[8][256];
+	static std::atomic<bool> ready{false};
+	if (!ready.load()) {
+		for (uint32_t i = 0; i < 256; i++) {
+			uint32_t r = i;
+			for (int j = 0; j < 8; j++)
+				r = (r >> 1) ^ (0xEDB88320u & (0u - (r & 1)));
+			T[0][i] = r;
+		}
+		for (uint32_t i = 0; i < 256; i++)
+			for (int k = 1; k < 8; k++)
+				T[k][i] = (T[k - 1][i] >> 8) ^ T[0][T[k - 1][i] & 0xFF];
+		ready.store(true);
+	}
+	crc = ~crc;
+	while (n >= 8) {
+		uint32_t a, b;
+		memcpy(&a, p, 4);
+		memcpy(&b, p + 4, 4);
+		a ^= crc;
+		crc = T[7][a & 0xFF] ^ T[6][(a >> 8) & 0xFF] ^ T[5][(a >> 16) & 0xFF] ^ T[4][a >> 24] ^ T[3][b & 0xFF] ^
+		      T[2][(b >> 8) & 0xFF] ^ T[1][(b >> 16) & 0xFF] ^ T[0][b >> 24];
+		p += 8;
+		n -= 8;
+	}
+	while (n--)
+		crc = (crc >> 8) ^ T[0][(crc ^ *p++) & 0xFF];
+	return ~crc;
+}
+
+inline uint64_t val(const uint8_t *p, int n)
+{
+	uint64_t v = 0;
+	for (int i = 0; i < n && i < 8; i++)
+		v |= (uint64_t)p[i] << (8 * i);
+	return v;
+}
+
+// one stream of a chunk -> its bytes; blocks are decoded by `nthreads` workers
+int stream_bytes(const uint8_t *img, const std::vector<Block> &blocks, unsigned lc, unsigned lp, unsigned pb, int nthreads,
+		 std::vector<uint8_t> *out)
+{
+	size_t total = 0;
+	std::vector<size_t> at(blocks.size());
+	for (size_t i = 0; i < blocks.size(); i++) {
+		at[i] = total;
+		total += blocks[i].u_len;
+	}
+	out->resize(total);
+	std::atomic<size_t> next{0};
+	std::atomic<int> err{0};
+	auto work = [&] {
+		for (;;) {
+			const size_t i = next.fetch_add(1);
+			if (i >= blocks.size() || err.load())
+				return;
+			const Block &b = blocks[i];
+			if (b.c_type == 3) {
+				if (b.c_len != b.u_len)
+					err = LRZGPU_E_FORMAT;
+				else
+					memcpy(out->data() + at[i], img + b.off, b.c_len);
+			} else if (b.c_type == 6) {
+				if (lzma_decode_block(img + b.off, b.c_len, out->data() + at[i], b.u_len, lc, lp, pb) != 0)
+					err = LRZGPU_E_FORMAT;
+			} else
+				err = LRZGPU_E_PARAM; // other back ends are outside this library
+		}
+	};
+	std::vector<std::thread> th;
+	const int nt = nthreads < 1 ? 1 : nthreads > (int)blocks.size() ? (int)(blocks.size() ? blocks.size() : 1) : nthreads;
+	for (int t = 1; t < nt; t++)
+		th.emplace_back(work);
+	work();
+	for (auto &t : th)
+		t.join();
+	return err.load();
+}
+
+} // namespace
+
+extern "C" int lrzgpu_decompress_buffer(const uint8_t *img, int64_t n, uint8_t **out, int64_t *out_len, int host_threads)
+{
+	if (!img || !out || !out_len || n < 21 + 2)
+		return LRZGPU_E_PARAM;
+	if (memcmp(img, "LRZI", 4) != 0 || img[4] != 0 || img[5] != 14)
+		return LRZGPU_E_FORMAT;
+	if (img[15] || img[16]) // encryption salt / filters: not written by this library
+		return LRZGPU_E_PARAM;
+	const uint64_t st_size = val(img + 6, 8);
+	const bool md5 = img[14] == 1;
+	if (img[14] > 1)
+		return LRZGPU_E_PARAM; // other hashes
+	const unsigned lc = 3, lp = 0, pb = 2; // LZMA_LC/LP/PB of src/stream.c:450-456
+	size_t pos = 21 + img[20];
+	uint8_t *dst = (uint8_t *)malloc(st_size ? st_size : 1);
+	if (!dst)
+		return LRZGPU_E_NOMEM;
+	if (host_threads <= 0)
+		host_threads = (int)std::thread::hardware_concurrency();
+	uint64_t at = 0;
+	int rc = 0;
+	for (;;) {
+		if (pos + 2 > (size_t)n) {
+			rc = LRZGPU_E_FORMAT;
+			break;
+		}
+		const int cb = img[pos], eof = img[pos + 1];
+		if (cb < 1 || cb > 8 || pos + 2 + (size_t)cb + 2 * (1 + 3 * (size_t)cb) > (size_t)n) {
+			rc = LRZGPU_E_FORMAT;
+			break;
+		}
+		const size_t base = pos + 2 + (size_t)cb, hlen = 1 + 3 * (size_t)cb;
+		size_t end = base + 2 * hlen;
+		std::vector<Block> blocks[2];
+		for (int s = 0; s < 2 && !rc; s++) {
+			size_t h = base + (size_t)s * hlen;
+			for (;;) {
+				if (h + hlen > (size_t)n) {
+					rc = LRZGPU_E_FORMAT;
+					break;
+				}
+				Block b;
+				b.c_type = img[h];
+				b.c_len = (size_t)val(img + h + 1, cb);
+				b.u_len = (size_t)val(img + h + 1 + cb, cb);
+				const size_t nxt = (size_t)val(img + h + 1 + 2 * cb, cb);
+				b.off = h + hlen;
+				if (b.c_len) {
+					if (b.off + b.c_len > (size_t)n) {
+						rc = LRZGPU_E_FORMAT;
+						break;
+					}
+					blocks[s].push_back(b);
+					if (b.off + b.c_len > end)
+						end = b.off + b.c_len;
+				} else if (h + hlen > end)
+					end = h + hlen;
+				if (!nxt)
+					break;
+				if (base + nxt <= h) { // chains only run forward
+					rc = LRZGPU_E_FORMAT;
+					break;
+				}
+				h = base + nxt;
+			}
+		}
+		if (rc)
+			break;
+		std::vector<uint8_t> s0, s1;
+		if ((rc = stream_bytes(img, blocks[0], lc, lp, pb, host_threads, &s0)) != 0 ||
+		    (rc = stream_bytes(img, blocks[1], lc, lp, pb, host_threads, &s1)) != 0)
+			break;
+		// token replay
+		size_t i = 0, lit = 0;
+		const uint64_t chunk0 = at;
+		bool done = false;
+		while (!done) {
+			if (i + 3 > s0.size()) {
+				rc = LRZGPU_E_FORMAT;
+				break;
+			}
+			const int t = s0[i];
+			const size_t ln = s0[i + 1] | ((size_t)s0[i + 2] << 8);
+			i += 3;
+			if (t == 0) {
+				if (ln == 0) {
+					done = true;
+					break;
+				}
+				if (lit + ln > s1.size() || at + ln > st_size) {
+					rc = LRZGPU_E_FORMAT;
+					break;
+				}
+				memcpy(dst + at, s1.data() + lit, ln);
+				lit += ln;
+				at += ln;
+			} else {
+				if (i + (size_t)cb > s0.size()) {
+					rc = LRZGPU_E_FORMAT;
+					break;
+				}
+				const uint64_t ofs = val(s0.data() + i, cb);
+				i += (size_t)cb;
+				if (ofs == 0 || ofs > at - chunk0 || at + ln > st_size) { // matches stay inside their chunk
+					rc = LRZGPU_E_FORMAT;
+					break;
+				}
+				const uint8_t *src = dst + at - ofs;
+				if (ofs >= ln)
+					memcpy(dst + at, src, ln);
+				else
+					for (size_t k = 0; k < ln; k++)
+						dst[at + k] = src[k];
+				at += ln;
+			}
+		}
+		if (rc)
+			break;
+		if (i + 4 != s0.size() || lit != s1.size()) {
+			rc = LRZGPU_E_FORMAT;
+			break;
+		}
+		const uint32_t want = ((uint32_t)s0[i] << 24) | ((uint32_t)s0[i + 1] << 16) | ((uint32_t)s0[i + 2] << 8) | s0[i + 3];
+		const uint32_t crc = crc32_host(0, dst + chunk0, (size_t)(at - chunk0));
+		if (crc != want) {
+			rc = LRZGPU_E_FORMAT;
+			break;
+		}
+		pos = end;
+		if (eof)
+			break;
+	}
+	if (!rc && at != st_size)
+		rc = LRZGPU_E_FORMAT;
+	if (!rc && md5) {
+		uint8_t dg[16];
+		if (pos + 16 != (size_t)n)
+			rc = LRZGPU_E_FORMAT;
+		else {
+			Md5 m;
+			m.update(dst, (size_t)st_size);
+			m.finish(dg);
+			if (memcmp(dg, img + pos, 16) != 0)
+				rc = LRZGPU_E_FORMAT;
+		}
+	} else if (!rc && pos != (size_t)n)
+		rc = LRZGPU_E_FORMAT;
+	if (rc) {
+		free(dst);
+		return rc;
+	}
+	*out = dst;
+	*out_len = (int64_t)st_size;
+	return 0;
+}

@@ -32,3 +32,31 @@ def test_decoder_rejects_corruption(O):
     bad[len(bad) // 2] ^= 0x40
     with pytest.raises(Exception):
         lrz_decode.decode(bytes(bad))
+
+
+@pytest.mark.parametrize("level", [1, 3, 5, 7, 9])
+@pytest.mark.parametrize("kind", ["text", "longrange", "random", "zeros", "phrases", "few"])
+def test_library_decoder_on_oracle_images(B, O, kind, level):
+    """lrzgpu_decompress_buffer (host LZMA decoder + token replay + CRC/MD5 checks) against images
+    written by the oracle (reference LzmaCompress inside): the library's read side is independent of
+    its write side, and agrees with the Python decoder."""
+    data = datagen.KINDS[kind](1048576 + 4321, seed=level + 20)
+    img, _ = O.compress_buffer(data, compression_level=level, threads=4, processors=4, ramsize=RAM)
+    assert B.decompress_buffer(img, host_threads=4) == data
+    assert bytes(lrz_decode.decode(img)) == data
+
+
+def test_library_decoder_edge_cases(B, O):
+    for data, kw in ((b"", {}), (b"x", {}), (datagen.text_like(300000, seed=3), {"no_compress": True}),
+                     (datagen.long_range(31, seed=1), {}), (bytes(70000), {})):
+        img, _ = O.compress_buffer(data, compression_level=7, threads=2, processors=2, ramsize=RAM, **kw)
+        assert B.decompress_buffer(img) == data
+    img, _ = O.compress_buffer(datagen.long_range(1 << 20, seed=4), compression_level=7, threads=2, processors=2, ramsize=RAM)
+    for cut in (20, 100, len(img) // 2, len(img) - 1):
+        with pytest.raises(RuntimeError):
+            B.decompress_buffer(img[:cut])
+    for flip in (200, len(img) // 3, len(img) // 2, len(img) - 5):  # payload bytes and the MD5 trailer
+        bad = bytearray(img)
+        bad[flip] ^= 0x21
+        with pytest.raises(RuntimeError):
+            B.decompress_buffer(bytes(bad))

@@ -20,7 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_roundtrip_kinds(B, kind, level):
     data = datagen.KINDS[kind](5 * 1048576 + 123, seed=level)
     img, _ = B.compress_buffer(data, level=level, threads=4, processors=8, ramsize=RAM, host_threads=8)
-    assert bytes(lrz_decode.decode(img)) == data
+    assert bytes(lrz_decode.decode(img)) == data  # independent decoder (liblzma)
+    assert B.decompress_buffer(img, host_threads=8) == data  # the library's own read side
 
 
 def test_roundtrip_multi_chunk(B):
@@ -29,6 +30,7 @@ def test_roundtrip_multi_chunk(B):
     hdr, chunks = lrz_decode.parse(img)
     assert len(chunks) == 3 and [c["eof"] for c in chunks] == [0, 0, 1]
     assert bytes(lrz_decode.decode(img, threads=16)) == data
+    assert B.decompress_buffer(img, host_threads=16) == data
 
 
 def test_roundtrip_full_size_headline_workload(B):
@@ -53,4 +55,7 @@ def test_roundtrip_full_size_headline_workload(B):
     assert len(chunks[0]["streams"][1]) >= 100  # ~128 literal blocks of stream_bufsize
     out = lrz_decode.decode(view, threads=usable)  # checks the chunk CRC and md5(out) == trailer itself
     assert out.shape[0] == n
+    del out
+    back = B.decompress_buffer(img, host_threads=usable)  # library decoder: same checks, own LZMA decoder
+    assert len(back) == n and hashlib.md5(back).digest() == want_md5
     img.free()
