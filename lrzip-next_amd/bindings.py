@@ -183,7 +183,11 @@ def make_control(level=7, rzip_level=0, threads=1, processors=1, ramsize=80 * 10
 
 
 def _take(out, olen):
-    res = C.string_at(out, olen.value)
+    n = olen.value
+    if n < (1 << 31) - 1:
+        res = C.string_at(out, n)
+    else:  # string_at() takes a C int
+        res = bytes(memoryview((C.c_ubyte * n).from_address(C.addressof(out.contents))).cast("B"))
     C.CDLL(None).free(out)
     return res
 
