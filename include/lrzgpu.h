@@ -175,6 +175,21 @@ void lrzgpu_profile_get(lrzgpu_profile *out);
  * Host code -- decompression is outside the accelerated path; it lets a GPU box check
  * decode(compress(x)) == x through this ABI.  *out is malloc()ed. */
 int lrzgpu_decompress_buffer(const uint8_t *lrz, int64_t n, uint8_t **out, int64_t *out_len, int host_threads);
+/* decompress_file() for that subset (src/lrzip.c decompress_file -> runzip_fd): whole fd_in -> fd_out */
+int lrzgpu_decompress_file(int fd_in, int fd_out, int host_threads);
+
+/* The figures `lrzip-next -i` prints (get_fileinfo, src/lrzip.c:1069-1460) for an image in memory. */
+typedef struct lrzgpu_info {
+	int major, minor;          /* 0.14 */
+	int64_t st_size;           /* uncompressed size from the magic */
+	int64_t compressed_size;
+	int hash_code;             /* 0 CRC only, 1 MD5 */
+	int lzma, dict_prop;       /* LZMA back end flag and its lzma2-style dictionary byte */
+	int level, rzip_level;
+	int64_t chunks, blocks, blocks_lzma;
+	int64_t stream_c_len[2], stream_u_len[2]; /* stream 0 (tokens) / stream 1 (literals): stored and original bytes */
+} lrzgpu_info;
+int lrzgpu_file_info(const uint8_t *lrz, int64_t n, lrzgpu_info *info);
 
 /* ---- misc ------------------------------------------------------------------------------------- */
 int lrzgpu_device_count(void);

@@ -257,6 +257,35 @@ def decompress_buffer(img, host_threads=0):
     return _take(out, olen)
 
 
+class Info(C.Structure):
+    _fields_ = [("major", C.c_int), ("minor", C.c_int), ("st_size", C.c_int64), ("compressed_size", C.c_int64),
+                ("hash_code", C.c_int), ("lzma", C.c_int), ("dict_prop", C.c_int), ("level", C.c_int),
+                ("rzip_level", C.c_int), ("chunks", C.c_int64), ("blocks", C.c_int64), ("blocks_lzma", C.c_int64),
+                ("stream_c_len", C.c_int64 * 2), ("stream_u_len", C.c_int64 * 2)]
+
+
+def file_info(img: bytes):
+    info = Info()
+    f = lib().lrzgpu_file_info
+    f.argtypes = [C.c_char_p, C.c_int64, C.POINTER(Info)]
+    rc = f(img, len(img), C.byref(info))
+    if rc != 0:
+        raise RuntimeError("lrzgpu_file_info rc=%d" % rc)
+    return info
+
+
+def decompress_file(path_in, path_out, host_threads=0):
+    fi = os.open(path_in, os.O_RDONLY)
+    fo = os.open(path_out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    try:
+        rc = lib().lrzgpu_decompress_file(fi, fo, host_threads)
+    finally:
+        os.close(fi)
+        os.close(fo)
+    if rc != 0:
+        raise RuntimeError("lrzgpu_decompress_file rc=%d" % rc)
+
+
 def plan(st_size, **kw):
     c = make_control(**kw)
     chunk = C.c_int64()

@@ -5,6 +5,8 @@
 // is outside the accelerated path; this exists so that a GPU box can check decode(compress(x)) == x
 // through the C ABI without the reference.  Subset: what lrzgpu_compress_* writes (lrzip-next 0.14
 // magic, no encryption/filters, stored and LZMA blocks, MD5 or no hash).
+#include <unistd.h>
+
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -263,5 +265,100 @@ extern "C" int lrzgpu_decompress_buffer(const uint8_t *img, int64_t n, uint8_t *
 	}
 	*out = dst;
 	*out_len = (int64_t)st_size;
+	return 0;
+}
+
+// decompress_file() for the same subset (reference src/lrzip.c decompress_file -> runzip_fd)
+extern "C" int lrzgpu_decompress_file(int fd_in, int fd_out, int host_threads)
+{
+	std::vector<uint8_t> img;
+	{
+		uint8_t tmp[1 << 16];
+		for (;;) {
+			const ssize_t r = read(fd_in, tmp, sizeof(tmp));
+			if (r < 0)
+				return LRZGPU_E_IO;
+			if (r == 0)
+				break;
+			img.insert(img.end(), tmp, tmp + r);
+		}
+	}
+	uint8_t *out = nullptr;
+	int64_t n = 0;
+	const int rc = lrzgpu_decompress_buffer(img.data(), (int64_t)img.size(), &out, &n, host_threads);
+	if (rc)
+		return rc;
+	int ret = 0;
+	for (int64_t o = 0; o < n;) {
+		const ssize_t w = write(fd_out, out + o, (size_t)(n - o > (1 << 30) ? (1 << 30) : n - o));
+		if (w <= 0) {
+			ret = LRZGPU_E_IO;
+			break;
+		}
+		o += w;
+	}
+	free(out);
+	return ret;
+}
+
+// get_fileinfo() essentials (reference src/lrzip.c:1069-1460, lrzip-next -i): sizes and block counts
+extern "C" int lrzgpu_file_info(const uint8_t *img, int64_t n, lrzgpu_info *info)
+{
+	if (!img || !info || n < 21 + 2)
+		return LRZGPU_E_PARAM;
+	if (memcmp(img, "LRZI", 4) != 0)
+		return LRZGPU_E_FORMAT;
+	memset(info, 0, sizeof(*info));
+	info->major = img[4];
+	info->minor = img[5];
+	info->st_size = (int64_t)val(img + 6, 8);
+	info->hash_code = img[14];
+	info->lzma = img[17] == 1;
+	info->dict_prop = img[18];
+	info->rzip_level = img[19] >> 4;
+	info->level = img[19] & 15;
+	if (img[4] != 0 || img[5] != 14)
+		return LRZGPU_E_FORMAT;
+	size_t pos = 21 + img[20];
+	for (;;) {
+		if (pos + 2 > (size_t)n)
+			return LRZGPU_E_FORMAT;
+		const int cb = img[pos], eof = img[pos + 1];
+		if (cb < 1 || cb > 8 || pos + 2 + (size_t)cb + 2 * (1 + 3 * (size_t)cb) > (size_t)n)
+			return LRZGPU_E_FORMAT;
+		const size_t base = pos + 2 + (size_t)cb, hlen = 1 + 3 * (size_t)cb;
+		size_t end = base + 2 * hlen;
+		info->chunks++;
+		for (int s = 0; s < 2; s++) {
+			size_t h = base + (size_t)s * hlen;
+			for (;;) {
+				if (h + hlen > (size_t)n)
+					return LRZGPU_E_FORMAT;
+				const int c_type = img[h];
+				const size_t c_len = (size_t)val(img + h + 1, cb), u_len = (size_t)val(img + h + 1 + cb, cb);
+				const size_t nxt = (size_t)val(img + h + 1 + 2 * cb, cb);
+				if (c_len) {
+					if (h + hlen + c_len > (size_t)n)
+						return LRZGPU_E_FORMAT;
+					info->blocks++;
+					if (c_type == 6)
+						info->blocks_lzma++;
+					info->stream_c_len[s] += (int64_t)c_len;
+					info->stream_u_len[s] += (int64_t)u_len;
+					if (h + hlen + c_len > end)
+						end = h + hlen + c_len;
+				}
+				if (!nxt)
+					break;
+				if (base + nxt <= h)
+					return LRZGPU_E_FORMAT;
+				h = base + nxt;
+			}
+		}
+		pos = end;
+		if (eof)
+			break;
+	}
+	info->compressed_size = n;
 	return 0;
 }

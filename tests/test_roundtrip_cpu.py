@@ -60,3 +60,18 @@ def test_library_decoder_edge_cases(B, O):
         bad[flip] ^= 0x21
         with pytest.raises(RuntimeError):
             B.decompress_buffer(bytes(bad))
+
+
+def test_file_info_and_decompress_file(B, O, tmp_path):
+    data = datagen.long_range(3 * 1048576 + 17, seed=6)
+    img, fs = O.compress_buffer(data, compression_level=7, threads=4, processors=4, ramsize=RAM)
+    info = B.file_info(img)
+    hdr, chunks = lrz_decode.parse(img)
+    assert (info.major, info.minor, info.st_size, info.compressed_size) == (0, 14, len(data), len(img))
+    assert info.hash_code == 1 and info.lzma == 1 and info.level == 7 and info.chunks == len(chunks) == fs.n_chunks
+    assert info.blocks == sum(len(s) for c in chunks for s in c["streams"]) == fs.n_blocks
+    assert info.stream_u_len[1] == sum(b[3] for c in chunks for b in c["streams"][1])
+    src, dst = tmp_path / "a.lrz", tmp_path / "a.out"
+    src.write_bytes(img)
+    B.decompress_file(str(src), str(dst))
+    assert dst.read_bytes() == data
