@@ -120,7 +120,7 @@ def cpu_baseline(sample_bytes, ctl_kw, cores, alphabet="alnum"):
             "seconds": round(dt, 2)}
 
 
-def pmc_traffic(kernel, args):
+def pmc_traffic(kernel, args, launches):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r1_k_resolve_pmc.json; counters cannot be read from inside the process)."""
     path = os.path.join(ROOT, "profiles", "r1_k_resolve_pmc.json")
@@ -130,7 +130,8 @@ def pmc_traffic(kernel, args):
         return None, "no PMC summary committed"
     if kernel != d.get("kernel") or args.mib != d.get("workload_mib") or args.alphabet != d.get("alphabet"):
         return None, "PMC summary is for %s on the %s MiB workload" % (d.get("kernel"), d.get("workload_mib"))
-    b = (d["fetch_kb_per_launch"] + d["write_kb_per_launch"]) * 1024.0
+    # per launch of THIS run: the segment count (launches) may differ from the profiled build's
+    b = (d["fetch_kb_total"] + d["write_kb_total"]) * 1024.0 / max(1, launches)
     return int(b), ("(FETCH_SIZE + WRITE_SIZE) x 1024 per launch from profiles/r1_bench4g_pmc_hbm.csv, raw; "
                     "gfx950 FETCH_SIZE under-reports wide streams 2x, so reads are between 1x and 2x the fetch part")
 
@@ -257,7 +258,7 @@ def main():
         ms, launches, alg_bytes = kernels[dom]
         avg_ms = ms / max(launches, 1)
         achieved = (alg_bytes / max(launches, 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic, traffic_note = pmc_traffic(dom, args)
+        traffic, traffic_note = pmc_traffic(dom, args, launches)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(achieved / 8000.0, 6), "traffic": traffic, "traffic_note": traffic_note,
                     "avg_launch_ms": round(avg_ms, 3), "launches": int(launches),
