@@ -46,7 +46,7 @@ class Profile(C.Structure):
                                           "resolve_inserts", "resolve_match_bytes", "crc_bytes", "gather_bytes",
                                           "lz4_bytes", "mf_positions", "mf_entries")] + \
                [("scan_wall_ms", C.c_double), ("resolve_dbg", C.c_int64 * 16), ("long_compare_ms", C.c_double),
-                ("long_compare_launches", C.c_int64), ("long_compare_bytes", C.c_int64)]
+                ("long_compare_launches", C.c_int64), ("long_compare_bytes", C.c_int64), ("spec_rollbacks", C.c_int64), ("spec_cancelled_blocks", C.c_int64)]
 
 
 ALPHABETS = {

@@ -164,6 +164,9 @@ typedef struct lrzgpu_profile {
 	double long_compare_ms;       /* k_long_compare: forward extents of matches > 4 MiB    */
 	int64_t long_compare_launches;
 	int64_t long_compare_bytes;   /* bytes of both operands it compared                    */
+	int64_t spec_rollbacks;       /* chunks whose early-released literal frontier a later match crossed
+	                                 (stream 1 rebuilt, early blocks discarded)              */
+	int64_t spec_cancelled_blocks; /* early-released blocks thrown away by those roll-backs   */
 } lrzgpu_profile;
 void lrzgpu_profile_reset(void);
 void lrzgpu_profile_get(lrzgpu_profile *out);

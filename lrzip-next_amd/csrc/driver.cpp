@@ -62,7 +62,13 @@ extern "C" void lrzgpu_control_init(lrzgpu_control *c)
 
 namespace {
 
-constexpr int64_t SPEC_MARGIN = (int64_t)2 << 20; // literal bytes this far behind the scan count as decided
+// literal bytes this far behind the scan count as decided (LRZGPU_SPEC_MARGIN overrides: test hook
+// for the roll-back path -- with 0 every match that extends backwards over a segment boundary violates)
+static int64_t spec_margin()
+{
+	const char *e = getenv("LRZGPU_SPEC_MARGIN"); // read per call: tests flip it inside one process
+	return e ? (int64_t)atoll(e) : (int64_t)2 << 20;
+}
 constexpr size_t STAGE_BYTES = (size_t)32 << 20;  // pinned D2H staging piece (two per GPU worker)
 
 double now_s()
@@ -941,7 +947,7 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 			}
 			if (violated)
 				return 0;
-			int64_t Fp = final_call ? chunk_size : upto - SPEC_MARGIN;
+			int64_t Fp = final_call ? chunk_size : upto - spec_margin();
 			if (!final_call && h.cur_len > 0 && h.cur_p < Fp)
 				Fp = h.cur_p;
 			if (Fp > chunk_size)
@@ -999,8 +1005,18 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 		}
 		if (!speculate || violated || S != er.stream1_len) {
 			// (re)build stream 1 from the final run table; early blocks, if any, are void
+			if (speculate && violated) {
+				ProfileStore &ps = ProfileStore::get();
+				std::lock_guard<std::mutex> lk(ps.mu);
+				ps.p.spec_rollbacks++;
+			}
 			if (!early.empty()) {
 				n_violations++;
+				{
+					ProfileStore &ps = ProfileStore::get();
+					std::lock_guard<std::mutex> lk(ps.mu);
+					ps.p.spec_cancelled_blocks += (int64_t)early.size();
+				}
 				{
 					std::lock_guard<std::mutex> lk(P.mu);
 					for (auto &kv : early)

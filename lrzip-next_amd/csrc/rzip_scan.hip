@@ -1996,6 +1996,11 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 		int64_t seg = (int64_t)(2 << 20) << (mbits > 9 ? 9 : mbits);
 		if (seg < (4 << 20)) // small early segments: the back end gets its first blocks sooner
 			seg = 4 << 20;
+		if (const char *e = getenv("LRZGPU_SEG_BYTES")) { // test hook: fixed segment size
+			const long long v = atoll(e);
+			if (v >= TILE)
+				seg = v;
+		}
 		if (seg > (int64_t)w->seg_cap - TILE)
 			seg = (int64_t)w->seg_cap - TILE;
 		int64_t seg_hi = seg_lo + seg;

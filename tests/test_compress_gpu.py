@@ -77,3 +77,48 @@ def test_device_resident_input(B, O):
     t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
     got, ctl = B.compress_device(t.data_ptr(), t.numel(), level=7, threads=4, processors=8, ramsize=RAM, host_threads=8)
     assert got == want
+
+
+def test_early_release_rollback(B, O, monkeypatch):
+    """The back end starts on literal blocks before the scan of the chunk is over; a later match that
+    extends BACKWARDS over bytes already released voids them (stream 1 is rebuilt).  With the safety
+    margin forced to 0, a copy that starts a few bytes before a scan-segment boundary (4 MiB + 1) and
+    whose first candidate lies after it does exactly that."""
+    import ctypes as C
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("lrz_bench_prof", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setenv("LRZGPU_SPEC_MARGIN", "0")
+    L = B.lib()
+    a = datagen.random_bytes(3 * 1048576, seed=51)
+    rollbacks = 0
+    # the copy starts d bytes before the boundary; a roll-back needs those d positions to hold no candidate
+    # (tag mask 1: one position in two is one), so small d and a few seeds
+    for trial, d in enumerate((1, 2, 1, 3, 2, 1, 2, 3)):
+        filler = datagen.random_bytes((4 << 20) + 1 - d - len(a), seed=60 + trial)
+        data = a + filler + a[:1 << 20] + datagen.random_bytes(2 << 20, seed=70 + trial)
+        L.lrzgpu_profile_reset()
+        _both(B, O, data, level=7, threads=2, processors=8)
+        prof = bench.Profile()
+        L.lrzgpu_profile_get(C.byref(prof))
+        rollbacks += prof.spec_rollbacks
+    assert rollbacks >= 1  # at least one of the offsets puts the first candidate behind the boundary
+
+    # the same after literal blocks have already gone to the back end: they are cancelled and redone
+    monkeypatch.setenv("LRZGPU_SEG_BYTES", str(4 << 20))  # segment boundaries at 1 + k * 4 MiB
+    base = datagen.random_bytes(4 << 20, seed=81)
+    parts, pos = [base], len(base)
+    for k in range(14, 18):  # copies of base[0:64 KiB] starting 1 or 2 bytes before the boundaries 56 .. 68 MiB
+        start = k * (4 << 20) + 1 - (1 + k % 2)
+        parts.append(datagen.random_bytes(start - pos, seed=100 + k))
+        parts.append(base[:65536])
+        pos = start + 65536
+    parts.append(datagen.random_bytes(1 << 20, seed=99))
+    data = b"".join(parts)
+    L.lrzgpu_profile_reset()
+    fs = _both(B, O, data, level=7, threads=16, processors=16)
+    prof = bench.Profile()
+    L.lrzgpu_profile_get(C.byref(prof))
+    assert fs.stream_bufsize * 2 < len(data)  # literal blocks were released before the late violations
+    assert prof.spec_rollbacks >= 1 and prof.spec_cancelled_blocks >= 1
