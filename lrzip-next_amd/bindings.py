@@ -274,6 +274,22 @@ def file_info(img: bytes):
     return info
 
 
+def compress_file(path_in, path_out, rzip_only_fd=False, **kw):
+    """lrzgpu_compress_file (magic + chunks + MD5) or, with rzip_only_fd, lrzgpu_rzip_fd (chunks + MD5 at
+    the current offset of fd_out, the caller writes the magic) -> Control."""
+    c = make_control(**kw)
+    fi = os.open(path_in, os.O_RDONLY)
+    fo = os.open(path_out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    try:
+        rc = (lib().lrzgpu_rzip_fd if rzip_only_fd else lib().lrzgpu_compress_file)(C.byref(c), fi, fo)
+    finally:
+        os.close(fi)
+        os.close(fo)
+    if rc != 0:
+        raise RuntimeError("compress via fd rc=%d" % rc)
+    return c
+
+
 def decompress_file(path_in, path_out, host_threads=0):
     fi = os.open(path_in, os.O_RDONLY)
     fo = os.open(path_out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)

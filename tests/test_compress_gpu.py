@@ -122,3 +122,20 @@ def test_early_release_rollback(B, O, monkeypatch):
     L.lrzgpu_profile_get(C.byref(prof))
     assert fs.stream_bufsize * 2 < len(data)  # literal blocks were released before the late violations
     assert prof.spec_rollbacks >= 1 and prof.spec_cancelled_blocks >= 1
+
+
+def test_fd_entry_points(B, O, tmp_path):
+    """lrzgpu_compress_file == the whole image; lrzgpu_rzip_fd == the same without the 21-byte magic
+    (rzip_fd() writes chunks + MD5, compress_file() adds the header: src/lrzip.c:1549)."""
+    data = datagen.long_range(5 * 1048576 + 77, seed=23, base_frac=0.4)
+    want, _ = O.compress_buffer(data, compression_level=7, threads=4, processors=8, ramsize=RAM, workers=8)
+    src = tmp_path / "in.bin"
+    src.write_bytes(data)
+    ctl = B.compress_file(str(src), str(tmp_path / "a.lrz"), level=7, threads=4, processors=8, ramsize=RAM, host_threads=8)
+    assert (tmp_path / "a.lrz").read_bytes() == want and ctl.st_size == len(data)
+    ctl = B.compress_file(str(src), str(tmp_path / "b.part"), rzip_only_fd=True, level=7, threads=4, processors=8,
+                          ramsize=RAM, host_threads=8)
+    assert (tmp_path / "b.part").read_bytes() == want[21:]
+    assert bytes(ctl.hash_resblock) == hashlib.md5(data).digest() and ctl.st_size == len(data)
+    B.decompress_file(str(tmp_path / "a.lrz"), str(tmp_path / "a.out"))
+    assert (tmp_path / "a.out").read_bytes() == data
