@@ -1,0 +1,36 @@
+"""Seeded random sweep of the whole path against the oracle: levels, -p, -w, lz4 gate on/off,
+threshold, input kind and size drawn at random (fixed seeds, so every run checks the same cases)."""
+import random
+
+import pytest
+
+import datagen
+
+pytestmark = pytest.mark.gpu
+RAM = 80 * 100 << 20
+
+
+def _case(seed):
+    r = random.Random(seed)
+    kind = r.choice(["text", "random", "phrases", "sparse", "longrange", "few", "zeros"])
+    n = r.choice([0, 1, 30, 31, 32, 4095, 65537, r.randrange(100000, 3000000), r.randrange(3000000, 12000000)])
+    if kind in ("few", "zeros"):
+        n = min(n, 1500000)  # collapsed tag spaces run in serial resolver steps: keep them small
+    kw = dict(level=r.randrange(1, 10), threads=r.choice([1, 2, 3, 4, 8, 16]), processors=r.choice([1, 4, 8, 16]),
+              lz4_test=r.random() < 0.8, threshold=r.choice([100, 100, 95, 80, 50]))
+    if r.random() < 0.15:
+        kw["no_compress"] = True
+    return kind, n, kw
+
+
+@pytest.mark.parametrize("seed", range(1000, 1160))
+def test_random_parameters(B, O, seed):
+    kind, n, kw = _case(seed)
+    data = datagen.KINDS[kind](n, seed=seed)
+    okw = dict(compression_level=kw["level"], threads=kw["threads"], processors=kw["processors"], ramsize=RAM,
+               no_compress=int(kw.get("no_compress", False)), lz4_test=int(kw["lz4_test"]), threshold=kw["threshold"], workers=8)
+    want, fs = O.compress_buffer(data, **okw)
+    got, ctl = B.compress_buffer(data, ramsize=RAM, host_threads=8, **kw)
+    assert ctl.stream_bufsize == fs.stream_bufsize and ctl.dictSize_used == fs.dict_size, (kind, n, kw)
+    assert got == want, (kind, n, kw, len(got), len(want))
+    assert B.decompress_buffer(got, host_threads=4) == data
