@@ -78,3 +78,22 @@ def test_victim_round_carry(B, O):
     for vr in (0, 5):
         _check(B, O, pat, level=7, victim_round=vr)
         _check(B, O, pat, level=4, victim_round=vr % 3)
+
+
+@pytest.mark.parametrize("mib", [512, 4096])
+def test_headline_shape(B, O, mib):
+    """The bench workload shape (seeded text + identical copy at distance n/2), up to the full 4 GiB of
+    BASELINE.json configs[1]: tag masks up to 0x1ff, clusters of ~340 slots, twins under continuous
+    cleaning, and a multi-GiB match that goes through k_long_compare -- both streams and every statistic
+    bit for bit against the oracle (its scan takes about a minute at 4 GiB)."""
+    import importlib.util
+    import os
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("lrz_bench_w", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n = mib << 20
+    data = bench.make_workload(n, 1, torch.device("cuda:0"), "alnum")[:n].cpu().numpy().tobytes()
+    st = _check(B, O, data, level=7)
+    assert st.match_bytes > (n // 2) - (8 << 20) and st.minimum_tag_mask >= 0x3f
