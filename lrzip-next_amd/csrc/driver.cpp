@@ -19,6 +19,8 @@
 // Output bytes depend only on (input, control parameters), never on thread counts or timing here.
 #include <hip/hip_runtime.h>
 #include <sched.h>
+
+#include <cerrno>
 #include <time.h>
 #include <unistd.h>
 
@@ -1190,6 +1192,22 @@ int write_all(int fd, const uint8_t *p, size_t n)
 int read_fd_all(int fd, std::vector<uint8_t> *buf)
 {
 	off_t end = lseek(fd, 0, SEEK_END);
+	if (end < 0 && errno == ESPIPE) {
+		// a pipe / stdin: the reference spools it into a temporary buffer first (src/lrzip.c:627-922)
+		buf->clear();
+		std::vector<uint8_t> tmp((size_t)1 << 20);
+		for (;;) {
+			ssize_t r = read(fd, tmp.data(), tmp.size());
+			if (r < 0) {
+				if (errno == EINTR)
+					continue;
+				return LRZGPU_E_IO;
+			}
+			if (r == 0)
+				return 0;
+			buf->insert(buf->end(), tmp.data(), tmp.data() + r);
+		}
+	}
 	if (end < 0 || lseek(fd, 0, SEEK_SET) < 0)
 		return LRZGPU_E_IO;
 	buf->resize((size_t)end);

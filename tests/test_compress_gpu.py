@@ -139,3 +139,35 @@ def test_fd_entry_points(B, O, tmp_path):
     assert bytes(ctl.hash_resblock) == hashlib.md5(data).digest() and ctl.st_size == len(data)
     B.decompress_file(str(tmp_path / "a.lrz"), str(tmp_path / "a.out"))
     assert (tmp_path / "a.out").read_bytes() == data
+
+
+def test_pipe_input_and_output(B, O):
+    """stdin/stdout style use: non-seekable fds on both sides (the reference spools stdin into a
+    temporary buffer, src/lrzip.c:627-922; this library reads the pipe to EOF and writes the image once)."""
+    import os
+    import threading
+    data = datagen.text_like(2 * 1048576 + 11, seed=29)
+    want, _ = O.compress_buffer(data, compression_level=7, threads=2, processors=8, ramsize=RAM, workers=8)
+    r_in, w_in = os.pipe()
+    r_out, w_out = os.pipe()
+    got = bytearray()
+
+    def feed():
+        with os.fdopen(w_in, "wb") as f:
+            f.write(data)
+
+    def drain():
+        with os.fdopen(r_out, "rb") as f:
+            got.extend(f.read())
+
+    t1, t2 = threading.Thread(target=feed), threading.Thread(target=drain)
+    t1.start()
+    t2.start()
+    c = B.make_control(level=7, threads=2, processors=8, ramsize=RAM, host_threads=8)
+    import ctypes as C
+    rc = B.lib().lrzgpu_compress_file(C.byref(c), r_in, w_out)
+    os.close(w_out)
+    os.close(r_in)
+    t1.join()
+    t2.join()
+    assert rc == 0 and bytes(got) == want
