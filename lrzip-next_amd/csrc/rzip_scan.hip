@@ -10,14 +10,22 @@
 //                      CURRENT minimum tag mask (masks only ever gain bits, so the filter yields a
 //                      superset of every later lookup/insert), compacted in position order with a
 //                      workgroup prefix sum.  HBM-bound: 1 B read per position.
-//   K2 k_resolve       one wavefront.  The exact hash-table automaton over the candidates:
-//                      a probe is ONE 64-slot (1 KiB) coalesced window load + wave ballots
-//                      (empty / tag-equal / min-bitness / lesser-bitness) instead of a slot-by-slot
-//                      pointer walk; insert displacement uses an explicit LDS stack; the clean
-//                      sweep is a ballot+ffs over the window at tag_clean_ptr; match verification
-//                      is a 64-lane wide compare (512 B per step, 16 KiB per step once a match is
-//                      long).  Upcoming candidates' bucket windows are prefetched a batch ahead.
-//                      Latency-bound by design (serial table state); bit-exact by construction.
+//      k_tile_scan /   exclusive scan of the per-tile counts and the packed, position-ordered
+//      k_compact_cands candidate list of the segment (64 candidates per resolver load at any density).
+//   K2 k_resolve       one wavefront.  The exact hash-table automaton over the candidates, as a
+//                      speculative in-order window: up to 64 candidates, one per lane, are simulated
+//                      against the table as it stands (walks over one rank byte and one fingerprint
+//                      byte per slot, 64 slots per step, 8 slots per SWAR operation; twins with the
+//                      same tag on top of their predecessor's predicted insert), the longest prefix
+//                      that is provably what the serial automaton would do is committed in parallel
+//                      (hashed LDS write counters + exact check for conflicts, ballot prefix counts
+//                      for the clean sweep), everything else -- real matches, sweep wraps, lazy
+//                      matching, collapsed tag spaces -- takes the serial step: one coalesced 64-slot
+//                      window load + wave ballots per probe, LDS stack for insert displacement,
+//                      64-lane wide match verification.  Bound by instruction issue and dependent
+//                      loads of one wave (serial table state), bit-exact by construction.
+//   K3 k_long_compare  all CUs.  Forward extent of a match that is still equal after 4 MiB; the
+//                      resolver launch ends with the request and resumes with the answer as a hint.
 //   K4 k_gather_runs   all CUs.  Materialises stream 1 (literal bytes) from the run table.
 //   K5 k_crc32_tiles   all CUs.  CRC-32 of the chunk, 64 KiB tiles combined with GF(2) shifts.
 #include <hip/hip_runtime.h>
