@@ -7,12 +7,13 @@
 //                    reference overlaps the same way through flush_buffer() (src/rzip.c:229-246).
 //                    "Decided" = behind every emitted match, or more than SPEC_MARGIN behind the
 //                    scan position; a later match reaching back over such bytes is detected and
-//                    the chunk's early blocks are then thrown away and redone (never observed on
-//                    real data: a backward extension is bounded by the candidate spacing).
+//                    the chunk's early blocks are then thrown away and redone (not observed on the
+//                    bench workloads; tests force it with LRZGPU_SPEC_MARGIN / LRZGPU_SEG_BYTES).
 //   lz4 gate         one wavefront per block, launched per group of new blocks on its own stream
 //   GPU workers      `gpu_slots` threads, each with a HIP stream + match-finder workspace + pinned
 //                    staging: finder for block k+1 while block k is parsed on the host
-//   host encoders    `host_threads` threads: LZMA optimal parser + range coder (lzma_enc.cpp)
+//   host encoders    `host_threads` threads (default: the CPUs the process may use): LZMA parser +
+//                    range coder (lzma_enc.cpp); all stream waits are blocking-sync events
 //   writer           ordered container assembly (stream_layer.cpp); the file order of the blocks is
 //                    block_order()'s replay of the reference flushes, whatever order they finished in
 //

@@ -15,6 +15,12 @@
 //     pure functions of the data (updated at every position), obtained with two more sorts.
 //   * records are written into a bump-allocated pool and then gathered into position order so the
 //     host parser streams them sequentially.
+//   * runs of one byte value put millions of consecutive positions into ONE bucket; each of them
+//     repeats its predecessor's result (full-length match at distance 1, inherited sons), so the
+//     lane that owns such a bucket writes them eight at a time without reading the tree.
+// Levels 1-4 (algo 0) use hash chains instead (HC5, LzFind.c:880-958, 1431-1502): every chain link
+// is "previous position with the same 5-byte hash" and no position changes what a later one sees,
+// so k_hc5 is one thread per position (see the comment above it).
 // Roofline: HBM-latency/throughput bound pointer chasing, no MFMA.  Algorithmic bytes/position:
 // 1 B read + 4 B head r/w + 8 B son pair + <=48 node visits (8 B pair + compares) -- see DESIGN.md.
 #include <hip/hip_runtime.h>
