@@ -29,12 +29,13 @@ extern "C" {
 #define LRZGPU_FLAG_NO_COMPRESS (1u << 5)  /* FLAG_NO_COMPRESS, -n */
 #define LRZGPU_FLAG_THRESHOLD (1u << 20)   /* FLAG_THRESHOLD: lz4 test on (default) */
 #define LRZGPU_FLAG_NOBEMT (1u << 27)      /* FLAG_NOBEMT */
+#define LRZGPU_FLAG_ZSTD (1u << 26)        /* FLAG_ZSTD_COMPRESS: --zstd back end (host libzstd), GPU rzip + gate */
 
 /* The fields of rzip_control (src/include/lrzip_private.h:472-581) the compress path depends on.
  * Output depends on them exactly as in the reference (block boundaries, dictionary, thread slots:
  * src/stream.c:1169-1331, src/util.c:103-188, src/rzip.c:999-1020). */
 typedef struct lrzgpu_control {
-	int compression_level;      /* -L, 5..9 on the GPU LZMA path (1..9 with NO_COMPRESS)          */
+	int compression_level;      /* -L, 1..9                                                        */
 	int rzip_compression_level; /* -R, 0 = same as compression_level (src/main.c:779-780)          */
 	int threads;                /* -p, before prepare_streamout_threads() adds one                 */
 	int processors;             /* PROCESSORS (sysconf) as the reference host would report         */
@@ -55,6 +56,8 @@ typedef struct lrzgpu_control {
 	uint32_t dictSize_used;     /* dictionary after open_stream_out()'s reduction loop             */
 	int64_t stream_bufsize;     /* block size open_stream_out() settled on                         */
 	int threads_used;
+	/* --zstd only (input, appended here to keep the layout above stable) */
+	int zstd_level;             /* --zstd-level 1..22, 0 = from -L (src/main.c:87, 692-711, 822-828) */
 } lrzgpu_control;
 
 void lrzgpu_control_init(lrzgpu_control *c); /* initialise_control() defaults, src/lrzip.c:1813-1857 */

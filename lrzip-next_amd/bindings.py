@@ -19,7 +19,7 @@ class Control(C.Structure):
                 ("flags", C.c_uint32), ("threshold", C.c_int), ("device", C.c_int), ("host_threads", C.c_int),
                 ("gpu_slots", C.c_int), ("verbose", C.c_int), ("st_size", C.c_int64),
                 ("hash_resblock", C.c_uint8 * 16), ("lzma_properties", C.c_uint8 * 5), ("dictSize_used", C.c_uint32),
-                ("stream_bufsize", C.c_int64), ("threads_used", C.c_int)]
+                ("stream_bufsize", C.c_int64), ("threads_used", C.c_int), ("zstd_level", C.c_int)]
 
 
 class ScanStats(C.Structure):
@@ -31,6 +31,7 @@ class ScanStats(C.Structure):
 FLAG_NO_COMPRESS = 1 << 5
 FLAG_THRESHOLD = 1 << 20
 FLAG_NOBEMT = 1 << 27
+FLAG_ZSTD = 1 << 26
 
 _lib = None
 
@@ -162,7 +163,7 @@ def lzma_compress(data: bytes, level=7, dict_size=1 << 25, fb=64, lc=3, lp=0, pb
 
 def make_control(level=7, rzip_level=0, threads=1, processors=1, ramsize=80 * 100 * 1048576, window=0, dict_size=0,
                  no_compress=False, lz4_test=True, threshold=100, nobemt=False, device=0, host_threads=0,
-                 gpu_slots=0, verbose=0):
+                 gpu_slots=0, verbose=0, zstd=False, zstd_level=0):
     c = Control()
     lib().lrzgpu_control_init(C.byref(c))
     c.compression_level = level
@@ -173,12 +174,13 @@ def make_control(level=7, rzip_level=0, threads=1, processors=1, ramsize=80 * 10
     c.window = window
     c.dictSize = dict_size
     c.flags = (FLAG_NO_COMPRESS if no_compress else 0) | (FLAG_THRESHOLD if lz4_test else 0) | \
-              (FLAG_NOBEMT if nobemt else 0)
+              (FLAG_NOBEMT if nobemt else 0) | (FLAG_ZSTD if zstd else 0)
     c.threshold = threshold
     c.device = device
     c.host_threads = host_threads
     c.gpu_slots = gpu_slots
     c.verbose = verbose
+    c.zstd_level = zstd_level
     return c
 
 

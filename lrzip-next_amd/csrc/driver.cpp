@@ -19,6 +19,7 @@
 //
 // Output bytes depend only on (input, control parameters), never on thread counts or timing here.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <sched.h>
 
 #include <cerrno>
@@ -133,6 +134,30 @@ struct ChunkCtx {
 	uint8_t *d_stream1 = nullptr; // owned, chunk_size + 256 bytes
 	int64_t stream1_len = 0;
 	std::vector<uint8_t> stream0;
+};
+
+// --zstd back end: the system libzstd, bound at run time like the reference links it
+// (src/stream.c:167-230 zstd_compress_buf; bit-exactness holds against the same libzstd build)
+struct ZstdLib {
+	size_t (*compress)(void *, size_t, const void *, size_t, int) = nullptr;
+	unsigned (*is_error)(size_t) = nullptr;
+	bool ok = false;
+	static const ZstdLib &get()
+	{
+		static const ZstdLib z = [] {
+			ZstdLib l;
+			void *h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_GLOBAL);
+			if (!h)
+				h = dlopen("libzstd.so", RTLD_NOW | RTLD_GLOBAL);
+			if (h) {
+				l.compress = (size_t(*)(void *, size_t, const void *, size_t, int))dlsym(h, "ZSTD_compress");
+				l.is_error = (unsigned (*)(size_t))dlsym(h, "ZSTD_isError");
+				l.ok = l.compress && l.is_error;
+			}
+			return l;
+		}();
+		return z;
+	}
 };
 
 // Recycled host buffers for block copies and match lists.  A 16 MiB block has ~450 MB of lists;
@@ -337,7 +362,27 @@ struct Pipeline {
 				enc_queue.pop_front();
 			}
 			const double te0 = now_s();
-			if (!j->cancelled) {
+			if (!j->cancelled && sz.zstd) {
+				// zstd_compress_buf(), src/stream.c:167-230: dlen = round_up_page(s_len); "does not fit" and
+				// "not smaller" both leave the block stored
+				const ZstdLib &z = ZstdLib::get();
+				size_t cap = ((size_t)j->ref.len + kPage - 1) / kPage * kPage;
+				RawBuf<uint8_t> dst;
+				dst.alloc(cap);
+				const size_t r = z.compress(dst.data(), cap, j->bytes.data(), (size_t)j->ref.len, sz.zstd_level);
+				if (z.is_error(r)) {
+					if ((size_t)0 - r != 70) { // ZSTD_error_dstSize_tooSmall = incompressible
+						fail(LRZGPU_E_INTERNAL);
+						return;
+					}
+					store_raw(j);
+				} else if ((int64_t)r >= j->ref.len) {
+					store_raw(j);
+				} else {
+					j->done.c_type = CTYPE_ZSTD;
+					j->done.payload.assign(dst.data(), dst.data() + r);
+				}
+			} else if (!j->cancelled) {
 				LzmaParams p;
 				lzma_normalize(p, sz.level, sz.dict_size, 3, 0, 2, sz.level < 7 ? 32 : 64);
 				MatchLists ml;
@@ -448,7 +493,7 @@ struct Pipeline {
 			j->done.streamno = j->ref.streamno;
 			j->done.s_len = n;
 			bool try_backend = !sz.no_compress && n >= 64 && !j->cancelled; // src/stream.c:1633
-			if (try_backend && !lzma_ok) {
+			if (try_backend && !sz.zstd && !lzma_ok) {
 				fail(LRZGPU_E_PARAM);
 				cleanup();
 				return;
@@ -490,7 +535,7 @@ struct Pipeline {
 			}
 			const double tw1 = now_s();
 			double tw2 = tw1;
-			if (compressible) {
+			if (compressible && !sz.zstd) {
 				// match finder on the GPU (runs concurrently with the gate launch of this block)
 				unsigned long long total = 0;
 				for (int attempt = 0;; attempt++) {
@@ -761,6 +806,8 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 		if (P.n_encoders > usable)
 			P.n_encoders = usable;
 	}
+	if (P.sz.zstd && !ZstdLib::get().ok)
+		return LRZGPU_E_PARAM; // --zstd asked for and no libzstd.so.1 on this host
 	P.n_gpu_workers = ctl->gpu_slots > 0 ? ctl->gpu_slots : 3;
 	P.held_limit = (size_t)P.n_encoders + (size_t)P.n_gpu_workers + 2;
 	ctl->stream_bufsize = P.sz.stream_bufsize;

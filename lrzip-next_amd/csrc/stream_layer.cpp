@@ -57,7 +57,27 @@ int compute_sizing(const lrzgpu_control *c, int64_t st_size, Sizing *out)
 	s.threshold = c->threshold;
 	if (s.level < 1 || s.level > 9 || s.rzip_level < 1 || s.rzip_level > 9 || c->threads < 1 || c->ramsize <= 0)
 		return LRZGPU_E_PARAM;
-	const bool lzma = !s.no_compress;
+	s.zstd = (c->flags & LRZGPU_FLAG_ZSTD) != 0 && !s.no_compress;
+	if (s.zstd) {
+		// zstd level <-> strategy <-> rzip level, src/main.c:87 (zstd_compression_level[]), 692-711, 822-828
+		static const int by_level[10] = {-1, 2, 4, 5, 7, 12, 15, 17, 18, 22};
+		if (c->zstd_level) {
+			if (c->zstd_level < 1 || c->zstd_level > 22)
+				return LRZGPU_E_PARAM;
+			s.zstd_level = c->zstd_level;
+			for (int st = 1; st <= 9; st++)
+				if (s.zstd_level <= by_level[st]) {
+					s.zstd_strategy = st;
+					if (!c->rzip_compression_level)
+						s.rzip_level = st; // --zstd-level sets the rzip level to the strategy
+					break;
+				}
+		} else {
+			s.zstd_level = by_level[s.level];
+			s.zstd_strategy = s.level;
+		}
+	}
+	const bool lzma = !s.no_compress && !s.zstd;
 	s.dict_size = c->dictSize ? c->dictSize : level_dict(s.level);
 	s.overhead = lzma ? overhead_for(s.dict_size) : 0;
 
@@ -229,7 +249,10 @@ void write_magic(uint8_t magic[21], const Sizing &s, int64_t st_size)
 	for (int i = 0; i < 8; i++)
 		magic[6 + i] = (uint8_t)((uint64_t)st_size >> (8 * i));
 	magic[14] = 1; // hash_code: MD5
-	if (!s.no_compress) {
+	if (s.zstd) { // src/lrzip.c:177-183
+		magic[17] = (uint8_t)((s.zstd_strategy << 4) + 4);
+		magic[18] = (uint8_t)s.zstd_level;
+	} else if (!s.no_compress) {
 		magic[17] = 1;
 		magic[18] = (uint8_t)lzma2_prop_from_dic(s.dict_size);
 	}

@@ -16,11 +16,14 @@ namespace lrzgpu {
 
 constexpr int CTYPE_NONE = 3; // src/include/lrzip_private.h:287-294
 constexpr int CTYPE_LZMA = 6;
+constexpr int CTYPE_ZSTD = 10;
 constexpr int64_t kPage = 4096;
 
 struct Sizing {
 	int level = 7, rzip_level = 7;
 	bool no_compress = false, lz4_test = true, nobemt = false;
+	bool zstd = false;        // --zstd back end (host libzstd); zstd_level 1..22, zstd_strategy 1..9
+	int zstd_level = 0, zstd_strategy = 0;
 	int threads = 1;          // after prepare_streamout_threads() and open_stream_out() reductions
 	uint32_t dict_size = 0;   // possibly reduced
 	int64_t overhead = 0;

@@ -5,6 +5,7 @@
 // is outside the accelerated path; this exists so that a GPU box can check decode(compress(x)) == x
 // through the C ABI without the reference.  Subset: what lrzgpu_compress_* writes (lrzip-next 0.14
 // magic, no encryption/filters, stored and LZMA blocks, MD5 or no hash).
+#include <dlfcn.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -69,6 +70,31 @@ inline uint64_t val(const uint8_t *p, int n)
 	return v;
 }
 
+// zstd blocks (c_type 10, --zstd files): the system libzstd, as src/stream.c:563-590 zstd_decompress_buf
+size_t zstd_decompress(void *dst, size_t cap, const void *src, size_t n, bool *ok)
+{
+	typedef size_t (*Fn)(void *, size_t, const void *, size_t);
+	typedef unsigned (*Err)(size_t);
+	static Fn fn = nullptr;
+	static Err is_err = nullptr;
+	static std::atomic<int> state{0};
+	if (state.load() == 0) {
+		void *h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_GLOBAL);
+		if (h) {
+			fn = (Fn)dlsym(h, "ZSTD_decompress");
+			is_err = (Err)dlsym(h, "ZSTD_isError");
+		}
+		state.store(fn && is_err ? 1 : 2);
+	}
+	if (state.load() != 1) {
+		*ok = false;
+		return 0;
+	}
+	const size_t r = fn(dst, cap, src, n);
+	*ok = !is_err(r);
+	return r;
+}
+
 // one stream of a chunk -> its bytes; blocks are decoded by `nthreads` workers
 int stream_bytes(const uint8_t *img, const std::vector<Block> &blocks, unsigned lc, unsigned lp, unsigned pb, int nthreads,
 		 std::vector<uint8_t> *out)
@@ -95,6 +121,11 @@ int stream_bytes(const uint8_t *img, const std::vector<Block> &blocks, unsigned 
 					memcpy(out->data() + at[i], img + b.off, b.c_len);
 			} else if (b.c_type == 6) {
 				if (lzma_decode_block(img + b.off, b.c_len, out->data() + at[i], b.u_len, lc, lp, pb) != 0)
+					err = LRZGPU_E_FORMAT;
+			} else if (b.c_type == 10) {
+				bool ok = false;
+				const size_t r = zstd_decompress(out->data() + at[i], b.u_len, img + b.off, b.c_len, &ok);
+				if (!ok || r != b.u_len)
 					err = LRZGPU_E_FORMAT;
 			} else
 				err = LRZGPU_E_PARAM; // other back ends are outside this library

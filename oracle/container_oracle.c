@@ -105,7 +105,7 @@ static void ob_val_at(struct outbuf *o, i64 pos, i64 v, int n)
 struct driver {
 	const lrzo_params *prm;
 	lrzo_lzma_fn lzma;
-	int level, threads, lz4_test;
+	int level, threads, lz4_test, zstd_level;
 	uint32_t dict_size;
 	i64 bufsize;
 
@@ -124,6 +124,9 @@ struct driver {
 	lrzo_file_stats *fs;
 };
 
+static size_t (*g_zstd_compress)(void *, size_t, const void *, size_t, int);
+void lrzo_set_zstd(size_t (*compress)(void *, size_t, const void *, size_t, int)) { g_zstd_compress = compress; }
+
 static void compress_block(struct driver *d, struct block *b)
 {
 	b->c_type = CTYPE_NONE;
@@ -132,6 +135,30 @@ static void compress_block(struct driver *d, struct block *b)
 		return;
 	if (d->lz4_test && !lrzo_lz4_compresses(b->buf, b->s_len, d->prm->threshold))
 		return;
+	if (d->prm->zstd) { /* zstd_compress_buf, src/stream.c:167-230 */
+		size_t dlen = (size_t)round_up_page(b->s_len), r;
+		uchar *c_buf = malloc(dlen);
+		if (!c_buf || !g_zstd_compress)
+			abort();
+		r = g_zstd_compress(c_buf, dlen, b->buf, (size_t)b->s_len, d->zstd_level);
+		if (r > (size_t)-200) { /* ZSTD_isError */
+			if ((size_t)0 - r != 70) { /* only dstSize_tooSmall means "incompressible" */
+				fprintf(stderr, "oracle: ZSTD_compress failed %zu\n", (size_t)0 - r);
+				abort();
+			}
+			free(c_buf);
+			return;
+		}
+		if ((i64)r >= b->c_len) {
+			free(c_buf);
+			return;
+		}
+		free(b->buf);
+		b->buf = c_buf;
+		b->c_len = (i64)r;
+		b->c_type = 10; /* CTYPE_ZSTD */
+		return;
+	}
 	{
 		size_t dlen = (size_t)round_up_page((i64)(size_t)(b->s_len * 1.02));
 		size_t prop_size = 5;
@@ -245,7 +272,7 @@ static void make_plan(const lrzo_params *prm, i64 n, struct plan_out *po)
 {
 	struct { int threads, level; uint32_t dict_size; i64 bufsize; } d;
 	i64 maxram, usable_ram, max_mmap, max_chunk, overhead, limit;
-	const int lzma_on = !prm->no_compress;
+	const int lzma_on = !prm->no_compress && !prm->zstd;
 	d.level = prm->compression_level;
 	/* setup_overhead / setup_ram */
 	d.dict_size = prm->dict_size ? prm->dict_size : dict_for_level(d.level);
@@ -345,7 +372,7 @@ int lrzo_compress_buffer(const lrzo_params *prm, const uchar *in, i64 n, lrzo_lz
 	lrzo_md5 md5;
 	uint64_t hx[256];
 	i64 victim_round = 0;
-	int rzip_level, lzma_on, nworkers, w;
+	int rzip_level, lzma_on, nworkers, w, zstd_strategy = 0;
 	pthread_t *tids;
 	i64 max_chunk, len, *chunk_sizes = NULL, nchunks = 0;
 	int *chunk_cbytes = NULL;
@@ -357,10 +384,30 @@ int lrzo_compress_buffer(const lrzo_params *prm, const uchar *in, i64 n, lrzo_lz
 	d.fs = &lfs;
 	d.level = prm->compression_level;
 	rzip_level = prm->rzip_level ? prm->rzip_level : prm->compression_level;
-	lzma_on = !prm->no_compress;
+	lzma_on = !prm->no_compress && !prm->zstd;
 	d.lz4_test = prm->lz4_test && !prm->no_compress; /* src/main.c:858-861 */
 	if (lzma_on && !lzma)
 		return -1;
+	if (prm->zstd && !prm->no_compress) {
+		/* zstd level <-> strategy <-> rzip level: src/main.c:87, 692-711, 822-828 */
+		static const int by_level[10] = {-1, 2, 4, 5, 7, 12, 15, 17, 18, 22};
+		if (!g_zstd_compress)
+			return -1;
+		if (prm->zstd_level) {
+			int st;
+			d.zstd_level = prm->zstd_level;
+			for (st = 1; st <= 9; st++)
+				if (d.zstd_level <= by_level[st]) {
+					zstd_strategy = st;
+					if (!prm->rzip_level)
+						rzip_level = st;
+					break;
+				}
+		} else {
+			d.zstd_level = by_level[d.level];
+			zstd_strategy = d.level;
+		}
+	}
 
 	{
 		struct plan_out po;
@@ -503,7 +550,10 @@ int lrzo_compress_buffer(const lrzo_params *prm, const uchar *in, i64 n, lrzo_lz
 				magic[6 + i] = (uchar)((uint64_t)n >> (8 * i));
 		}
 		magic[14] = 1; /* MD5 */
-		if (lzma_on) {
+		if (prm->zstd && !prm->no_compress) { /* src/lrzip.c:177-183 */
+			magic[17] = (uchar)((zstd_strategy << 4) + 4);
+			magic[18] = (uchar)d.zstd_level;
+		} else if (lzma_on) {
 			magic[17] = 1;
 			magic[18] = (uchar)lzma2_prop_from_dic(d.dict_size);
 		}

@@ -117,7 +117,12 @@ typedef struct {
 	uint32_t dict_size;        /* 0 => by level */
 	int workers;               /* oracle-side worker threads for block compression (timing only) */
 	int verbose;
+	int zstd;                  /* --zstd back end (src/stream.c:167-230) instead of LZMA */
+	int zstd_level;            /* --zstd-level 1..22, 0 = from -L (src/main.c:87, 692-711, 822-828) */
 } lrzo_params;
+/* ZSTD_compress of the host's libzstd (the oracle has no zstd of its own: the reference links the
+ * system library too, so parity is against the same build). */
+void lrzo_set_zstd(size_t (*compress)(void *, size_t, const void *, size_t, int));
 void lrzo_params_default(lrzo_params *p);
 
 /* LzmaCompress-compatible callback (oracle/_ref or any other). */

@@ -29,12 +29,33 @@ def _lzma_raw(payload, u_len, dict_size):
     return out
 
 
+_ZSTD = None
+
+
+def _zstd_raw(payload, u_len):
+    """zstd blocks of --zstd files: the system libzstd through ctypes."""
+    global _ZSTD
+    import ctypes as C
+    if _ZSTD is None:
+        _ZSTD = C.CDLL("libzstd.so.1")
+        _ZSTD.ZSTD_decompress.restype = C.c_size_t
+        _ZSTD.ZSTD_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        _ZSTD.ZSTD_isError.argtypes = [C.c_size_t]
+    out = C.create_string_buffer(u_len if u_len else 1)
+    src = bytes(payload)
+    r = _ZSTD.ZSTD_decompress(out, u_len, src, len(src))
+    if _ZSTD.ZSTD_isError(r) or r != u_len:
+        raise ValueError("zstd block failed to decode to %d bytes" % u_len)
+    return out.raw[:u_len]
+
+
 def parse(lrz):
     """-> (header dict, [chunk dict]) with every block located but not yet decoded."""
     buf = memoryview(lrz)
     if bytes(buf[:4]) != b"LRZI" or buf[4] != 0 or buf[5] != 14:
         raise ValueError("not an lrzip-next 0.14 file")
-    hdr = {"st_size": _val(buf, 6, 8), "md5": buf[14] == 1, "lzma": buf[17] == 1,
+    hdr = {"st_size": _val(buf, 6, 8), "md5": buf[14] == 1, "lzma": buf[17] == 1, "zstd": (buf[17] & 15) == 4,
+           "zstd_strategy": buf[17] >> 4, "zstd_level": buf[18] if (buf[17] & 15) == 4 else 0,
            "dict_size": _dict_size(buf[18]) if buf[17] == 1 else 0, "levels": buf[19], "comment": buf[20]}
     pos = 21 + hdr["comment"]
     chunks = []
@@ -77,6 +98,8 @@ def _stream_bytes(buf, blocks, dict_size, pool):
             return bytes(buf[off:off + c_len])
         if c_type == 6:
             return _lzma_raw(buf[off:off + c_len], u_len, dict_size)
+        if c_type == 10:
+            return _zstd_raw(buf[off:off + c_len], u_len)
         raise ValueError("block type %d is outside this decoder" % c_type)
     return b"".join(pool.map(one, blocks))
 

@@ -25,7 +25,7 @@ class Params(C.Structure):
     _fields_ = [("compression_level", C.c_int), ("rzip_level", C.c_int), ("no_compress", C.c_int),
                 ("threads", C.c_int), ("processors", C.c_int), ("ramsize", C.c_int64), ("window", C.c_int64),
                 ("lz4_test", C.c_int), ("threshold", C.c_int), ("nobemt", C.c_int), ("dict_size", C.c_uint32),
-                ("workers", C.c_int), ("verbose", C.c_int)]
+                ("workers", C.c_int), ("verbose", C.c_int), ("zstd", C.c_int), ("zstd_level", C.c_int)]
 
 
 class FileStats(C.Structure):
@@ -184,7 +184,11 @@ def compress_buffer(data: bytes, **kw):
             raise KeyError(k)
         setattr(p, k, v)
     fn = None
-    if not p.no_compress:
+    if p.zstd and not p.no_compress:
+        z = C.CDLL("libzstd.so.1")  # the system library, as the reference links it
+        L.lrzo_set_zstd.argtypes = [C.c_void_p]
+        L.lrzo_set_zstd(C.cast(z.ZSTD_compress, C.c_void_p))
+    elif not p.no_compress:
         R = ref_lzma()
         fn = C.cast(R.LzmaCompress, C.c_void_p)
     out = C.POINTER(C.c_ubyte)()

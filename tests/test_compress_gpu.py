@@ -15,7 +15,8 @@ RAM = 80 * 100 << 20
 def _both(B, O, data, **kw):
     okw = dict(compression_level=kw.get("level", 7), threads=kw.get("threads", 1), processors=kw.get("processors", 1),
                ramsize=kw.get("ramsize", RAM), window=kw.get("window", 0), no_compress=int(kw.get("no_compress", False)),
-               lz4_test=int(kw.get("lz4_test", True)), threshold=kw.get("threshold", 100), workers=8)
+               lz4_test=int(kw.get("lz4_test", True)), threshold=kw.get("threshold", 100), workers=8,
+               zstd=int(kw.get("zstd", False)), zstd_level=kw.get("zstd_level", 0))
     want, fs = O.compress_buffer(data, **okw)
     got, ctl = B.compress_buffer(data, host_threads=8, **kw)
     assert ctl.stream_bufsize == fs.stream_bufsize and ctl.dictSize_used == fs.dict_size
@@ -171,3 +172,15 @@ def test_pipe_input_and_output(B, O):
     t1.join()
     t2.join()
     assert rc == 0 and bytes(got) == want
+
+
+@pytest.mark.parametrize("zl", [0, 1, 15, 22])
+def test_zstd_backend(B, O, zl):
+    """--zstd (BASELINE config 4's back end): rzip scan + lz4 gate on the GPU, blocks through the host's
+    libzstd like the reference (src/stream.c:167-230), c_type 10, strategy/level in the magic,
+    --zstd-level driving the rzip level (src/main.c:692-711)."""
+    for kind, n in (("text", 3 * 1048576 + 5), ("longrange", 6 * 1048576), ("random", 1 << 20)):
+        data = datagen.KINDS[kind](n, seed=40 + zl)
+        _both(B, O, data, level=6, threads=3, processors=8, zstd=True, zstd_level=zl)
+        img, _ = B.compress_buffer(data, level=6, threads=3, processors=8, ramsize=RAM, host_threads=8, zstd=True, zstd_level=zl)
+        assert B.decompress_buffer(img) == data

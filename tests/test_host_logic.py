@@ -39,16 +39,16 @@ def test_plan_equals_oracle_sizing(B, O, st_size):
         for threads, procs in ((1, 1), (4, 8), (8, 8), (64, 256), (256, 256)):
             for ram in (80 * 100 << 20, 16 << 30, 3000 << 30):
                 for window in (0, 1, 21):
-                    for nc in (False, True):
+                    for nc, zs in ((False, False), (True, False), (False, True)):
                         c, chunk = B.plan(st_size, level=level, threads=threads, processors=procs, ramsize=ram,
-                                          window=window, no_compress=nc)
+                                          window=window, no_compress=nc, zstd=zs)
                         p = O.Params()
                         O.lib().lrzo_params_default(ctypes.byref(p))
                         p.compression_level, p.threads, p.processors, p.ramsize = level, threads, procs, ram
-                        p.window, p.no_compress = window, int(nc)
+                        p.window, p.no_compress, p.zstd = window, int(nc), int(zs)
                         fs = O.FileStats()
                         O.lib().lrzo_plan(ctypes.byref(p), st_size, ctypes.byref(fs))
-                        key = (st_size, level, threads, procs, ram, window, nc)
+                        key = (st_size, level, threads, procs, ram, window, nc, zs)
                         assert c.stream_bufsize == fs.stream_bufsize, key
                         assert c.threads_used == fs.threads_used and c.dictSize_used == fs.dict_size, key
 

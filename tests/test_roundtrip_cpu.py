@@ -75,3 +75,15 @@ def test_file_info_and_decompress_file(B, O, tmp_path):
     src.write_bytes(img)
     B.decompress_file(str(src), str(dst))
     assert dst.read_bytes() == data
+
+
+@pytest.mark.parametrize("zl", [0, 3, 15, 19])
+def test_zstd_images_decode(B, O, zl):
+    """--zstd back end (system libzstd): oracle image -> both decoders; magic carries strategy and level."""
+    data = datagen.long_range(2 * 1048576 + 99, seed=8) + datagen.text_like(1 << 20, seed=9)
+    img, fs = O.compress_buffer(data, compression_level=6, threads=4, processors=4, ramsize=RAM, zstd=1, zstd_level=zl)
+    hdr, chunks = lrz_decode.parse(img)
+    assert hdr["zstd"] and not hdr["lzma"] and hdr["zstd_level"] == (zl or 15)
+    assert any(b[0] == 10 for c in chunks for s in c["streams"] for b in s)
+    assert bytes(lrz_decode.decode(img)) == data
+    assert B.decompress_buffer(img, host_threads=4) == data

@@ -20,6 +20,9 @@ def _case(seed):
               lz4_test=r.random() < 0.8, threshold=r.choice([100, 100, 95, 80, 50]))
     if r.random() < 0.15:
         kw["no_compress"] = True
+    elif r.random() < 0.15:
+        kw["zstd"] = True
+        kw["zstd_level"] = r.choice([0, 0, 1, 5, 12, 19, 22])
     return kind, n, kw
 
 
@@ -28,7 +31,8 @@ def test_random_parameters(B, O, seed):
     kind, n, kw = _case(seed)
     data = datagen.KINDS[kind](n, seed=seed)
     okw = dict(compression_level=kw["level"], threads=kw["threads"], processors=kw["processors"], ramsize=RAM,
-               no_compress=int(kw.get("no_compress", False)), lz4_test=int(kw["lz4_test"]), threshold=kw["threshold"], workers=8)
+               no_compress=int(kw.get("no_compress", False)), lz4_test=int(kw["lz4_test"]), threshold=kw["threshold"], workers=8,
+               zstd=int(kw.get("zstd", False)), zstd_level=kw.get("zstd_level", 0))
     want, fs = O.compress_buffer(data, **okw)
     got, ctl = B.compress_buffer(data, ramsize=RAM, host_threads=8, **kw)
     assert ctl.stream_bufsize == fs.stream_bufsize and ctl.dictSize_used == fs.dict_size, (kind, n, kw)
