@@ -194,6 +194,10 @@ def _take(out, olen):
     return res
 
 
+_LIBC_FREE = C.CDLL(None).free
+_LIBC_FREE.argtypes = [C.c_void_p]
+
+
 class LrzBuffer:
     """The malloc()ed .lrz image a compress call returned, without a copy into Python bytes."""
 
@@ -211,11 +215,14 @@ class LrzBuffer:
 
     def free(self):
         if self._ptr is not None:
-            C.CDLL(None).free(self._ptr)
+            _LIBC_FREE(self._ptr)
             self._ptr = None
 
     def __del__(self):
-        self.free()
+        try:
+            self.free()
+        except Exception:  # interpreter shutdown: the process is going away anyway
+            pass
 
 
 def compress_buffer(data: bytes, **kw):
