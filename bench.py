@@ -190,7 +190,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: liblrzgpu has no CPU fallback")
 
     cores = os.cpu_count() or 1
-    threads = args.threads or max(1, cores // world)
+    threads = args.threads or cores  # -p as the reference defaults it on this host, the same at every N
     phys = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
     ctl_kw = dict(level=7, threads=threads, processors=cores, ramsize=phys)
     usable = usable_cpus()
