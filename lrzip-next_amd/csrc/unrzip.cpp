@@ -12,7 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <future>
+#include <memory>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -143,7 +144,20 @@ int stream_bytes(const uint8_t *img, const std::vector<Block> &blocks, unsigned 
 
 } // namespace
 
+static int decompress_impl(const uint8_t *img, int64_t n, uint8_t **out, int64_t *out_len, int host_threads);
+
 extern "C" int lrzgpu_decompress_buffer(const uint8_t *img, int64_t n, uint8_t **out, int64_t *out_len, int host_threads)
+{
+	try { // the image is untrusted input: absurd sizes in its headers must not escape as C++ exceptions
+		return decompress_impl(img, n, out, out_len, host_threads);
+	} catch (const std::bad_alloc &) {
+		return LRZGPU_E_NOMEM;
+	} catch (...) {
+		return LRZGPU_E_INTERNAL;
+	}
+}
+
+static int decompress_impl(const uint8_t *img, int64_t n, uint8_t **out, int64_t *out_len, int host_threads)
 {
 	if (!img || !out || !out_len || n < 21 + 2)
 		return LRZGPU_E_PARAM;
@@ -157,7 +171,11 @@ extern "C" int lrzgpu_decompress_buffer(const uint8_t *img, int64_t n, uint8_t *
 		return LRZGPU_E_PARAM; // other hashes
 	const unsigned lc = 3, lp = 0, pb = 2; // LZMA_LC/LP/PB of src/stream.c:450-456
 	size_t pos = 21 + img[20];
-	uint8_t *dst = (uint8_t *)malloc(st_size ? st_size : 1);
+	struct FreeDeleter {
+		void operator()(uint8_t *p) const { free(p); }
+	};
+	std::unique_ptr<uint8_t, FreeDeleter> dst_owner((uint8_t *)malloc(st_size ? st_size : 1));
+	uint8_t *dst = dst_owner.get();
 	if (!dst)
 		return LRZGPU_E_NOMEM;
 	if (host_threads <= 0)
@@ -290,11 +308,9 @@ extern "C" int lrzgpu_decompress_buffer(const uint8_t *img, int64_t n, uint8_t *
 		}
 	} else if (!rc && pos != (size_t)n)
 		rc = LRZGPU_E_FORMAT;
-	if (rc) {
-		free(dst);
+	if (rc)
 		return rc;
-	}
-	*out = dst;
+	*out = dst_owner.release();
 	*out_len = (int64_t)st_size;
 	return 0;
 }
