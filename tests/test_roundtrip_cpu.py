@@ -87,3 +87,32 @@ def test_zstd_images_decode(B, O, zl):
     assert any(b[0] == 10 for c in chunks for s in c["streams"] for b in s)
     assert bytes(lrz_decode.decode(img)) == data
     assert B.decompress_buffer(img, host_threads=4) == data
+
+
+def test_library_decoder_survives_fuzz(B, O):
+    """400 random mutations (flips, truncations, inserted junk) of small images: every call returns
+    an error or the exact original -- never a crash, never different bytes."""
+    import random
+    data = datagen.long_range(200000, seed=12) + datagen.text_like(100000, seed=13)
+    imgs = [O.compress_buffer(data, compression_level=lvl, threads=2, processors=2, ramsize=RAM)[0] for lvl in (3, 7)]
+    imgs.append(O.compress_buffer(data, compression_level=5, threads=2, processors=2, ramsize=RAM, zstd=1)[0])
+    r = random.Random(2024)
+    for k in range(400):
+        img = bytearray(r.choice(imgs))
+        kind = r.randrange(4)
+        if kind == 0:
+            for _ in range(r.randrange(1, 4)):
+                img[r.randrange(len(img))] ^= 1 << r.randrange(8)
+        elif kind == 1:
+            img = img[:r.randrange(len(img))]
+        elif kind == 2:
+            pos = r.randrange(len(img))
+            img[pos:pos] = bytes(r.randrange(256) for _ in range(r.randrange(1, 9)))
+        else:
+            pos = r.randrange(21, len(img))
+            img[pos:pos + 8] = (r.getrandbits(64)).to_bytes(8, "little")
+        try:
+            out = B.decompress_buffer(bytes(img), host_threads=2)
+        except RuntimeError:
+            continue
+        assert out == data, k
