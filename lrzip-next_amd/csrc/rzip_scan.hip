@@ -1116,10 +1116,14 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 						}
 						u64 E = 0, S = 0, Q = 0; // bit q: slot idx + q is empty / stops my insert / may hold my tag
 #pragma unroll
-						for (int c = 3; c >= 0; c--) {
-							E = (E << 16) | (flags_to_bits(bytes_lt(r4[c].b, B01)) << 8) | flags_to_bits(bytes_lt(r4[c].a, B01));
-							S = (S << 16) | (flags_to_bits(bytes_lt(r4[c].b, thr8)) << 8) | flags_to_bits(bytes_lt(r4[c].a, thr8));
-							Q = (Q << 16) | (flags_to_bits(bytes_eq(f4[c].b, fp8)) << 8) | flags_to_bits(bytes_eq(f4[c].a, fp8));
+						for (int c = 0; c < 4; c++) {
+							E |= (u64)((flags_to_bits(bytes_lt(r4[c].b, B01)) << 8) | flags_to_bits(bytes_lt(r4[c].a, B01))) << (16 * c);
+							S |= (u64)((flags_to_bits(bytes_lt(r4[c].b, thr8)) << 8) | flags_to_bits(bytes_lt(r4[c].a, thr8))) << (16 * c);
+							Q |= (u64)((flags_to_bits(bytes_eq(f4[c].b, fp8)) << 8) | flags_to_bits(bytes_eq(f4[c].a, fp8))) << (16 * c);
+							// loose masks mean short clusters: stop evaluating once every walking lane has met
+							// its first empty slot (two for a twin, whose lookup may walk on past the first)
+							if (c < 3 && !__ballot(tw ? __popcll(E) < 2 : E == 0))
+								break;
 						}
 						steps += 64;
 						if (idx + 64 > tbl_size || steps > A1_MAX_STEPS) {
