@@ -1319,9 +1319,11 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 							}
 							u64 S2 = 0, Q2 = 0;
 #pragma unroll
-							for (int c = 3; c >= 0; c--) {
-								S2 = (S2 << 16) | (flags_to_bits(bytes_lt(r4[c].b, thr2_8)) << 8) | flags_to_bits(bytes_lt(r4[c].a, thr2_8));
-								Q2 = (Q2 << 16) | (flags_to_bits(bytes_eq(f4[c].b, fp2_8)) << 8) | flags_to_bits(bytes_eq(f4[c].a, fp2_8));
+							for (int c = 0; c < 4; c++) {
+								S2 |= (u64)((flags_to_bits(bytes_lt(r4[c].b, thr2_8)) << 8) | flags_to_bits(bytes_lt(r4[c].a, thr2_8))) << (16 * c);
+								Q2 |= (u64)((flags_to_bits(bytes_eq(f4[c].b, fp2_8)) << 8) | flags_to_bits(bytes_eq(f4[c].a, fp2_8))) << (16 * c);
+								if (c < 3 && !__ballot(S2 == 0))
+									break; // every walking lane has its stop
 							}
 							st2 += 64;
 							if (j + 64 > tbl_size || st2 > A1_MAX_STEPS || r2 >= 63) {
