@@ -1246,7 +1246,8 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 			// value) goes to the serial path
 			if (__ballot(need_sim && tw && tw_hit && !L.complex_)) {
 				if (need_sim && tw && tw_hit && !L.complex_) {
-					if (lane_verify(buf, P, P_prev, R.end, R.last_match))
+					// (independent 8-byte looks first: text twins differ right there)
+					if (!quick_reject(buf, P, P_prev, R.end, R.last_match) && lane_verify(buf, P, P_prev, R.end, R.last_match))
 						L.complex_ = true;
 					else
 						L.misses++;
