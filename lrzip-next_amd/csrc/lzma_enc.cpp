@@ -58,6 +58,23 @@ const uint8_t kShortRepNext[kNumStates] = {9, 9, 9, 9, 9, 9, 9, 11, 11, 11, 11, 
 constexpr unsigned kStateLitAfterMatch = 4, kStateLitAfterRep = 5, kStateMatchAfterLit = 7, kStateRepAfterLit = 8;
 
 inline bool is_lit_state(unsigned s) { return s < 7; }
+// first index in [from, limit) where a[] and b[] differ (limit if none): eight bytes per step
+inline unsigned mismatch_from(const uint8_t *a, const uint8_t *b, unsigned from, unsigned limit)
+{
+	unsigned i = from;
+	while (i + 8 <= limit) {
+		uint64_t x, y;
+		memcpy(&x, a + i, 8);
+		memcpy(&y, b + i, 8);
+		x ^= y;
+		if (x)
+			return i + ((unsigned)__builtin_ctzll(x) >> 3);
+		i += 8;
+	}
+	while (i < limit && a[i] == b[i])
+		i++;
+	return i;
+}
 inline unsigned len_to_pos_state(unsigned len) { return len < kNumLenToPosStates + 1 ? len - 2 : kNumLenToPosStates - 1; }
 
 inline unsigned pos_slot(uint32_t d)
@@ -594,8 +611,7 @@ struct Encoder {
 					continue;
 				}
 				unsigned len;
-				for (len = 2; len < navail && d[len] == d2[len]; len++) {
-				}
+				len = mismatch_from(d, d2, 2, navail);
 				rep_lens[i] = len;
 				if (len > rep_lens[rep_max])
 					rep_max = i;
@@ -869,8 +885,7 @@ struct Encoder {
 					unsigned len, limit = fast_bytes + 1;
 					if (limit > navail_full)
 						limit = navail_full;
-					for (len = 3; len < limit && d[len] == d2[len]; len++) {
-					}
+					len = mismatch_from(d, d2, 3, limit);
 					unsigned st2 = kLitNext[st];
 					unsigned ps2 = (position + 1) & pb_mask;
 					uint32_t pr = lit_pr + price_rep0(st2, ps2);
@@ -897,8 +912,7 @@ struct Encoder {
 				if (d[0] != d2[0] || d[1] != d2[1])
 					continue;
 				unsigned len;
-				for (len = 2; len < navail && d[len] == d2[len]; len++) {
-				}
+				len = mismatch_from(d, d2, 2, navail);
 				{
 					unsigned offset = cur + len;
 					if (last < offset)
@@ -937,8 +951,7 @@ struct Encoder {
 						st2 = kStateLitAfterRep;
 						ps2 = (ps2 + 1) & pb_mask;
 						pr += price_rep0(st2, ps2);
-						for (; l2 < limit && d[l2] == d2[l2]; l2++) {
-						}
+						l2 = mismatch_from(d, d2, l2, limit);
 						l2 -= len;
 						unsigned offset = cur + len + l2;
 						if (last < offset)
@@ -1006,8 +1019,7 @@ struct Encoder {
 							limit = navail_full;
 						l2 += 2;
 						if (l2 <= limit && d[l2 - 2] == d2[l2 - 2] && d[l2 - 1] == d2[l2 - 1]) {
-							for (; l2 < limit && d[l2] == d2[l2]; l2++) {
-							}
+							l2 = mismatch_from(d, d2, l2, limit);
 							l2 -= len;
 							unsigned st2 = kMatchNext[st];
 							unsigned ps2 = (position + len) & pb_mask;
@@ -1073,8 +1085,7 @@ struct Encoder {
 			if (d[0] != d2[0] || d[1] != d2[1])
 				continue;
 			unsigned len;
-			for (len = 2; len < navail && d[len] == d2[len]; len++) {
-			}
+			len = mismatch_from(d, d2, 2, navail);
 			if (len >= fast_bytes) {
 				back_res = i;
 				move_pos(len - 1);
