@@ -86,3 +86,36 @@ def test_hash_index_frozen_table(B, O):
     a = (C.c_uint64 * 256)()
     B.lib().lrzgpu_hash_index(a)
     assert list(a) == O.hash_index()
+
+
+def test_ctypes_mirrors_match_the_header(B, tmp_path):
+    """The Python mirrors of the ABI structs (bindings.py, bench.py) have the sizes and field offsets the
+    C header gives them (compiled here with gcc)."""
+    import ctypes as C
+    import importlib.util
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "sz.c"
+    src.write_text('''#include <stdio.h>
+#include <stddef.h>
+#include "lrzgpu.h"
+int main(void) {
+  printf("%zu %zu %zu %zu\\n", sizeof(lrzgpu_control), sizeof(lrzgpu_profile), sizeof(lrzgpu_info), sizeof(lrzgpu_scan_stats));
+  printf("%zu %zu %zu %zu %zu\\n", offsetof(lrzgpu_control, ramsize), offsetof(lrzgpu_control, st_size),
+         offsetof(lrzgpu_control, stream_bufsize), offsetof(lrzgpu_control, zstd_level), offsetof(lrzgpu_profile, resolve_dbg));
+  printf("%zu %zu\\n", offsetof(lrzgpu_profile, spec_cancelled_blocks), offsetof(lrzgpu_info, stream_u_len));
+  return 0; }''')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    lines = subprocess.check_output([str(exe)]).decode().split("\n")
+    spec = importlib.util.spec_from_file_location("lrz_bench_abi", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sizes = [int(x) for x in lines[0].split()]
+    assert sizes == [C.sizeof(B.Control), C.sizeof(bench.Profile), C.sizeof(B.Info), C.sizeof(B.ScanStats)]
+    offs = [int(x) for x in lines[1].split()]
+    assert offs == [B.Control.ramsize.offset, B.Control.st_size.offset, B.Control.stream_bufsize.offset,
+                    B.Control.zstd_level.offset, bench.Profile.resolve_dbg.offset]
+    offs = [int(x) for x in lines[2].split()]
+    assert offs == [bench.Profile.spec_cancelled_blocks.offset, B.Info.stream_u_len.offset]
