@@ -108,6 +108,10 @@ int lrzgpu_lz4_compresses(const uint8_t *s_buf, int64_t s_len, int threshold, in
 int lrzgpu_lz4_compresses_dev(const void *d_buf, int64_t s_len, int threshold, int device);
 /* LZ4_compress_default(src, dst, srcSize, dstCapacity) return value (liblz4 1.9.3), size only. */
 int lrzgpu_lz4_compress_default_size(const uint8_t *src, int src_size, int dst_capacity, int device);
+/* The same with the early verdict the pipeline uses: the exact size, or -- as soon as "size <
+ * stop_below" is certain (what is left costs at most rest + rest/255 + 16 bytes) -- an upper bound of
+ * the size that is itself below stop_below. */
+int lrzgpu_lz4_size_stop_below(const uint8_t *src, int src_size, int dst_capacity, int stop_below, int device);
 
 /* ---- LZMA backend -----------------------------------------------------------------------------
  * LzmaCompress() -- src/lzma/include/LzmaLib.h:95-112, same arguments and SRes codes

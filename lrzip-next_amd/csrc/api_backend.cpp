@@ -41,9 +41,9 @@ int select_device(int device)
 
 // ---- lz4 gate: src/stream.c:2325-2380 -------------------------------------------------------
 
-static int lz4_size_dev(const uint8_t *d_src, int src_size, int dst_capacity)
+static int lz4_size_dev(const uint8_t *d_src, int src_size, int dst_capacity, int stop_below = 0)
 {
-	Lz4Job job{d_src, src_size, dst_capacity}, *d_job = nullptr;
+	Lz4Job job{d_src, src_size, dst_capacity, stop_below}, *d_job = nullptr;
 	int *d_res = nullptr, res = -1;
 	if (hipMalloc(&d_job, sizeof(job)) != hipSuccess)
 		return LRZGPU_E_NOMEM;
@@ -98,7 +98,19 @@ extern "C" int lrzgpu_lz4_compresses(const uint8_t *s_buf, int64_t s_len, int th
 	return v;
 }
 
+static int lz4_size_host(const uint8_t *src, int src_size, int dst_capacity, int stop_below, int device);
+
 extern "C" int lrzgpu_lz4_compress_default_size(const uint8_t *src, int src_size, int dst_capacity, int device)
+{
+	return lz4_size_host(src, src_size, dst_capacity, 0, device);
+}
+
+extern "C" int lrzgpu_lz4_size_stop_below(const uint8_t *src, int src_size, int dst_capacity, int stop_below, int device)
+{
+	return lz4_size_host(src, src_size, dst_capacity, stop_below > 0 ? stop_below : 0, device);
+}
+
+static int lz4_size_host(const uint8_t *src, int src_size, int dst_capacity, int stop_below, int device)
 {
 	int rc = select_device(device);
 	if (rc)
@@ -112,7 +124,7 @@ extern "C" int lrzgpu_lz4_compress_default_size(const uint8_t *src, int src_size
 		(void)hipFree(d);
 		return LRZGPU_E_HIP;
 	}
-	int v = lz4_size_dev(d, src_size, dst_capacity);
+	int v = lz4_size_dev(d, src_size, dst_capacity, stop_below);
 	(void)hipFree(d);
 	return v;
 }

@@ -82,6 +82,8 @@ void lrzo_md5_final(lrzo_md5 *m, uchar out[16]);
 /* liblz4 1.9.3 LZ4_compress_default(src,dst,srcSize,dstCapacity) return value
  * (compressed size, 0 on failure), without producing the bytes. */
 int lrzo_lz4_compress_default_size(const uchar *src, int src_size, int dst_capacity);
+/* same with the early verdict of the GPU gate (see lz4_oracle.c) */
+int lrzo_lz4_size_stop_below(const uchar *src, int src_size, int dst_capacity, int stop_below, int *stopped_early);
 /* reference src/stream.c:2325-2380 lz4_compresses: 0 = skip backend, else pct. */
 int lrzo_lz4_compresses(const uchar *s_buf, i64 s_len, int threshold);
 

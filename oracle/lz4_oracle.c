@@ -45,7 +45,7 @@ static inline unsigned count_eq(const uchar *a, const uchar *b, const uchar *ali
 	return (unsigned)(a - s);
 }
 
-int lrzo_lz4_compress_default_size(const uchar *src, int src_size, int dst_capacity)
+static int lz4_size_impl(const uchar *src, int src_size, int dst_capacity, int stop_below, int *stopped_early)
 {
 	/* all positions are offsets from src; op is the output byte count */
 	uint32_t table[1 << (LZ4_HASHLOG + 1)];
@@ -126,6 +126,18 @@ int lrzo_lz4_compress_default_size(const uchar *src, int src_size, int dst_capac
 				op += (mc - ML_MASK) / 255 + 1;
 		}
 		anchor = ip;
+		if (stop_below > 0) {
+			/* what is left can cost at most rest + rest/255 + 16 bytes (the LZ4_compressBound
+			 * argument applied to the suffix): once that is below the caller's bound the verdict
+			 * "smaller than stop_below" is certain */
+			i64 rest = (i64)(iend - anchor);
+			i64 ub = op + rest + rest / 255 + 16;
+			if (ub < (i64)stop_below) {
+				if (stopped_early)
+					*stopped_early = 1;
+				return (int)ub;
+			}
+		}
 		if (ip >= mflimit_plus_one)
 			break;
 		table[hash_pos(ip - 2, by_u16)] = (uint32_t)(ip - 2 - src);
@@ -184,4 +196,19 @@ int lrzo_lz4_compresses(const uchar *s_buf, i64 s_len, int threshold)
 		}
 	}
 	return (int)(pct > threshold ? 0 : pct < 1 ? pct + 1 : pct);
+}
+
+int lrzo_lz4_compress_default_size(const uchar *src, int src_size, int dst_capacity)
+{
+	return lz4_size_impl(src, src_size, dst_capacity, 0, NULL);
+}
+
+/* The early-verdict variant the GPU gate uses in the pipeline (lz4_gate.hip, Lz4Job.stop_below):
+ * returns the exact size, or -- as soon as "size < stop_below" is certain -- an upper bound of the
+ * size that is itself below stop_below.  *stopped_early tells which. */
+int lrzo_lz4_size_stop_below(const uchar *src, int src_size, int dst_capacity, int stop_below, int *stopped_early)
+{
+	if (stopped_early)
+		*stopped_early = 0;
+	return lz4_size_impl(src, src_size, dst_capacity, stop_below, stopped_early);
 }

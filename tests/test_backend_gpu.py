@@ -131,3 +131,21 @@ def test_lz4_gate_decision(B, O):
             data = datagen.KINDS[kind](n, seed=7)
             for thr in (100, 90, 50):
                 assert B.lib().lrzgpu_lz4_compresses(data, n, thr, 0) == O.lib().lrzo_lz4_compresses(data, n, thr)
+
+
+def test_lz4_early_verdict_equals_oracle(B, O):
+    """The gate kernel's early exit returns exactly what the CPU restatement of the same rule returns
+    (same sequence boundaries, same bound), for bounds that trigger it and bounds that do not."""
+    import ctypes as C
+    LO, LG = O.lib(), B.lib()
+    LO.lrzo_lz4_size_stop_below.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    LG.lrzgpu_lz4_size_stop_below.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    for kind in ["text", "random", "few", "phrases", "sparse", "zeros"]:
+        for n in (13, 1000, 65546, 65547, 300000, 2000000):
+            data = datagen.KINDS[kind](n, seed=n % 71 + 4)
+            for frac in (1.0, 0.9, 0.5, 0.1):
+                bound = max(1, int(n * frac))
+                flag = C.c_int(0)
+                want = LO.lrzo_lz4_size_stop_below(data, n, n + 1, bound, C.byref(flag))
+                got = LG.lrzgpu_lz4_size_stop_below(data, n, n + 1, bound, 0)
+                assert got == want, (kind, n, bound, got, want, flag.value)

@@ -120,3 +120,34 @@ def test_lz4_oracle_against_system_liblz4(O):
             for cap in (n + 1, n, n // 2, n + n // 255 + 16):
                 dst = C.create_string_buffer(max(cap, 1))
                 assert O.lib().lrzo_lz4_compress_default_size(data, n, cap) == lz4.LZ4_compress_default(data, dst, n, cap)
+
+
+def test_lz4_early_verdict_bound(O):
+    """The gate's early exit claims: once out_so_far + rest + rest/255 + 16 < bound, the final LZ4 size
+    is below the bound too.  Checked on the CPU restatement over many inputs, sizes and bounds: an
+    early stop always returns a value >= the exact size and < the bound, and no early stop means the
+    exact size."""
+    import ctypes as C
+    import random
+    L = O.lib()
+    L.lrzo_lz4_size_stop_below.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    r = random.Random(7)
+    early = 0
+    for trial in range(600):
+        kind = r.choice(["text", "random", "few", "phrases", "sparse", "zeros", "longrange"])
+        n = r.choice([13, 64, 1000, 65546, 65547, r.randrange(2000, 300000)])
+        data = datagen.KINDS[kind](n, seed=trial)
+        if r.random() < 0.3:  # mixed: a compressible head and an incompressible tail, and the reverse
+            other = datagen.random_bytes(n, seed=trial + 1)
+            cut = r.randrange(n + 1)
+            data = (data[:cut] + other[cut:]) if r.random() < 0.5 else (other[:cut] + data[cut:])
+        exact = L.lrzo_lz4_compress_default_size(data, n, n + 1)
+        bound = max(1, int(n * r.choice([1.0, 1.0, 0.95, 0.8, 0.5, 0.2])))
+        flag = C.c_int(0)
+        got = L.lrzo_lz4_size_stop_below(data, n, n + 1, bound, C.byref(flag))
+        if flag.value:
+            early += 1
+            assert 0 < exact <= got < bound, (kind, n, bound, exact, got)
+        else:
+            assert got == exact, (kind, n, bound, exact, got)
+    assert early > 100
