@@ -58,6 +58,8 @@ typedef struct lrzgpu_control {
 	int threads_used;
 	/* --zstd only (input, appended here to keep the layout above stable) */
 	int zstd_level;             /* --zstd-level 1..22, 0 = from -L (src/main.c:87, 692-711, 822-828) */
+	/* execution (no influence on the bytes produced; appended) */
+	int scan_slots;             /* rzip chunks scanned concurrently on the GPU, 0 = default (8)      */
 } lrzgpu_control;
 
 void lrzgpu_control_init(lrzgpu_control *c); /* initialise_control() defaults, src/lrzip.c:1813-1857 */
@@ -77,6 +79,28 @@ int lrzgpu_compress_buffer(lrzgpu_control *control, const uint8_t *in, int64_t n
 
 /* Same, input already resident in HBM (d_in is a device pointer on control->device). */
 int lrzgpu_compress_buffer_dev(lrzgpu_control *control, const void *d_in, int64_t n, uint8_t **out, int64_t *out_len);
+
+/* ---- one file, one process per GPU ---------------------------------------------------------------
+ * rzip chunks are independent units of the format (own header, hash table, CRC, block offsets relative to
+ * the chunk: src/rzip.c:599-626, src/stream.c:1740-1770), so chunk k of a file goes to GPU k mod G.
+ * lrzgpu_compress_chunks* runs the whole path (scan, gate, LZMA blocks) for the chunks k with
+ * k % stride == first of the n-byte input and calls on_chunk once per finished chunk, in ascending k,
+ * with the chunk's bytes exactly as they stand in the file (chunk header, stream headers, chained
+ * blocks).  The one value that crosses a chunk boundary is insert_hash()'s static victim_round
+ * (src/rzip.c:308): victim_in[k] >= 0 gives the value chunk k starts from, victim_in == NULL or a
+ * negative entry lets the library predict it (what chunk k-1 left when this call scanned it, else 0);
+ * on_chunk reports the value used and the value left, so the caller that owns the file can check the
+ * chain victim_out[k-1] == victim_in[k] and ask again for a chunk whose guess was wrong.
+ * with_md5: also compute the MD5 of the whole input into control->hash_resblock (one caller does).
+ * lrzgpu_assemble_chunks (host only): magic + the chunk images in order + MD5 = the .lrz file. */
+typedef int (*lrzgpu_chunk_fn)(void *ctx, int chunk_index, int64_t victim_in, int64_t victim_out,
+			       const uint8_t *chunk_image, int64_t len);
+int lrzgpu_compress_chunks(lrzgpu_control *control, const uint8_t *in, int64_t n, int first, int stride,
+			   const int64_t *victim_in, int with_md5, lrzgpu_chunk_fn on_chunk, void *ctx);
+int lrzgpu_compress_chunks_dev(lrzgpu_control *control, const void *d_in, int64_t n, int first, int stride,
+			       const int64_t *victim_in, int with_md5, lrzgpu_chunk_fn on_chunk, void *ctx);
+int lrzgpu_assemble_chunks(lrzgpu_control *control, int64_t st_size, int n_chunks, const uint8_t *const *chunk_img,
+			   const int64_t *chunk_len, const uint8_t md5[16], uint8_t **out, int64_t *out_len);
 
 /* ---- rzip stage -------------------------------------------------------------------------------
  * hash_search(), src/rzip.c:586-762: scan one chunk resident in HBM.  Emits the two rzip streams
@@ -174,6 +198,8 @@ typedef struct lrzgpu_profile {
 	int64_t spec_rollbacks;       /* chunks whose early-released literal frontier a later match crossed
 	                                 (stream 1 rebuilt, early blocks discarded)              */
 	int64_t spec_cancelled_blocks; /* early-released blocks thrown away by those roll-backs   */
+	int64_t victim_rescans;       /* chunks scanned again because the victim_round they started from
+	                                 was not what their predecessor left (src/rzip.c:308)        */
 } lrzgpu_profile;
 void lrzgpu_profile_reset(void);
 void lrzgpu_profile_get(lrzgpu_profile *out);
@@ -202,6 +228,9 @@ typedef struct lrzgpu_info {
 int lrzgpu_file_info(const uint8_t *lrz, int64_t n, lrzgpu_info *info);
 
 /* ---- misc ------------------------------------------------------------------------------------- */
+/* Device workspaces, pinned and pageable host buffers are cached between calls (a compressor handles
+ * block after block, file after file); this returns all of it to the system. */
+void lrzgpu_trim(void);
 int lrzgpu_device_count(void);
 const char *lrzgpu_version(void);
 

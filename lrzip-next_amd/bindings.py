@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 # scan, gate and finder streams should not share hardware queues (effective only if HIP is not yet initialised)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liblrzgpu.so")
@@ -19,7 +19,8 @@ class Control(C.Structure):
                 ("flags", C.c_uint32), ("threshold", C.c_int), ("device", C.c_int), ("host_threads", C.c_int),
                 ("gpu_slots", C.c_int), ("verbose", C.c_int), ("st_size", C.c_int64),
                 ("hash_resblock", C.c_uint8 * 16), ("lzma_properties", C.c_uint8 * 5), ("dictSize_used", C.c_uint32),
-                ("stream_bufsize", C.c_int64), ("threads_used", C.c_int), ("zstd_level", C.c_int)]
+                ("stream_bufsize", C.c_int64), ("threads_used", C.c_int), ("zstd_level", C.c_int),
+                ("scan_slots", C.c_int)]
 
 
 class ScanStats(C.Structure):
@@ -71,8 +72,56 @@ def lib():
                                              C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_char_p),
                                              C.POINTER(C.c_int64), C.c_char_p, C.POINTER(C.POINTER(C.c_ubyte)),
                                              C.POINTER(C.c_int64)]
+        L.lrzgpu_compress_chunks.argtypes = [C.POINTER(Control), C.c_char_p, C.c_int64, C.c_int, C.c_int,
+                                             C.POINTER(C.c_int64), C.c_int, CHUNK_FN, C.c_void_p]
+        L.lrzgpu_compress_chunks_dev.argtypes = [C.POINTER(Control), C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                                 C.POINTER(C.c_int64), C.c_int, CHUNK_FN, C.c_void_p]
+        L.lrzgpu_assemble_chunks.argtypes = [C.POINTER(Control), C.c_int64, C.c_int, C.POINTER(C.c_char_p),
+                                             C.POINTER(C.c_int64), C.c_char_p, C.POINTER(C.POINTER(C.c_ubyte)),
+                                             C.POINTER(C.c_int64)]
+        L.lrzgpu_trim.restype = None
         _lib = L
     return _lib
+
+
+CHUNK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.POINTER(C.c_ubyte), C.c_int64)
+
+
+def compress_chunks(data=None, first=0, stride=1, victim_in=None, with_md5=False, dev_ptr=None, n=None, ctl=None, **kw):
+    """The chunks k % stride == first of one file through the whole path ->
+    ({chunk index: (victim_in, victim_out, chunk image bytes)}, Control).  data: host bytes, or dev_ptr + n."""
+    c = ctl if ctl is not None else make_control(**kw)
+    got = {}
+
+    def on_chunk(_ctx, idx, vin, vout, img, ln):
+        got[idx] = (vin, vout, C.string_at(img, ln) if ln < (1 << 31) - 1 else bytes(memoryview((C.c_ubyte * ln).from_address(C.addressof(img.contents))).cast("B")))
+        return 0
+
+    cb = CHUNK_FN(on_chunk)
+    vi = None
+    if victim_in is not None:
+        vi = (C.c_int64 * len(victim_in))(*victim_in)
+    if dev_ptr is not None:
+        rc = lib().lrzgpu_compress_chunks_dev(C.byref(c), C.c_void_p(dev_ptr), n, first, stride, vi, int(with_md5), cb, None)
+    else:
+        rc = lib().lrzgpu_compress_chunks(C.byref(c), data, len(data), first, stride, vi, int(with_md5), cb, None)
+    if rc != 0:
+        raise RuntimeError("lrzgpu_compress_chunks rc=%d" % rc)
+    return got, c
+
+
+def assemble_chunks(images, st_size, md5, ctl=None, **kw):
+    """magic + chunk images in order + MD5 -> .lrz bytes (host only)."""
+    c = ctl if ctl is not None else make_control(**kw)
+    k = len(images)
+    arr = (C.c_char_p * k)(*images)
+    lens = (C.c_int64 * k)(*[len(i) for i in images])
+    out = C.POINTER(C.c_ubyte)()
+    olen = C.c_int64()
+    rc = lib().lrzgpu_assemble_chunks(C.byref(c), st_size, k, arr, lens, bytes(md5), C.byref(out), C.byref(olen))
+    if rc != 0:
+        raise RuntimeError("lrzgpu_assemble_chunks rc=%d" % rc)
+    return _take(out, olen), c
 
 
 def chunk_bytes_for(n):
@@ -163,7 +212,7 @@ def lzma_compress(data: bytes, level=7, dict_size=1 << 25, fb=64, lc=3, lp=0, pb
 
 def make_control(level=7, rzip_level=0, threads=1, processors=1, ramsize=80 * 100 * 1048576, window=0, dict_size=0,
                  no_compress=False, lz4_test=True, threshold=100, nobemt=False, device=0, host_threads=0,
-                 gpu_slots=0, verbose=0, zstd=False, zstd_level=0):
+                 gpu_slots=0, verbose=0, zstd=False, zstd_level=0, scan_slots=0):
     c = Control()
     lib().lrzgpu_control_init(C.byref(c))
     c.compression_level = level
@@ -181,6 +230,7 @@ def make_control(level=7, rzip_level=0, threads=1, processors=1, ramsize=80 * 10
     c.gpu_slots = gpu_slots
     c.verbose = verbose
     c.zstd_level = zstd_level
+    c.scan_slots = scan_slots
     return c
 
 

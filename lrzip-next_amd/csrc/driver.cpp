@@ -1,21 +1,34 @@
 // driver.cpp -- whole-file compress driver: the rzip_fd() control flow (reference src/rzip.c:922-1264)
-// over the GPU stages, with the per-block back end pipelined between the GPU and host threads.
+// over the GPU stages, with chunks scanned concurrently and the per-block back end pipelined between
+// the GPU and host threads.
 //
-//   main thread      per chunk: K1/K2 scan segments.  After every segment the literal bytes that are
-//                    already decided are gathered (K4) and every stream-1 block they complete is
-//                    handed to the back end AT ONCE, so the back end runs under the scan -- the
+//   reader           one thread, chunk after chunk in file order: makes the chunk's bytes resident in HBM
+//                    (a view of a device buffer, or pread()/memcpy into pinned pieces + H2D) -- the
+//                    reference maps one chunk at a time (src/rzip.c:1057-1107)
+//   scanners         `scan_slots` threads, each with a scan stream + resolver workspace + gate streams.
+//                    rzip chunks are independent units of the format (own table, own CRC; src/rzip.c:
+//                    599-626); the resolver of one chunk is ONE wavefront, so several chunks are
+//                    resolved side by side on different CUs.  The only state that crosses a chunk boundary
+//                    is insert_hash()'s static victim_round (src/rzip.c:308): a chunk that starts before
+//                    its predecessor has finished assumes the value the predecessor is expected to leave
+//                    and is scanned again if that turns out wrong.
+//                    While a chunk is scanned the literal bytes that are already decided are gathered
+//                    (K4) and every stream-1 block they complete is handed to the back end AT ONCE -- the
 //                    reference overlaps the same way through flush_buffer() (src/rzip.c:229-246).
-//                    "Decided" = behind every emitted match, or more than SPEC_MARGIN behind the
-//                    scan position; a later match reaching back over such bytes is detected and
-//                    the chunk's early blocks are then thrown away and redone (not observed on the
-//                    bench workloads; tests force it with LRZGPU_SPEC_MARGIN / LRZGPU_SEG_BYTES).
+//                    "Decided" = behind every emitted match, or more than SPEC_MARGIN behind the scan
+//                    position; a later match reaching back over such bytes is detected and the chunk's
+//                    early blocks are then thrown away and redone (tests force it with
+//                    LRZGPU_SPEC_MARGIN / LRZGPU_SEG_BYTES).
 //   lz4 gate         one wavefront per block, launched per group of new blocks on its own stream
-//   GPU workers      `gpu_slots` threads, each with a HIP stream + match-finder workspace + pinned
-//                    staging: finder for block k+1 while block k is parsed on the host
+//   GPU workers      `gpu_slots` threads, each with a HIP stream + match-finder workspace: finder for
+//                    block k+1 while block k is parsed on the host; lists land in pinned host buffers
 //   host encoders    `host_threads` threads (default: the CPUs the process may use): LZMA parser +
 //                    range coder (lzma_enc.cpp); all stream waits are blocking-sync events
-//   writer           ordered container assembly (stream_layer.cpp); the file order of the blocks is
-//                    block_order()'s replay of the reference flushes, whatever order they finished in
+//   committer        the calling thread: validates the victim_round chain in chunk order, waits for the
+//                    chunk's blocks, lays the chunk out (stream_layer.cpp; the file order of the blocks is
+//                    block_order()'s replay of the reference flushes, whatever order they finished in)
+//                    and hands it to the sink (memory image or fd) -- one chunk of output resident at a time
+//   md5              whole-input MD5 on its own thread (serial by construction)
 //
 // Output bytes depend only on (input, control parameters), never on thread counts or timing here.
 #include <hip/hip_runtime.h>
@@ -40,10 +53,12 @@
 
 #include "../../include/lrzgpu.h"
 #include "common.h"
+#include "driver.h"
 #include "lz4_gate.h"
 #include "lzma_enc.h"
 #include "lzma_mf.h"
 #include "md5.h"
+#include "pools.h"
 #include "profile.h"
 #include "rzip_emit.h"
 #include "rzip_scan.h"
@@ -64,7 +79,14 @@ extern "C" void lrzgpu_control_init(lrzgpu_control *c)
 	c->ramsize = (pages > 0 && psz > 0) ? (int64_t)pages * psz : (int64_t)8 << 30; // src/lrzip.c:95-125
 }
 
-namespace {
+extern "C" void lrzgpu_trim(void)
+{
+	WorkspacePool::get().trim();
+	DevicePool::get().trim();
+	HostPool::get().trim();
+}
+
+namespace lrzgpu {
 
 // literal bytes this far behind the scan count as decided (LRZGPU_SPEC_MARGIN overrides: test hook
 // for the roll-back path -- with 0 every match that extends backwards over a segment boundary violates)
@@ -73,52 +95,24 @@ static int64_t spec_margin()
 	const char *e = getenv("LRZGPU_SPEC_MARGIN"); // read per call: tests flip it inside one process
 	return e ? (int64_t)atoll(e) : (int64_t)2 << 20;
 }
-constexpr size_t STAGE_BYTES = (size_t)32 << 20;  // pinned D2H staging piece (two per GPU worker)
+constexpr size_t STAGE_BYTES = (size_t)32 << 20; // pinned staging piece (uploads, unpinned fall-backs)
 
-double now_s()
+static double now_s()
 {
 	struct timespec ts;
 	clock_gettime(CLOCK_MONOTONIC, &ts);
 	return ts.tv_sec + ts.tv_nsec * 1e-9;
 }
-bool tracing()
+static bool tracing()
 {
 	static int t = getenv("LRZGPU_TRACE") ? 1 : 0;
 	return t != 0;
 }
 
-// The resolver is one latency-bound wavefront; finder / gate kernels of the blocks emitted early would
-// otherwise share its CU (issue slots, L1, LDS).  The scan stream therefore owns a small set of CUs
-// and every back-end stream gets the complement (hipExtStreamCreateWithCUMask).
-int scan_cu_words(uint32_t scan_mask[8], uint32_t rest_mask[8])
+static hipError_t make_stream(hipStream_t *s, bool high_priority = false)
 {
-	int ncu = 256;
-	hipDeviceProp_t prop;
-	int dev = 0;
-	if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-		ncu = prop.multiProcessorCount;
-	if (ncu > 256)
-		ncu = 256;
-	const char *e = getenv("LRZGPU_SCAN_CUS");
-	int k = e ? atoi(e) : 0; // off by default: measured no gain, and masked streams are blocking streams
-	if (k <= 0 || k >= ncu)
-		return 0; // masking disabled
-	for (int w = 0; w < 8; w++)
-		scan_mask[w] = rest_mask[w] = 0;
-	for (int c = 0; c < ncu; c++) {
-		if (c < k)
-			scan_mask[c >> 5] |= 1u << (c & 31);
-		else
-			rest_mask[c >> 5] |= 1u << (c & 31);
-	}
-	return (ncu + 31) / 32;
-}
-hipError_t make_stream(hipStream_t *s, int words, const uint32_t *mask, bool high_priority = false)
-{
-	if (words > 0)
-		return hipExtStreamCreateWithCUMask(s, (uint32_t)words, mask);
 	if (high_priority) {
-		// the scan stream must never queue behind a multi-second gate/finder kernel: streams share a
+		// a scan stream must never queue behind a multi-second gate/finder kernel: streams share a
 		// small pool of hardware queues (GPU_MAX_HW_QUEUES), priority streams get their own
 		int lo = 0, hi = 0;
 		if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
@@ -126,15 +120,6 @@ hipError_t make_stream(hipStream_t *s, int words, const uint32_t *mask, bool hig
 	}
 	return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
 }
-
-struct ChunkCtx {
-	int index = 0;
-	int64_t size = 0;
-	int chunk_bytes = 0;
-	uint8_t *d_stream1 = nullptr; // owned, chunk_size + 256 bytes
-	int64_t stream1_len = 0;
-	std::vector<uint8_t> stream0;
-};
 
 // --zstd back end: the system libzstd, bound at run time like the reference links it
 // (src/stream.c:167-230 zstd_compress_buf; bit-exactness holds against the same libzstd build)
@@ -160,93 +145,26 @@ struct ZstdLib {
 	}
 };
 
-// Recycled host buffers for block copies and match lists.  A 16 MiB block has ~450 MB of lists;
-// taking that from malloc() for every block means a fresh mmap, a page fault per 4 KiB and an
-// munmap -- seconds of kernel time per GiB of input that the encoders would rather have.
-struct HostPool {
-	std::mutex mu;
-	std::vector<std::pair<size_t, void *>> idle; // (capacity, pointer)
-	size_t idle_bytes = 0;
-	static HostPool &get()
-	{
-		static HostPool p;
-		return p;
-	}
-	static size_t idle_limit() // keep at most 1/8 of physical memory (and at most 48 GiB) parked
-	{
-		static const size_t lim = [] {
-			const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
-			size_t phys = pages > 0 && psz > 0 ? (size_t)pages * (size_t)psz : (size_t)64 << 30;
-			size_t l = phys / 8;
-			return l > ((size_t)48 << 30) ? (size_t)48 << 30 : l;
-		}();
-		return lim;
-	}
-	void *take(size_t bytes, size_t *cap)
-	{
-		{
-			std::lock_guard<std::mutex> lk(mu);
-			size_t best = idle.size();
-			for (size_t i = 0; i < idle.size(); i++)
-				if (idle[i].first >= bytes && (best == idle.size() || idle[i].first < idle[best].first))
-					best = i;
-			if (best != idle.size() && idle[best].first <= 2 * bytes + ((size_t)64 << 20)) {
-				void *p = idle[best].second;
-				*cap = idle[best].first;
-				idle_bytes -= idle[best].first;
-				idle[best] = idle.back();
-				idle.pop_back();
-				return p;
-			}
-		}
-		const size_t round = (size_t)8 << 20;
-		*cap = (bytes + round - 1) / round * round;
-		if (*cap == 0)
-			*cap = round;
-		return malloc(*cap);
-	}
-	void give(void *p, size_t cap)
-	{
-		if (!p)
-			return;
-		std::lock_guard<std::mutex> lk(mu);
-		if (idle.size() >= 96 || idle_bytes + cap > idle_limit()) {
-			free(p);
-			return;
-		}
-		idle.emplace_back(cap, p);
-		idle_bytes += cap;
-	}
-	~HostPool()
-	{
-		for (auto &e : idle)
-			free(e.second);
-	}
-};
+struct Job;
 
-template <typename T> struct RawBuf { // uninitialised host buffer (std::vector would zero-fill), recycled
-	T *p = nullptr;
-	size_t n = 0, cap = 0;
-	RawBuf() = default;
-	RawBuf(const RawBuf &) = delete;
-	RawBuf &operator=(const RawBuf &) = delete;
-	void alloc(size_t k)
-	{
-		release();
-		p = (T *)HostPool::get().take((k ? k : 1) * sizeof(T), &cap);
-		if (!p)
-			throw std::bad_alloc();
-		n = k;
-	}
-	void release()
-	{
-		if (p)
-			HostPool::get().give(p, cap);
-		p = nullptr;
-		n = cap = 0;
-	}
-	~RawBuf() { release(); }
-	T *data() { return p; }
+struct ChunkCtx {
+	int index = 0;
+	int64_t offset = 0, size = 0;
+	int chunk_bytes = 0;
+	bool last = false;
+	// input: a view into the caller's device buffer, or an owned copy
+	const uint8_t *d_in = nullptr;
+	DevBuf in_buf;
+	// scan results
+	DevBuf stream1; // chunk_size + 256 bytes
+	int64_t stream1_len = 0;
+	std::vector<uint8_t> stream0;
+	int64_t vr_in = 0, vr_out = 0;
+	std::vector<std::unique_ptr<Job>> jobs; // every job ever created for this chunk (early, final, discarded)
+	std::vector<Job *> file_order;          // the chunk's blocks in the order the reference writes them
+	// guarded by Run::mu
+	bool input_ready = false, scanned = false;
+	double t_scanned = 0;
 };
 
 struct Job {
@@ -259,8 +177,8 @@ struct Job {
 	bool mf_done = false;
 	bool compressible_mf = false; // finder ran and produced lists
 	bool dispatched = false;
-	bool cancelled = false;
 	bool finished = false;
+	std::atomic<bool> cancelled{false};
 	// data
 	RawBuf<uint8_t> bytes;
 	RawBuf<uint8_t> counts;
@@ -279,11 +197,9 @@ struct Lz4Batch {
 };
 
 struct Pipeline {
-	lrzgpu_control *ctl;
+	lrzgpu_control *ctl = nullptr;
 	Sizing sz;
 	int device = 0;
-	int mask_words = 0;
-	uint32_t scan_mask[8], rest_mask[8];
 	int n_gpu_workers = 2, n_encoders = 1;
 	int err = 0;
 
@@ -306,6 +222,11 @@ struct Pipeline {
 		cv_jobs.notify_all();
 		cv_enc.notify_all();
 		cv_done.notify_all();
+	}
+	int error()
+	{
+		std::lock_guard<std::mutex> lk(mu);
+		return err;
 	}
 
 	void mark_finished(Job *j, bool held_lists)
@@ -416,9 +337,17 @@ struct Pipeline {
 		}
 	}
 
-	// device -> host through the worker's pinned staging pair (pageable hipMemcpy is ~1 GB/s here)
-	static int d2h_staged(void *dst, const void *d_src, size_t bytes, uint8_t *stage[2], hipStream_t s)
+	// device -> host.  Pinned destinations take the DMA directly; pageable ones go through the worker's
+	// pinned staging pair (a pageable hipMemcpy is ~1 GB/s here)
+	static int d2h(void *dst, bool dst_pinned, const void *d_src, size_t bytes, uint8_t *stage[2], hipStream_t s)
 	{
+		if (!bytes)
+			return 0;
+		if (dst_pinned) {
+			if (hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, s) != hipSuccess || stream_wait(s) != hipSuccess)
+				return -1;
+			return 0;
+		}
 		size_t off = 0, prev_off = 0, prev_len = 0;
 		int k = 0;
 		while (off < bytes || prev_len) {
@@ -447,19 +376,21 @@ struct Pipeline {
 			return;
 		}
 		hipStream_t s;
-		if (make_stream(&s, mask_words, rest_mask) != hipSuccess) {
+		if (make_stream(&s) != hipSuccess) {
 			fail(LRZGPU_E_HIP);
 			return;
 		}
 		MfWorkspace *ws = nullptr;
-		uint8_t *d_stage = nullptr;
+		double ws_per_pos = 0;
+		DevBuf d_stage;
 		uint8_t *stage[2] = {nullptr, nullptr};
 		double per_pos = 16;
 		const size_t bufsize = (size_t)sz.stream_bufsize;
+		static const bool want_pinned = !getenv("LRZGPU_NO_PINNED_LISTS");
 		auto cleanup = [&] {
-			mf_workspace_destroy(ws);
-			if (d_stage)
-				(void)hipFree(d_stage);
+			WorkspacePool::get().give_mf(ws, ws_per_pos, device);
+			ws = nullptr;
+			d_stage.release();
 			for (int k = 0; k < 2; k++)
 				if (stage[k])
 					(void)hipHostFree(stage[k]);
@@ -500,21 +431,21 @@ struct Pipeline {
 			}
 			// block bytes: device view + host copy
 			const uint8_t *d_blk = nullptr;
-			j->bytes.alloc((size_t)n);
+			j->bytes.alloc((size_t)n, want_pinned && j->ref.streamno == 1 && n >= (1 << 20));
 			int rc = 0;
 			if (j->ref.streamno == 0) {
 				memcpy(j->bytes.data(), j->chunk->stream0.data() + j->ref.off, (size_t)n);
 				if (try_backend) {
-					if (!d_stage && hipMalloc(&d_stage, bufsize + 256) != hipSuccess)
+					if (!d_stage.p && !d_stage.alloc(bufsize + 256, device))
 						rc = LRZGPU_E_NOMEM;
-					else if (hipMemcpyAsync(d_stage, j->bytes.data(), (size_t)n, hipMemcpyHostToDevice, s) != hipSuccess ||
+					else if (hipMemcpyAsync(d_stage.p, j->bytes.data(), (size_t)n, hipMemcpyHostToDevice, s) != hipSuccess ||
 						 stream_wait(s) != hipSuccess)
 						rc = LRZGPU_E_HIP;
-					d_blk = d_stage;
+					d_blk = d_stage.p;
 				}
 			} else {
-				d_blk = j->chunk->d_stream1 + j->ref.off;
-				if (n && !j->cancelled && d2h_staged(j->bytes.data(), d_blk, (size_t)n, stage, s) != 0)
+				d_blk = j->chunk->stream1.p + j->ref.off;
+				if (n && !j->cancelled && d2h(j->bytes.data(), j->bytes.pinned, d_blk, (size_t)n, stage, s) != 0)
 					rc = LRZGPU_E_HIP;
 			}
 			if (rc) {
@@ -539,10 +470,13 @@ struct Pipeline {
 				// match finder on the GPU (runs concurrently with the gate launch of this block)
 				unsigned long long total = 0;
 				for (int attempt = 0;; attempt++) {
-					if (!ws && mf_workspace_create(&ws, bufsize, per_pos) != 0) {
-						fail(LRZGPU_E_NOMEM);
-						cleanup();
-						return;
+					if (!ws) {
+						ws = WorkspacePool::get().take_mf(bufsize, per_pos, device, &ws_per_pos);
+						if (!ws) {
+							fail(LRZGPU_E_NOMEM);
+							cleanup();
+							return;
+						}
 					}
 					int r = mf_run_device(ws, d_blk, (size_t)n, lp.dict_size, (uint32_t)lp.fb, lp.cut(), s, &total, pack, lp.fast);
 					if (r == 0)
@@ -550,7 +484,7 @@ struct Pipeline {
 					if (r == -4 && attempt < 3) { // pool too small for this data: grow and retry
 						mf_workspace_destroy(ws);
 						ws = nullptr;
-						per_pos *= 3;
+						per_pos = ws_per_pos * 3;
 						continue;
 					}
 					fail(LRZGPU_E_INTERNAL);
@@ -559,11 +493,11 @@ struct Pipeline {
 				}
 				tw2 = now_s();
 				const size_t words = pack ? (size_t)(total / 2) : (size_t)total;
-				j->counts.alloc((size_t)n);
-				j->pairs.alloc(words);
+				j->counts.alloc((size_t)n, want_pinned);
+				j->pairs.alloc(words, want_pinned);
 				j->packed = pack;
-				if (d2h_staged(j->counts.data(), ws->counts, (size_t)n, stage, s) != 0 ||
-				    (words && d2h_staged(j->pairs.data(), ws->pool_out, words * 4, stage, s) != 0)) {
+				if (d2h(j->counts.data(), j->counts.pinned, ws->counts, (size_t)n, stage, s) != 0 ||
+				    (words && d2h(j->pairs.data(), j->pairs.pinned, ws->pool_out, words * 4, stage, s) != 0)) {
 					fail(LRZGPU_E_HIP);
 					cleanup();
 					return;
@@ -588,12 +522,24 @@ struct Pipeline {
 		}
 	}
 
+	// a thread body: nothing may escape it (std::terminate), failures become the pipeline's error
+	template <typename F> void guarded(F &&f)
+	{
+		try {
+			f();
+		} catch (const std::bad_alloc &) {
+			fail(LRZGPU_E_NOMEM);
+		} catch (...) {
+			fail(LRZGPU_E_INTERNAL);
+		}
+	}
+
 	void start()
 	{
 		for (int i = 0; i < n_gpu_workers; i++)
-			threads.emplace_back([this] { gpu_worker_main(); });
+			threads.emplace_back([this] { guarded([this] { gpu_worker_main(); }); });
 		for (int i = 0; i < n_encoders; i++)
-			threads.emplace_back([this] { encoder_main(); });
+			threads.emplace_back([this] { guarded([this] { encoder_main(); }); });
 	}
 	void stop()
 	{
@@ -607,31 +553,51 @@ struct Pipeline {
 			t.join();
 		threads.clear();
 	}
+
+	// mark jobs void and wait until no thread touches them (or their chunk's device buffers) any more
+	void cancel_and_wait(const std::vector<Job *> &jobs)
+	{
+		std::unique_lock<std::mutex> lk(mu);
+		for (Job *j : jobs)
+			j->cancelled = true;
+		cv_done.wait(lk, [&] {
+			if (err)
+				return true;
+			for (Job *j : jobs)
+				if (!j->finished)
+					return false;
+			return true;
+		});
+	}
 };
 
-struct Input {
-	const uint8_t *host = nullptr; // one of host / dev
-	const uint8_t *dev = nullptr;
-	int fd = -1;
-	int64_t n = 0;
-};
-
-// Everything the main thread needs to feed blocks to the pipeline while the scan is running.
+// What a scanner thread needs to feed blocks to the pipeline while its scan is running.
 struct Feeder {
 	Pipeline &P;
-	hipStream_t ms, ls; // scan/gather stream, current lz4 gate stream
-	std::vector<hipStream_t> gate_streams; // gate launches last seconds each: they must overlap one another
+	hipStream_t ms = nullptr;                // scan/gather stream
+	std::vector<hipStream_t> gate_streams;   // gate launches last seconds each: they must overlap one another
 	size_t gate_rr = 0;
-	std::vector<std::unique_ptr<Job>> owned; // every job ever created (early, final, discarded)
 	std::vector<Lz4Batch> batches;
-	// gate job descriptors / results live in one arena allocated up front: hipMalloc/hipFree inside the
-	// scan would synchronise the whole device (and with it the multi-second gate launches)
-	Lz4Job *d_job_arena = nullptr;
-	int *d_res_arena = nullptr;
+	// gate job descriptors / results live in arenas allocated outside the scan: hipMalloc/hipFree inside
+	// it would synchronise the whole device (and with it the multi-second gate launches)
+	DevBuf arena;
 	size_t arena_cap = 0, arena_used = 0;
-	int ret = 0;
 
-	Feeder(Pipeline &p) : P(p), ms(nullptr), ls(nullptr) {}
+	explicit Feeder(Pipeline &p) : P(p) {}
+
+	int reserve(size_t descriptors)
+	{
+		if (arena_cap - arena_used >= descriptors)
+			return 0;
+		if (!batches.empty()) // descriptors of launches in flight live in the current arena
+			return LRZGPU_E_INTERNAL;
+		arena.release();
+		arena_cap = descriptors < 4096 ? 4096 : descriptors;
+		arena_used = 0;
+		if (!arena.alloc(arena_cap * (sizeof(Lz4Job) + sizeof(int)) + 64, P.device))
+			return LRZGPU_E_NOMEM;
+		return 0;
+	}
 
 	Job *new_job(ChunkCtx *cc, const BlockRef &br)
 	{
@@ -640,11 +606,11 @@ struct Feeder {
 		j->ref = br;
 		j->gate_needed = P.sz.lz4_test && !P.sz.no_compress && br.streamno == 1 && br.len >= 64 && br.len <= 100 * 1048576;
 		Job *r = j.get();
-		owned.push_back(std::move(j));
+		cc->jobs.push_back(std::move(j));
 		return r;
 	}
 
-	// queue blocks for the finder and launch their lz4 gate (asynchronously, on `ls`)
+	// queue blocks for the finder and launch their lz4 gate (asynchronously)
 	int submit(const std::vector<Job *> &jobs)
 	{
 		if (jobs.empty())
@@ -660,7 +626,7 @@ struct Feeder {
 		for (Job *j : jobs)
 			if (j->gate_needed) {
 				Lz4Job q;
-				q.src = j->chunk->d_stream1 + j->ref.off;
+				q.src = j->chunk->stream1.p + j->ref.off;
 				q.src_size = (int)j->ref.len;
 				q.dst_capacity = (int)j->ref.len + 1;
 				// the container only depends on the verdict (src/stream.c:2325-2380 returns a percentage
@@ -674,19 +640,21 @@ struct Feeder {
 			return 0;
 		if (arena_used + lj.size() > arena_cap)
 			return LRZGPU_E_INTERNAL;
-		b.d_jobs = d_job_arena + arena_used;
-		b.d_res = d_res_arena + arena_used;
+		b.d_jobs = (Lz4Job *)arena.p + arena_used;
+		b.d_res = (int *)(arena.p + arena_cap * sizeof(Lz4Job)) + arena_used;
 		arena_used += lj.size();
-		// descriptors go up on the (idle) scan stream: `ls` may still be busy with earlier gate launches
+		// descriptors go up on the (idle) scan stream: a gate stream may still be busy with earlier launches
 		if (hipMemcpyAsync(b.d_jobs, lj.data(), lj.size() * sizeof(Lz4Job), hipMemcpyHostToDevice, ms) != hipSuccess ||
 		    stream_wait(ms) != hipSuccess)
 			return LRZGPU_E_HIP;
-		ls = gate_streams[gate_rr++ % gate_streams.size()];
+		hipStream_t ls = gate_streams[gate_rr++ % gate_streams.size()];
 		b.timer = new EventTimer(ls);
 		int lr = lz4_sizes_device(b.d_jobs, (int)lj.size(), b.d_res, ls);
 		b.timer->stop();
-		if (lr != 0 || hipEventCreateWithFlags(&b.ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess || hipEventRecord(b.ev, ls) != hipSuccess)
+		if (lr != 0 || hipEventCreateWithFlags(&b.ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess || hipEventRecord(b.ev, ls) != hipSuccess) {
+			delete b.timer;
 			return LRZGPU_E_HIP;
+		}
 		batches.push_back(std::move(b));
 		return 0;
 	}
@@ -734,25 +702,26 @@ struct Feeder {
 		}
 		return 0;
 	}
-};
 
-// memcpy of a result image: a few threads once it is large (one core moves ~5 GB/s)
-static void big_copy(uint8_t *dst, const uint8_t *src, size_t n)
-{
-	const size_t piece = (size_t)64 << 20;
-	if (n < 2 * piece) {
-		memcpy(dst, src, n);
-		return;
+	void destroy()
+	{
+		for (Lz4Batch &b : batches) {
+			if (b.ev) {
+				(void)hipEventSynchronize(b.ev);
+				(void)hipEventDestroy(b.ev);
+			}
+			delete b.timer;
+		}
+		batches.clear();
+		if (ms)
+			(void)hipStreamDestroy(ms);
+		for (hipStream_t gs : gate_streams)
+			(void)hipStreamDestroy(gs);
+		ms = nullptr;
+		gate_streams.clear();
+		arena.release();
 	}
-	const int nt = n / piece < 8 ? (int)(n / piece) : 8;
-	std::vector<std::thread> th;
-	for (int t = 0; t < nt; t++) {
-		const size_t a = n / nt * t, b = t + 1 == nt ? n : n / nt * (t + 1);
-		th.emplace_back([=] { memcpy(dst + a, src + a, b - a); });
-	}
-	for (auto &x : th)
-		x.join();
-}
+};
 
 // CPUs this process may burn: the affinity mask, capped by a cgroup CPU quota (v2 cpu.max, v1 cfs_quota_us)
 static int usable_cpus()
@@ -787,12 +756,501 @@ static int usable_cpus()
 	return r < 1 ? 1 : r;
 }
 
-int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out, bool with_magic)
+static int write_all(int fd, const uint8_t *p, size_t n)
+{
+	while (n) {
+		ssize_t w = write(fd, p, n > ((size_t)1 << 30) ? ((size_t)1 << 30) : n);
+		if (w < 0 && errno == EINTR)
+			continue;
+		if (w <= 0)
+			return LRZGPU_E_IO;
+		p += w;
+		n -= (size_t)w;
+	}
+	return 0;
+}
+
+static int pread_all(int fd, uint8_t *p, size_t n, int64_t off)
+{
+	while (n) {
+		ssize_t r = pread(fd, p, n > ((size_t)1 << 30) ? ((size_t)1 << 30) : n, (off_t)off);
+		if (r < 0 && errno == EINTR)
+			continue;
+		if (r <= 0)
+			return LRZGPU_E_IO;
+		p += r;
+		n -= (size_t)r;
+		off += r;
+	}
+	return 0;
+}
+
+// ---- one compress run ------------------------------------------------------------------------------
+struct Run {
+	lrzgpu_control *ctl;
+	const CompressSource &in;
+	CompressSink &out;
+	const ChunkSelect *sel;
+	Pipeline P;
+	std::vector<std::unique_ptr<ChunkCtx>> chunks; // outlive every thread of the run
+	std::vector<int> mine;                         // indices into `chunks` this run compresses, ascending
+	std::mutex mu;
+	std::condition_variable cv;
+	size_t next_scan = 0;   // position in `mine` the next free scanner takes
+	size_t committed = 0;   // chunks of `mine` already laid out: the reader stays a bounded distance ahead
+	int scan_slots = 1;
+	bool speculate = true;
+	int64_t n_early = 0, n_violations = 0, n_rescans = 0;
+	double t0 = 0;
+
+	Run(lrzgpu_control *c, const CompressSource &i, CompressSink &o, const ChunkSelect *s) : ctl(c), in(i), out(o), sel(s) {}
+
+	void fail(int e)
+	{
+		P.fail(e);
+		std::lock_guard<std::mutex> lk(mu);
+		cv.notify_all();
+	}
+
+	// ---- reader: chunk bytes into HBM, in file order ----------------------------------------------
+	void reader_main()
+	{
+		if (hipSetDevice(P.device) != hipSuccess) {
+			fail(LRZGPU_E_HIP);
+			return;
+		}
+		hipStream_t s = nullptr;
+		uint8_t *stage[2] = {nullptr, nullptr};
+		auto cleanup = [&] {
+			for (int k = 0; k < 2; k++)
+				if (stage[k])
+					(void)hipHostFree(stage[k]);
+			if (s)
+				(void)hipStreamDestroy(s);
+		};
+		if (make_stream(&s) != hipSuccess) {
+			fail(LRZGPU_E_HIP);
+			return;
+		}
+		for (size_t m = 0; m < mine.size(); m++) {
+			ChunkCtx *cc = chunks[(size_t)mine[m]].get();
+			{
+				// at most scan_slots + 1 chunks ahead of the committer hold input copies
+				std::unique_lock<std::mutex> lk(mu);
+				cv.wait(lk, [&] { return P.err || m < committed + (size_t)scan_slots + 1; });
+				if (P.err)
+					break;
+			}
+			int rc = 0;
+			const bool interior = in.dev && ((uintptr_t)(in.dev + cc->offset) & 15) == 0 && cc->offset + cc->size < in.n;
+			if (interior) {
+				cc->d_in = in.dev + cc->offset; // interior chunk of a resident buffer: readable past its end
+			} else if (!cc->in_buf.alloc((size_t)cc->size + 256, P.device)) {
+				rc = LRZGPU_E_NOMEM;
+			} else {
+				cc->d_in = cc->in_buf.p;
+				hipError_t e = hipSuccess;
+				if (in.dev) {
+					if (cc->size)
+						e = hipMemcpyAsync(cc->in_buf.p, in.dev + cc->offset, (size_t)cc->size, hipMemcpyDeviceToDevice, s);
+				} else {
+					// host memory or a file: through two pinned pieces, copy/pread of piece k+1 under the DMA of piece k
+					if (!stage[0] && (hipHostMalloc((void **)&stage[0], STAGE_BYTES, hipHostMallocDefault) != hipSuccess ||
+							  hipHostMalloc((void **)&stage[1], STAGE_BYTES, hipHostMallocDefault) != hipSuccess))
+						rc = LRZGPU_E_NOMEM;
+					hipEvent_t done[2] = {nullptr, nullptr};
+					for (int k = 0; k < 2 && !rc; k++)
+						if (hipEventCreateWithFlags(&done[k], hipEventBlockingSync | hipEventDisableTiming) != hipSuccess)
+							rc = LRZGPU_E_HIP;
+					int k = 0;
+					bool used[2] = {false, false};
+					for (int64_t o = 0; o < cc->size && !rc; o += (int64_t)STAGE_BYTES, k ^= 1) {
+						const size_t len = (size_t)(cc->size - o < (int64_t)STAGE_BYTES ? cc->size - o : (int64_t)STAGE_BYTES);
+						if (used[k] && hipEventSynchronize(done[k]) != hipSuccess) {
+							rc = LRZGPU_E_HIP;
+							break;
+						}
+						if (in.host)
+							memcpy(stage[k], in.host + cc->offset + o, len);
+						else if (pread_all(in.fd, stage[k], len, in.fd_base + cc->offset + o) != 0) {
+							rc = LRZGPU_E_IO;
+							break;
+						}
+						if (hipMemcpyAsync(cc->in_buf.p + o, stage[k], len, hipMemcpyHostToDevice, s) != hipSuccess ||
+						    hipEventRecord(done[k], s) != hipSuccess)
+							rc = LRZGPU_E_HIP;
+						used[k] = true;
+					}
+					for (int q = 0; q < 2; q++)
+						if (done[q]) {
+							if (used[q])
+								(void)hipEventSynchronize(done[q]);
+							(void)hipEventDestroy(done[q]);
+						}
+				}
+				if (!rc && e == hipSuccess)
+					e = hipMemsetAsync(cc->in_buf.p + cc->size, 0, 256, s);
+				if (!rc && (e != hipSuccess || stream_wait(s) != hipSuccess))
+					rc = LRZGPU_E_HIP;
+			}
+			if (rc) {
+				fail(rc);
+				break;
+			}
+			std::lock_guard<std::mutex> lk(mu);
+			cc->input_ready = true;
+			cv.notify_all();
+		}
+		cleanup();
+	}
+
+	// ---- whole-input MD5 (the reference feeds it from cksumthread, src/rzip.c:564-584) ---------------
+	uint8_t digest[16];
+	void md5_main()
+	{
+		Md5 m;
+		if (in.host) {
+			m.update(in.host, (size_t)in.n);
+		} else if (in.n) {
+			const size_t piece = (size_t)32 << 20;
+			uint8_t *stage[2] = {nullptr, nullptr};
+			hipStream_t s = nullptr;
+			int rc = 0;
+			if (in.dev) {
+				if (hipSetDevice(P.device) != hipSuccess)
+					rc = LRZGPU_E_HIP;
+				else if (hipHostMalloc((void **)&stage[0], piece, hipHostMallocDefault) != hipSuccess ||
+					 hipHostMalloc((void **)&stage[1], piece, hipHostMallocDefault) != hipSuccess || make_stream(&s) != hipSuccess)
+					rc = LRZGPU_E_NOMEM;
+				// piece k+1 comes down while piece k is hashed
+				size_t prev = 0;
+				int k = 0;
+				for (int64_t o = 0; (o < in.n || prev) && !rc; o += (int64_t)piece, k ^= 1) {
+					size_t len = 0;
+					if (o < in.n) {
+						len = (size_t)(in.n - o < (int64_t)piece ? in.n - o : (int64_t)piece);
+						if (hipMemcpyAsync(stage[k], in.dev + o, len, hipMemcpyDeviceToHost, s) != hipSuccess)
+							rc = LRZGPU_E_HIP;
+					}
+					if (prev)
+						m.update(stage[k ^ 1], prev);
+					if (!rc && stream_wait(s) != hipSuccess)
+						rc = LRZGPU_E_HIP;
+					prev = len;
+					if (P.error())
+						break;
+				}
+				for (int q = 0; q < 2; q++)
+					if (stage[q])
+						(void)hipHostFree(stage[q]);
+				if (s)
+					(void)hipStreamDestroy(s);
+			} else {
+				std::vector<uint8_t> buf(piece);
+				for (int64_t o = 0; o < in.n && !rc; o += (int64_t)piece) {
+					const size_t len = (size_t)(in.n - o < (int64_t)piece ? in.n - o : (int64_t)piece);
+					if (pread_all(in.fd, buf.data(), len, in.fd_base + o) != 0)
+						rc = LRZGPU_E_IO;
+					else
+						m.update(buf.data(), len);
+					if (P.error())
+						break;
+				}
+			}
+			if (rc) {
+				fail(rc);
+				return;
+			}
+		}
+		m.finish(digest);
+	}
+
+	// ---- one chunk through K1..K5 with early block release ---------------------------------------
+	struct Scanner {
+		Feeder F;
+		ScanWorkspace *sw = nullptr;
+		DevBuf runs;
+		explicit Scanner(Pipeline &p) : F(p) {}
+	};
+
+	int scanner_open(Scanner &S)
+	{
+		if (hipSetDevice(P.device) != hipSuccess || make_stream(&S.F.ms, true) != hipSuccess)
+			return LRZGPU_E_HIP;
+		const int ngate = scan_slots > 1 ? 2 : 6;
+		for (int k = 0; k < ngate; k++) {
+			hipStream_t gs;
+			if (make_stream(&gs) != hipSuccess)
+				return LRZGPU_E_HIP;
+			S.F.gate_streams.push_back(gs);
+		}
+		const int64_t cap_chunk = P.sz.max_chunk < in.n ? P.sz.max_chunk : in.n;
+		S.sw = WorkspacePool::get().take_scan(P.sz.rzip_level, cap_chunk, P.device);
+		return S.sw ? 0 : LRZGPU_E_NOMEM;
+	}
+	void scanner_close(Scanner &S)
+	{
+		S.F.destroy();
+		const int64_t cap_chunk = P.sz.max_chunk < in.n ? P.sz.max_chunk : in.n;
+		WorkspacePool::get().give_scan(S.sw, P.sz.rzip_level, cap_chunk, P.device);
+		S.sw = nullptr;
+		S.runs.release();
+	}
+
+	// gathers stream-1 bytes [S0, S1) from `runs` (absolute dst offsets)
+	int gather(Scanner &S, ChunkCtx *cc, const std::vector<CopyRun> &runs, int64_t S0, int64_t S1)
+	{
+		if (runs.empty() || S1 <= S0)
+			return 0;
+		hipStream_t ms = S.F.ms;
+		if (runs.size() * sizeof(CopyRun) > S.runs.cap && !S.runs.alloc((runs.size() * 2 + 64) * sizeof(CopyRun), P.device))
+			return LRZGPU_E_NOMEM;
+		if (hipMemcpyAsync(S.runs.p, runs.data(), runs.size() * sizeof(CopyRun), hipMemcpyHostToDevice, ms) != hipSuccess)
+			return LRZGPU_E_HIP;
+		EventTimer tg(ms);
+		int gr = gather_runs_device(cc->d_in, cc->stream1.p, (const CopyRun *)S.runs.p, (int)runs.size(), S0, S1, ms);
+		tg.stop();
+		if (gr != 0 || stream_wait(ms) != hipSuccess)
+			return LRZGPU_E_HIP;
+		ProfileStore &ps = ProfileStore::get();
+		std::lock_guard<std::mutex> lk(ps.mu);
+		ps.p.gather_ms += tg.ms();
+		ps.p.gather_launches++;
+		ps.p.gather_bytes += S1 - S0;
+		return 0;
+	}
+
+	int scan_chunk(Scanner &S, ChunkCtx *cc, int64_t vr_in)
+	{
+		const int64_t chunk_size = cc->size, bufsize = P.sz.stream_bufsize;
+		Feeder &F = S.F;
+		cc->vr_in = vr_in;
+		cc->file_order.clear();
+		cc->stream0.clear();
+		if (!cc->stream1.p && !cc->stream1.alloc((size_t)chunk_size + 256, P.device))
+			return LRZGPU_E_NOMEM;
+		{
+			int pr = F.poll(true); // nothing of an earlier chunk may still sit in the descriptor arena
+			if (pr)
+				return pr;
+			int rr = F.reserve((size_t)(chunk_size / bufsize + 8) * 2);
+			if (rr)
+				return rr;
+		}
+		// ---- speculative early emission while the scan runs -----------------------------------
+		int64_t E = 0;          // chunk position up to which stream-1 bytes have been gathered
+		int64_t Sg = 0;         // stream-1 bytes gathered so far
+		int64_t seen = 0;       // match records consumed
+		int64_t blocks_out = 0; // full stream-1 blocks already submitted
+		bool violated = false;
+		std::map<int64_t, Job *> early; // stream-1 offset -> job
+		std::vector<MatchRec> rec_buf;
+
+		auto advance = [&](const ScanState &h, int64_t upto, bool final_call, const std::vector<MatchRec> *final_recs) -> int {
+			const int64_t nrec = final_recs ? (int64_t)final_recs->size() : h.n_records;
+			std::vector<CopyRun> runs;
+			const int64_t S_before = Sg;
+			if (nrec > seen) {
+				const MatchRec *rp;
+				if (final_recs)
+					rp = final_recs->data() + seen;
+				else {
+					rec_buf.resize((size_t)(nrec - seen));
+					if (hipMemcpyAsync(rec_buf.data(), S.sw->records + seen, (size_t)(nrec - seen) * sizeof(MatchRec), hipMemcpyDeviceToHost, F.ms) != hipSuccess ||
+					    stream_wait(F.ms) != hipSuccess)
+						return LRZGPU_E_HIP;
+					rp = rec_buf.data();
+				}
+				for (int64_t k = 0; k < nrec - seen && !violated; k++) {
+					const MatchRec &r = rp[k];
+					if (r.p < E) {
+						violated = true; // a match reaches back over bytes already emitted as literals
+						break;
+					}
+					if (E < r.p) {
+						runs.push_back(CopyRun{E, Sg, r.p - E});
+						Sg += r.p - E;
+					}
+					E = r.p + r.len;
+				}
+				seen = nrec;
+			}
+			if (violated)
+				return 0;
+			int64_t Fp = final_call ? chunk_size : upto - spec_margin();
+			if (!final_call && h.cur_len > 0 && h.cur_p < Fp)
+				Fp = h.cur_p;
+			if (Fp > chunk_size)
+				Fp = chunk_size;
+			if (Fp > E) {
+				if (!runs.empty() && runs.back().src_off + runs.back().len == E)
+					runs.back().len += Fp - E;
+				else
+					runs.push_back(CopyRun{E, Sg, Fp - E});
+				Sg += Fp - E;
+				E = Fp;
+			}
+			if (Sg > S_before) {
+				int g = gather(S, cc, runs, S_before, Sg);
+				if (g)
+					return g;
+			}
+			if (final_call)
+				return 0;
+			std::vector<Job *> fresh;
+			while ((blocks_out + 1) * bufsize <= Sg) {
+				Job *j = F.new_job(cc, BlockRef{1, blocks_out * bufsize, bufsize});
+				early[blocks_out * bufsize] = j;
+				fresh.push_back(j);
+				blocks_out++;
+			}
+			{
+				std::lock_guard<std::mutex> lk(mu);
+				n_early += (int64_t)fresh.size();
+			}
+			int sr2 = F.submit(fresh);
+			if (sr2)
+				return sr2;
+			if (P.error())
+				return P.error();
+			return F.poll(false);
+		};
+
+		ScanProgressFn progress = nullptr;
+		if (speculate)
+			progress = [&](const ScanState &h, int64_t upto) -> int { return advance(h, upto, false, nullptr); };
+
+		ScanResult sr;
+		int64_t vr = vr_in;
+		int r = scan_chunk_device(S.sw, cc->d_in, chunk_size, P.sz.rzip_level, &vr, &sr, F.ms, progress);
+		if (r)
+			return r < -50 ? r : (r == -4 ? LRZGPU_E_NOMEM : LRZGPU_E_INTERNAL);
+		cc->vr_out = vr;
+		EmitResult er;
+		emit_streams(sr.records, chunk_size, cc->chunk_bytes, sr.crc, &er);
+		cc->stream0.swap(er.stream0);
+		cc->stream1_len = er.stream1_len;
+		if (speculate && !violated) {
+			int a = advance(sr.final_state, chunk_size, true, &sr.records);
+			if (a)
+				return a;
+		}
+		if (!speculate || violated || Sg != er.stream1_len) {
+			// (re)build stream 1 from the final run table; early blocks, if any, are void
+			if (speculate && violated) {
+				ProfileStore &ps = ProfileStore::get();
+				std::lock_guard<std::mutex> lk(ps.mu);
+				ps.p.spec_rollbacks++;
+			}
+			if (!early.empty()) {
+				{
+					std::lock_guard<std::mutex> lk(mu);
+					n_violations++;
+				}
+				{
+					ProfileStore &ps = ProfileStore::get();
+					std::lock_guard<std::mutex> lk(ps.mu);
+					ps.p.spec_cancelled_blocks += (int64_t)early.size();
+				}
+				std::vector<Job *> dead;
+				for (auto &kv : early)
+					dead.push_back(kv.second);
+				for (Job *j : dead)
+					j->cancelled = true;
+				int pr = F.poll(true);
+				if (pr)
+					return pr;
+				P.cancel_and_wait(dead);
+				if (P.error())
+					return P.error();
+				early.clear();
+			}
+			int g = gather(S, cc, er.runs, 0, er.stream1_len);
+			if (g)
+				return g;
+		}
+		if (hipMemsetAsync(cc->stream1.p + er.stream1_len, 0, 256, F.ms) != hipSuccess || stream_wait(F.ms) != hipSuccess)
+			return LRZGPU_E_HIP;
+		// the chunk's blocks in the order the reference flushes them; early blocks are reused
+		std::vector<BlockRef> refs;
+		block_order(cc->stream0, cc->chunk_bytes, cc->stream1_len, bufsize, &refs);
+		std::vector<Job *> fresh;
+		for (const BlockRef &br : refs) {
+			Job *j = nullptr;
+			if (br.streamno == 1 && br.len == bufsize) {
+				auto it = early.find(br.off);
+				if (it != early.end()) {
+					j = it->second;
+					early.erase(it);
+				}
+			}
+			if (!j) {
+				j = F.new_job(cc, br);
+				fresh.push_back(j);
+			}
+			cc->file_order.push_back(j);
+		}
+		if (!early.empty()) // cannot happen: every early block is a full stream-1 block of the final layout
+			return LRZGPU_E_INTERNAL;
+		return F.submit(fresh);
+	}
+
+	void scanner_main()
+	{
+		Scanner S(P);
+		int rc = scanner_open(S);
+		while (!rc) {
+			ChunkCtx *cc = nullptr;
+			int64_t vr_in = 0;
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				if (P.err || next_scan >= mine.size())
+					break;
+				const size_t m = next_scan++;
+				cc = chunks[(size_t)mine[m]].get();
+				cv.wait(lk, [&] { return P.err || cc->input_ready; });
+				if (P.err)
+					break;
+				vr_in = predicted_vr(cc->index);
+			}
+			rc = scan_chunk(S, cc, vr_in);
+			if (!rc)
+				rc = S.F.poll(true);
+			if (rc)
+				break;
+			std::lock_guard<std::mutex> lk(mu);
+			cc->scanned = true;
+			cc->t_scanned = now_s();
+			cv.notify_all();
+		}
+		if (rc)
+			fail(rc);
+		scanner_close(S);
+	}
+
+	// victim_round a chunk should start from (mu held): what its predecessor left if that is known, the
+	// caller's hint for the first chunk of a partial run, else 0 -- the value only moves when a tag value
+	// collects max_chain_len table entries, which ordinary data does rarely
+	int64_t predicted_vr(int index)
+	{
+		if (index == 0)
+			return 0;
+		const ChunkCtx *prev = chunks[(size_t)index - 1].get();
+		if (prev->scanned)
+			return prev->vr_out;
+		if (sel && sel->victim_in && sel->victim_in[index] >= 0)
+			return sel->victim_in[index];
+		return 0;
+	}
+
+	int run();
+};
+
+int Run::run()
 {
 	int rc = select_device(ctl->device);
 	if (rc)
 		return rc;
-	Pipeline P;
 	P.ctl = ctl;
 	P.device = ctl->device;
 	rc = compute_sizing(ctl, in.n, &P.sz);
@@ -814,408 +1272,182 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 	ctl->dictSize_used = P.sz.dict_size;
 	ctl->threads_used = P.sz.threads;
 	ctl->st_size = in.n;
-	const bool speculate = !getenv("LRZGPU_NO_OVERLAP");
-	if (ctl->verbose)
-		fprintf(stderr, "lrzgpu: threads %d bufsize %lld dict %u chunk %lld encoders %d gpu workers %d\n", P.sz.threads,
-			(long long)P.sz.stream_bufsize, P.sz.dict_size, (long long)P.sz.max_chunk, P.n_encoders, P.n_gpu_workers);
+	speculate = !getenv("LRZGPU_NO_OVERLAP");
 
-	// whole-input MD5 on a side thread (the reference feeds it from cksumthread, src/rzip.c:564-584)
-	uint8_t digest[16];
-	std::atomic<int> md5_err{0};
-	std::thread md5_thread([&] {
-		Md5 m;
-		if (in.host) {
-			m.update(in.host, (size_t)in.n);
-		} else if (in.dev) {
-			if (hipSetDevice(ctl->device) != hipSuccess) {
-				md5_err = LRZGPU_E_HIP;
-				return;
+	// the chunks of the file (src/rzip.c:1041: at least one pass, even for an empty input)
+	{
+		int64_t len = in.n, pass = 0;
+		while (!pass || len > 0) {
+			pass++;
+			std::unique_ptr<ChunkCtx> cc(new ChunkCtx());
+			cc->index = (int)chunks.size();
+			cc->offset = in.n - len;
+			cc->size = P.sz.max_chunk < len ? P.sz.max_chunk : len;
+			cc->chunk_bytes = chunk_bytes_for(cc->size);
+			len -= cc->size;
+			cc->last = len <= 0;
+			chunks.push_back(std::move(cc));
+		}
+	}
+	for (size_t k = 0; k < chunks.size(); k++)
+		if (!sel || (sel->stride > 0 && (int)k % sel->stride == sel->first))
+			mine.push_back((int)k);
+	scan_slots = ctl->scan_slots > 0 ? ctl->scan_slots : 8;
+	if (const char *e = getenv("LRZGPU_SCAN_SLOTS"))
+		if (atoi(e) > 0)
+			scan_slots = atoi(e);
+	if ((size_t)scan_slots > mine.size())
+		scan_slots = mine.empty() ? 1 : (int)mine.size();
+	if (ctl->verbose)
+		fprintf(stderr, "lrzgpu: threads %d bufsize %lld dict %u chunk %lld chunks %zu (%zu here) scanners %d encoders %d gpu workers %d\n",
+			P.sz.threads, (long long)P.sz.stream_bufsize, P.sz.dict_size, (long long)P.sz.max_chunk, chunks.size(), mine.size(),
+			scan_slots, P.n_encoders, P.n_gpu_workers);
+
+	t0 = now_s();
+	P.start();
+	std::vector<std::thread> side;
+	const bool want_md5 = !sel || sel->with_md5;
+	if (want_md5)
+		side.emplace_back([this] { P.guarded([this] { md5_main(); }); });
+	side.emplace_back([this] { P.guarded([this] { reader_main(); }); });
+	for (int k = 0; k < scan_slots; k++)
+		side.emplace_back([this] { P.guarded([this] { scanner_main(); }); });
+
+	// ---- committer: chunks in file order ------------------------------------------------------------
+	int ret = 0;
+	std::unique_ptr<Scanner> rescanner;
+	double t_scan_last = 0, t_blocks = 0;
+	const bool whole_file = !sel;
+	if (whole_file && out.begin(21) != 0) // magic placeholder (compress_file, src/lrzip.c:1487-1547)
+		ret = LRZGPU_E_IO;
+	for (size_t m = 0; m < mine.size() && !ret; m++) {
+		ChunkCtx *cc = chunks[(size_t)mine[m]].get();
+		{
+			std::unique_lock<std::mutex> lk(mu);
+			cv.wait(lk, [&] { return P.err || cc->scanned; });
+			if (P.err) {
+				ret = P.err;
+				break;
 			}
-			const size_t piece = (size_t)64 << 20;
-			uint8_t *stage = nullptr;
-			hipStream_t s;
-			if (hipHostMalloc((void **)&stage, piece, hipHostMallocDefault) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
-				md5_err = LRZGPU_E_NOMEM;
-				return;
-			}
-			for (int64_t o = 0; o < in.n; o += (int64_t)piece) {
-				size_t k = (size_t)(in.n - o < (int64_t)piece ? in.n - o : (int64_t)piece);
-				if (hipMemcpyAsync(stage, in.dev + o, k, hipMemcpyDeviceToHost, s) != hipSuccess || stream_wait(s) != hipSuccess) {
-					md5_err = LRZGPU_E_HIP;
+		}
+		// victim_round chain: only checkable when this run also scanned the predecessor
+		if (cc->index > 0 && (!sel || sel->stride == 1)) {
+			const ChunkCtx *prev = chunks[(size_t)cc->index - 1].get();
+			if (prev->vr_out != cc->vr_in) {
+				// the chunk was scanned from the wrong victim_round: void its blocks and scan it again
+				n_rescans++;
+				std::vector<Job *> dead;
+				for (auto &j : cc->jobs)
+					dead.push_back(j.get());
+				P.cancel_and_wait(dead);
+				if (P.error()) {
+					ret = P.error();
 					break;
 				}
-				m.update(stage, k);
-			}
-			(void)hipHostFree(stage);
-			(void)hipStreamDestroy(s);
-		}
-		m.finish(digest);
-	});
-
-	P.mask_words = speculate ? scan_cu_words(P.scan_mask, P.rest_mask) : 0;
-	const double t0 = now_s();
-	double t_scan = 0, t_enq = 0;
-	int64_t n_early = 0, n_violations = 0;
-	P.start();
-
-	Feeder F(P);
-	std::vector<std::unique_ptr<ChunkCtx>> chunks;
-	std::vector<Job *> file_order; // every block of the file, in the order the reference writes them
-	ScanWorkspace *sw = nullptr;
-	int64_t victim_round = 0;
-	int64_t len = in.n;
-	int ret = 0;
-	if (make_stream(&F.ms, P.mask_words, P.scan_mask, true) != hipSuccess)
-		ret = LRZGPU_E_HIP;
-	for (int k = 0; k < 6 && !ret; k++) {
-		hipStream_t gs;
-		if (make_stream(&gs, P.mask_words, P.rest_mask) != hipSuccess)
-			ret = LRZGPU_E_HIP;
-		else
-			F.gate_streams.push_back(gs);
-	}
-	hipStream_t ms = F.ms;
-	{
-		const int64_t per_chunk = (P.sz.max_chunk < in.n ? P.sz.max_chunk : in.n) / P.sz.stream_bufsize + 8;
-		const int64_t nchunks = in.n / (P.sz.max_chunk > 0 ? P.sz.max_chunk : 1) + 2;
-		F.arena_cap = (size_t)(per_chunk * nchunks * 2);
-		if (!ret && (hipMalloc(&F.d_job_arena, F.arena_cap * sizeof(Lz4Job)) != hipSuccess || hipMalloc(&F.d_res_arena, F.arena_cap * sizeof(int)) != hipSuccess))
-			ret = LRZGPU_E_NOMEM;
-	}
-	uint8_t *d_upload = nullptr; // chunk staging when the input is on the host
-	CopyRun *d_runs = nullptr;
-	size_t d_runs_cap = 0;
-	int pass = 0;
-	const int64_t bufsize = P.sz.stream_bufsize;
-
-	// gathers stream-1 bytes [S0, S1) from `runs` (absolute dst offsets)
-	auto gather = [&](const uint8_t *d_chunk, ChunkCtx *cc, const std::vector<CopyRun> &runs, int64_t S0, int64_t S1) -> int {
-		if (runs.empty() || S1 <= S0)
-			return 0;
-		if (runs.size() > d_runs_cap) {
-			if (d_runs)
-				(void)hipFree(d_runs);
-			d_runs_cap = runs.size() * 2 + 64;
-			if (hipMalloc(&d_runs, d_runs_cap * sizeof(CopyRun)) != hipSuccess)
-				return LRZGPU_E_NOMEM;
-		}
-		if (hipMemcpyAsync(d_runs, runs.data(), runs.size() * sizeof(CopyRun), hipMemcpyHostToDevice, ms) != hipSuccess)
-			return LRZGPU_E_HIP;
-		EventTimer tg(ms);
-		int gr = gather_runs_device(d_chunk, cc->d_stream1, d_runs, (int)runs.size(), S0, S1, ms);
-		tg.stop();
-		if (gr != 0 || stream_wait(ms) != hipSuccess)
-			return LRZGPU_E_HIP;
-		ProfileStore &ps = ProfileStore::get();
-		std::lock_guard<std::mutex> lk(ps.mu);
-		ps.p.gather_ms += tg.ms();
-		ps.p.gather_launches++;
-		ps.p.gather_bytes += S1 - S0;
-		return 0;
-	};
-
-	while (!ret && (!pass || len > 0)) { // src/rzip.c:1041
-		pass++;
-		const int64_t offset = in.n - len;
-		const int64_t chunk_size = P.sz.max_chunk < len ? P.sz.max_chunk : len;
-		std::unique_ptr<ChunkCtx> cc(new ChunkCtx());
-		cc->index = (int)chunks.size();
-		cc->size = chunk_size;
-		cc->chunk_bytes = chunk_bytes_for(chunk_size);
-
-		const uint8_t *d_chunk = nullptr;
-		if (in.dev && ((uintptr_t)(in.dev + offset) & 15) == 0 && offset + chunk_size < in.n) {
-			d_chunk = in.dev + offset; // interior chunk of a resident buffer: readable past its end
-		} else {
-			// host input, the last chunk (needs 64 readable bytes of padding) or an unaligned view
-			if (!d_upload && hipMalloc(&d_upload, (size_t)(P.sz.max_chunk < in.n ? P.sz.max_chunk : in.n) + 256) != hipSuccess) {
-				ret = LRZGPU_E_NOMEM;
-				break;
-			}
-			hipError_t e = hipSuccess;
-			if (chunk_size) {
-				if (in.dev)
-					e = hipMemcpyAsync(d_upload, in.dev + offset, (size_t)chunk_size, hipMemcpyDeviceToDevice, ms);
-				else
-					e = hipMemcpyAsync(d_upload, in.host + offset, (size_t)chunk_size, hipMemcpyHostToDevice, ms);
-			}
-			if (e == hipSuccess)
-				e = hipMemsetAsync(d_upload + chunk_size, 0, 256, ms);
-			if (e != hipSuccess) {
-				ret = LRZGPU_E_HIP;
-				break;
-			}
-			d_chunk = d_upload;
-		}
-		if (hipMalloc(&cc->d_stream1, (size_t)chunk_size + 256) != hipSuccess) {
-			ret = LRZGPU_E_NOMEM;
-			break;
-		}
-		if (!sw && scan_workspace_create(&sw, P.sz.rzip_level, P.sz.max_chunk < in.n ? P.sz.max_chunk : in.n) != 0) {
-			ret = LRZGPU_E_NOMEM;
-			break;
-		}
-
-		// ---- speculative early emission while the scan runs -----------------------------------
-		int64_t E = 0;          // chunk position up to which stream-1 bytes have been gathered
-		int64_t S = 0;          // stream-1 bytes gathered so far
-		int64_t seen = 0;       // match records consumed
-		int64_t blocks_out = 0; // full stream-1 blocks already submitted
-		bool violated = false;
-		std::map<int64_t, Job *> early; // stream-1 offset -> job
-		std::vector<MatchRec> rec_buf;
-		ChunkCtx *ccp = cc.get();
-
-		auto advance = [&](const ScanState &h, int64_t upto, bool final_call, const std::vector<MatchRec> *final_recs) -> int {
-			// new records
-			const int64_t nrec = final_recs ? (int64_t)final_recs->size() : h.n_records;
-			std::vector<CopyRun> runs;
-			const int64_t S_before = S;
-			if (nrec > seen) {
-				const MatchRec *rp;
-				if (final_recs)
-					rp = final_recs->data() + seen;
-				else {
-					rec_buf.resize((size_t)(nrec - seen));
-					if (hipMemcpy(rec_buf.data(), sw->records + seen, (size_t)(nrec - seen) * sizeof(MatchRec), hipMemcpyDeviceToHost) != hipSuccess)
-						return LRZGPU_E_HIP;
-					rp = rec_buf.data();
-				}
-				for (int64_t k = 0; k < nrec - seen && !violated; k++) {
-					const MatchRec &r = rp[k];
-					if (r.p < E) {
-						violated = true; // a match reaches back over bytes already emitted as literals
+				if (!rescanner) {
+					rescanner.reset(new Scanner(P));
+					int orc = scanner_open(*rescanner);
+					if (orc) {
+						ret = orc;
 						break;
 					}
-					if (E < r.p) {
-						runs.push_back(CopyRun{E, S, r.p - E});
-						S += r.p - E;
-					}
-					E = r.p + r.len;
 				}
-				seen = nrec;
-			}
-			if (violated)
-				return 0;
-			int64_t Fp = final_call ? chunk_size : upto - spec_margin();
-			if (!final_call && h.cur_len > 0 && h.cur_p < Fp)
-				Fp = h.cur_p;
-			if (Fp > chunk_size)
-				Fp = chunk_size;
-			if (Fp > E) {
-				if (!runs.empty() && runs.back().src_off + runs.back().len == E)
-					runs.back().len += Fp - E;
-				else
-					runs.push_back(CopyRun{E, S, Fp - E});
-				S += Fp - E;
-				E = Fp;
-			}
-			if (S > S_before) {
-				int g = gather(d_chunk, ccp, runs, S_before, S);
-				if (g)
-					return g;
-			}
-			if (final_call)
-				return 0;
-			std::vector<Job *> fresh;
-			while ((blocks_out + 1) * bufsize <= S) {
-				Job *j = F.new_job(ccp, BlockRef{1, blocks_out * bufsize, bufsize});
-				early[blocks_out * bufsize] = j;
-				fresh.push_back(j);
-				blocks_out++;
-				n_early++;
-			}
-			int sr2 = F.submit(fresh);
-			if (sr2)
-				return sr2;
-			return F.poll(false);
-		};
-
-		ScanProgressFn progress = nullptr;
-		if (speculate)
-			progress = [&](const ScanState &h, int64_t upto) -> int { return advance(h, upto, false, nullptr); };
-
-		ScanResult sr;
-		int r = scan_chunk_device(sw, d_chunk, chunk_size, P.sz.rzip_level, &victim_round, &sr, ms, progress);
-		if (r) {
-			ret = r < -50 ? r : (r == -4 ? LRZGPU_E_NOMEM : LRZGPU_E_INTERNAL);
-			break;
-		}
-		t_scan = now_s();
-		EmitResult er;
-		emit_streams(sr.records, chunk_size, cc->chunk_bytes, sr.crc, &er);
-		cc->stream0.swap(er.stream0);
-		cc->stream1_len = er.stream1_len;
-		if (speculate && !violated) {
-			int a = advance(sr.final_state, chunk_size, true, &sr.records);
-			if (a) {
-				ret = a;
-				break;
-			}
-		}
-		if (!speculate || violated || S != er.stream1_len) {
-			// (re)build stream 1 from the final run table; early blocks, if any, are void
-			if (speculate && violated) {
-				ProfileStore &ps = ProfileStore::get();
-				std::lock_guard<std::mutex> lk(ps.mu);
-				ps.p.spec_rollbacks++;
-			}
-			if (!early.empty()) {
-				n_violations++;
-				{
-					ProfileStore &ps = ProfileStore::get();
-					std::lock_guard<std::mutex> lk(ps.mu);
-					ps.p.spec_cancelled_blocks += (int64_t)early.size();
-				}
-				{
-					std::lock_guard<std::mutex> lk(P.mu);
-					for (auto &kv : early)
-						kv.second->cancelled = true;
-				}
-				int pr = F.poll(true);
-				if (pr) {
-					ret = pr;
+				int src = scan_chunk(*rescanner, cc, prev->vr_out);
+				if (!src)
+					src = rescanner->F.poll(true);
+				if (src) {
+					ret = src;
 					break;
 				}
-				std::unique_lock<std::mutex> lk(P.mu);
-				P.cv_done.wait(lk, [&] {
-					if (P.err)
-						return true;
-					for (auto &kv : early)
-						if (!kv.second->finished)
-							return false;
-					return true;
-				});
-				early.clear();
 			}
-			int g = gather(d_chunk, ccp, er.runs, 0, er.stream1_len);
-			if (g) {
-				ret = g;
+		}
+		t_scan_last = cc->t_scanned;
+		cc->in_buf.release(); // no rescan can be asked for any more
+		cc->d_in = nullptr;
+		// wait for every block of the chunk (discarded early ones included: they reference its buffers)
+		{
+			std::unique_lock<std::mutex> lk(P.mu);
+			P.cv_done.wait(lk, [&] {
+				if (P.err)
+					return true;
+				for (auto &j : cc->jobs)
+					if (!j->finished)
+						return false;
+				return true;
+			});
+			if (P.err) {
+				ret = P.err;
 				break;
 			}
 		}
-		if (hipMemsetAsync(cc->d_stream1 + er.stream1_len, 0, 256, ms) != hipSuccess || stream_wait(ms) != hipSuccess) {
-			ret = LRZGPU_E_HIP;
-			break;
+		t_blocks = now_s();
+		cc->stream1.release();
+		// ordered container assembly of this chunk
+		std::vector<DoneBlock> blocks;
+		size_t total = 2 + (size_t)cc->chunk_bytes * 7 + 2;
+		for (Job *j : cc->file_order) {
+			total += 1 + 3 * 8 + j->done.payload.size();
+			blocks.push_back(std::move(j->done));
 		}
-		// the chunk's blocks in the order the reference flushes them; early blocks are reused
-		std::vector<BlockRef> refs;
-		block_order(cc->stream0, cc->chunk_bytes, cc->stream1_len, bufsize, &refs);
-		std::vector<Job *> fresh;
-		for (const BlockRef &br : refs) {
-			Job *j = nullptr;
-			if (br.streamno == 1 && br.len == bufsize) {
-				auto it = early.find(br.off);
-				if (it != early.end()) {
-					j = it->second;
-					early.erase(it);
-				}
-			}
-			if (!j) {
-				j = F.new_job(ccp, br);
-				fresh.push_back(j);
-			}
-			file_order.push_back(j);
-		}
-		if (!early.empty()) { // cannot happen: every early block is a full stream-1 block of the final layout
-			ret = LRZGPU_E_INTERNAL;
-			break;
-		}
-		int s2 = F.submit(fresh);
-		if (s2) {
-			ret = s2;
-			break;
-		}
-		t_enq = now_s();
-		chunks.push_back(std::move(cc));
-		len -= chunk_size;
+		std::vector<uint8_t> img;
+		img.reserve(total);
+		write_chunk(&img, cc->chunk_bytes, cc->last, cc->size, blocks);
+		if (sel && sel->on_chunk) {
+			if (sel->on_chunk(sel->ctx, cc->index, cc->vr_in, cc->vr_out, img.data(), (int64_t)img.size()) != 0)
+				ret = LRZGPU_E_IO;
+		} else if (out.put(img.data(), img.size()) != 0)
+			ret = LRZGPU_E_IO;
+		cc->jobs.clear();
+		cc->file_order.clear();
+		std::vector<uint8_t>().swap(cc->stream0);
+		std::lock_guard<std::mutex> lk(mu);
+		committed = m + 1;
+		cv.notify_all();
 	}
 	if (ret)
-		P.fail(ret);
-	else {
-		int pr = F.poll(true);
-		if (pr) {
-			ret = pr;
-			P.fail(ret);
-		}
-	}
-
-	// wait for every block (discarded early ones included: they reference device buffers)
+		fail(ret);
+	if (rescanner)
+		scanner_close(*rescanner);
+	// every thread ends on its own (work done) or on the error flag; chunks and jobs outlive them all
+	for (auto &t : side)
+		t.join();
 	{
+		// blocks still in flight after a failure reference chunk buffers: wait them out before those go
 		std::unique_lock<std::mutex> lk(P.mu);
-		P.cv_done.wait(lk, [&] {
-			if (P.err)
+		if (!P.err)
+			P.cv_done.wait(lk, [&] {
+				for (auto &c : chunks)
+					for (auto &j : c->jobs)
+						if (!j->finished)
+							return false;
 				return true;
-			for (auto &j : F.owned)
-				if (!j->finished)
-					return false;
-			return true;
-		});
-		if (P.err && !ret)
-			ret = P.err;
+			});
 	}
-	const double t_blocks = now_s();
 	P.stop();
-	md5_thread.join();
 	const double t_md5 = now_s();
-	if (!ret && md5_err)
-		ret = md5_err;
-	scan_workspace_destroy(sw);
-	if (d_upload)
-		(void)hipFree(d_upload);
-	if (d_runs)
-		(void)hipFree(d_runs);
-	for (Lz4Batch &b : F.batches) {
-		delete b.timer;
-		if (b.ev)
-			(void)hipEventDestroy(b.ev);
-	}
-	if (F.d_job_arena)
-		(void)hipFree(F.d_job_arena);
-	if (F.d_res_arena)
-		(void)hipFree(F.d_res_arena);
-	if (F.ms)
-		(void)hipStreamDestroy(F.ms);
-	for (hipStream_t gs : F.gate_streams)
-		(void)hipStreamDestroy(gs);
-	for (auto &c : chunks)
-		if (c->d_stream1) {
-			(void)hipFree(c->d_stream1);
-			c->d_stream1 = nullptr;
-		}
+	if (!ret && P.err)
+		ret = P.err;
 	if (ret)
 		return ret;
 
-	// ordered container assembly (one allocation: headers + payloads are known now)
-	{
-		size_t total = 21 + 16;
-		for (auto &c : chunks)
-			total += 2 + (size_t)c->chunk_bytes * 7 + 2;
-		for (Job *j : file_order)
-			total += 1 + 3 * 8 + j->done.payload.size();
-		out->reserve(total);
-	}
-	if (with_magic)
-		out->assign(21, 0);
-	size_t ji = 0;
-	for (size_t ci = 0; ci < chunks.size(); ci++) {
-		std::vector<DoneBlock> blocks;
-		while (ji < file_order.size() && file_order[ji]->chunk == chunks[ci].get()) {
-			blocks.push_back(std::move(file_order[ji]->done));
-			ji++;
-		}
-		write_chunk(out, chunks[ci]->chunk_bytes, ci + 1 == chunks.size(), chunks[ci]->size, blocks);
-	}
-	out->insert(out->end(), digest, digest + 16);
-	memcpy(ctl->hash_resblock, digest, 16);
-	if (tracing())
-		fprintf(stderr, "lrzgpu driver: scan done %.2f  blocks queued %.2f  last finder %.2f  last encode %.2f  all blocks %.2f  md5 joined %.2f  assembled %.2f s (since start; last chunk); early blocks %lld, redone chunks %lld; worker sums: block copy+gate %.2f finder %.2f lists D2H %.2f, encoders busy %.2f idle %.2f s\n",
-			t_scan - t0, t_enq - t0, P.t_last_mf - t0, P.t_last_enc - t0, t_blocks - t0, t_md5 - t0, now_s() - t0,
-			(long long)n_early, (long long)n_violations, P.blk_busy, P.mf_busy, P.d2h_busy, P.enc_busy, P.enc_wait);
-	if (with_magic) {
+	if (whole_file) {
+		if (out.put(digest, 16) != 0)
+			return LRZGPU_E_IO;
 		uint8_t magic[21];
 		write_magic(magic, P.sz, in.n);
-		memcpy(out->data(), magic, 21);
+		if (out.finish(magic, 21) != 0)
+			return LRZGPU_E_IO;
+	}
+	if (want_md5)
+		memcpy(ctl->hash_resblock, digest, 16);
+	if (tracing())
+		fprintf(stderr, "lrzgpu driver: %zu chunks, %d scanners: last scan done %.2f  last finder %.2f  last encode %.2f  all blocks %.2f  md5 joined %.2f  assembled %.2f s (since start); early blocks %lld, redone chunks %lld, rescans (victim_round) %lld; worker sums: block copy+gate %.2f finder %.2f lists D2H %.2f, encoders busy %.2f idle %.2f s\n",
+			chunks.size(), scan_slots, t_scan_last - t0, P.t_last_mf - t0, P.t_last_enc - t0, t_blocks - t0, t_md5 - t0, now_s() - t0,
+			(long long)n_early, (long long)n_violations, (long long)n_rescans, P.blk_busy, P.mf_busy, P.d2h_busy, P.enc_busy, P.enc_wait);
+	{
+		ProfileStore &ps = ProfileStore::get();
+		std::lock_guard<std::mutex> lk(ps.mu);
+		ps.p.victim_rescans += n_rescans;
 	}
 	{
 		LzmaParams p;
@@ -1225,24 +1457,159 @@ int run_compress(lrzgpu_control *ctl, const Input &in, std::vector<uint8_t> *out
 	return 0;
 }
 
-int write_all(int fd, const uint8_t *p, size_t n)
+int run_compress(lrzgpu_control *ctl, const CompressSource &in, CompressSink &out, const ChunkSelect *sel)
 {
-	while (n) {
-		ssize_t w = write(fd, p, n > ((size_t)1 << 30) ? ((size_t)1 << 30) : n);
-		if (w <= 0)
-			return LRZGPU_E_IO;
-		p += w;
-		n -= (size_t)w;
+	try {
+		Run r(ctl, in, out, sel);
+		return r.run();
+	} catch (const std::bad_alloc &) {
+		return LRZGPU_E_NOMEM;
+	} catch (...) {
+		return LRZGPU_E_INTERNAL;
 	}
+}
+
+// ---- sinks ----------------------------------------------------------------------------------------
+int MemorySink::begin(size_t placeholder)
+{
+	buf.assign(placeholder, 0);
+	return 0;
+}
+int MemorySink::put(const uint8_t *p, size_t n)
+{
+	buf.insert(buf.end(), p, p + n);
+	return 0;
+}
+int MemorySink::finish(const uint8_t *head, size_t n)
+{
+	if (buf.size() < n)
+		return -1;
+	memcpy(buf.data(), head, n);
 	return 0;
 }
 
-int read_fd_all(int fd, std::vector<uint8_t> *buf)
+int FdSink::begin(size_t placeholder)
 {
-	off_t end = lseek(fd, 0, SEEK_END);
-	if (end < 0 && errno == ESPIPE) {
-		// a pipe / stdin: the reference spools it into a temporary buffer first (src/lrzip.c:627-922)
-		buf->clear();
+	// compress_file() reserves the magic up front and rewrites it at the end (src/lrzip.c:1487-1555);
+	// rzip_fd() alone writes no magic at all
+	if (!with_magic)
+		return 0;
+	start = lseek(fd, 0, SEEK_CUR);
+	seekable = start >= 0;
+	if (!seekable) {
+		held.assign(placeholder, 0); // a pipe: the image is held back until the magic is known
+		return 0;
+	}
+	std::vector<uint8_t> z(placeholder, 0);
+	return write_all(fd, z.data(), z.size());
+}
+int FdSink::put(const uint8_t *p, size_t n)
+{
+	if (with_magic && !seekable) {
+		held.insert(held.end(), p, p + n);
+		return 0;
+	}
+	return write_all(fd, p, n);
+}
+int FdSink::finish(const uint8_t *head, size_t n)
+{
+	if (!with_magic)
+		return 0;
+	if (!seekable) {
+		memcpy(held.data(), head, n);
+		return write_all(fd, held.data(), held.size());
+	}
+	const off_t end = lseek(fd, 0, SEEK_CUR);
+	if (end < 0 || lseek(fd, start, SEEK_SET) < 0 || write_all(fd, head, n) != 0 || lseek(fd, end, SEEK_SET) < 0)
+		return -1;
+	return 0;
+}
+
+} // namespace lrzgpu
+
+// memcpy of a result image: a few threads once it is large (one core moves ~5 GB/s)
+static void big_copy(uint8_t *dst, const uint8_t *src, size_t n)
+{
+	const size_t piece = (size_t)64 << 20;
+	if (n < 2 * piece) {
+		memcpy(dst, src, n);
+		return;
+	}
+	const int nt = n / piece < 8 ? (int)(n / piece) : 8;
+	std::vector<std::thread> th;
+	for (int t = 0; t < nt; t++) {
+		const size_t a = n / nt * t, b = t + 1 == nt ? n : n / nt * (t + 1);
+		th.emplace_back([=] { memcpy(dst + a, src + a, b - a); });
+	}
+	for (auto &x : th)
+		x.join();
+}
+
+template <typename F> static int abi_guard(F &&f) // nothing may leave an extern "C" entry point
+{
+	try {
+		return f();
+	} catch (const std::bad_alloc &) {
+		return LRZGPU_E_NOMEM;
+	} catch (...) {
+		return LRZGPU_E_INTERNAL;
+	}
+}
+
+static int compress_to_malloc(lrzgpu_control *control, const CompressSource &src, uint8_t **out, int64_t *out_len)
+{
+	MemorySink sink;
+	int r = run_compress(control, src, sink, nullptr);
+	if (r)
+		return r;
+	*out = (uint8_t *)malloc(sink.buf.size() ? sink.buf.size() : 1);
+	if (!*out)
+		return LRZGPU_E_NOMEM;
+	big_copy(*out, sink.buf.data(), sink.buf.size());
+	*out_len = (int64_t)sink.buf.size();
+	return 0;
+}
+
+extern "C" int lrzgpu_compress_buffer(lrzgpu_control *control, const uint8_t *in, int64_t n, uint8_t **out, int64_t *out_len)
+{
+	if (!control || !out || !out_len || n < 0 || (!in && n))
+		return LRZGPU_E_PARAM;
+	return abi_guard([&] {
+		CompressSource s;
+		static const uint8_t empty = 0;
+		s.host = in ? in : &empty;
+		s.n = n;
+		return compress_to_malloc(control, s, out, out_len);
+	});
+}
+
+extern "C" int lrzgpu_compress_buffer_dev(lrzgpu_control *control, const void *d_in, int64_t n, uint8_t **out, int64_t *out_len)
+{
+	if (!control || !out || !out_len || n < 0 || (!d_in && n))
+		return LRZGPU_E_PARAM;
+	return abi_guard([&] {
+		CompressSource s;
+		s.dev = (const uint8_t *)d_in;
+		s.n = n;
+		if (n == 0) {
+			static const uint8_t empty = 0;
+			s.dev = nullptr;
+			s.host = &empty;
+		}
+		return compress_to_malloc(control, s, out, out_len);
+	});
+}
+
+// fd_in -> source.  Regular files are read chunk by chunk as the scan needs them (the reference maps one
+// chunk at a time, src/rzip.c:1057-1107); a pipe is spooled first, as the reference does for STDIN
+// (src/lrzip.c:627-922) -- but then compressed like a regular file of that size: the reference's STDIN
+// mode sizes its chunks differently and leaves st_size out of the magic, which is not reproduced.
+static int source_from_fd(int fd, CompressSource *s, std::vector<uint8_t> *spool)
+{
+	const off_t cur = lseek(fd, 0, SEEK_CUR);
+	if (cur < 0) {
+		if (errno != ESPIPE)
+			return LRZGPU_E_IO;
 		std::vector<uint8_t> tmp((size_t)1 << 20);
 		for (;;) {
 			ssize_t r = read(fd, tmp.data(), tmp.size());
@@ -1252,105 +1619,133 @@ int read_fd_all(int fd, std::vector<uint8_t> *buf)
 				return LRZGPU_E_IO;
 			}
 			if (r == 0)
-				return 0;
-			buf->insert(buf->end(), tmp.data(), tmp.data() + r);
+				break;
+			spool->insert(spool->end(), tmp.data(), tmp.data() + r);
 		}
+		static const uint8_t empty = 0;
+		s->host = spool->empty() ? &empty : spool->data();
+		s->n = (int64_t)spool->size();
+		return 0;
 	}
+	const off_t end = lseek(fd, 0, SEEK_END);
 	if (end < 0 || lseek(fd, 0, SEEK_SET) < 0)
 		return LRZGPU_E_IO;
-	buf->resize((size_t)end);
-	size_t got = 0;
-	while (got < (size_t)end) {
-		ssize_t r = read(fd, buf->data() + got, (size_t)end - got > ((size_t)1 << 30) ? ((size_t)1 << 30) : (size_t)end - got);
-		if (r <= 0)
-			return LRZGPU_E_IO;
-		got += (size_t)r;
-	}
-	return 0;
-}
-
-} // namespace
-
-extern "C" int lrzgpu_compress_buffer(lrzgpu_control *control, const uint8_t *in, int64_t n, uint8_t **out, int64_t *out_len)
-{
-	if (!control || n < 0 || (!in && n))
-		return LRZGPU_E_PARAM;
-	Input i;
-	static const uint8_t empty = 0;
-	i.host = in ? in : &empty;
-	i.n = n;
-	std::vector<uint8_t> o;
-	int r = run_compress(control, i, &o, true);
-	if (r)
-		return r;
-	*out = (uint8_t *)malloc(o.size() ? o.size() : 1);
-	if (!*out)
-		return LRZGPU_E_NOMEM;
-	big_copy(*out, o.data(), o.size());
-	*out_len = (int64_t)o.size();
-	return 0;
-}
-
-extern "C" int lrzgpu_compress_buffer_dev(lrzgpu_control *control, const void *d_in, int64_t n, uint8_t **out, int64_t *out_len)
-{
-	if (!control || n < 0 || (!d_in && n))
-		return LRZGPU_E_PARAM;
-	Input i;
-	i.dev = (const uint8_t *)d_in;
-	i.n = n;
-	if (n == 0) {
+	s->fd = fd;
+	s->fd_base = 0;
+	s->n = (int64_t)end;
+	if (s->n == 0) {
 		static const uint8_t empty = 0;
-		i.dev = nullptr;
-		i.host = &empty;
+		s->fd = -1;
+		s->host = &empty;
 	}
-	std::vector<uint8_t> o;
-	int r = run_compress(control, i, &o, true);
-	if (r)
-		return r;
-	*out = (uint8_t *)malloc(o.size() ? o.size() : 1);
-	if (!*out)
-		return LRZGPU_E_NOMEM;
-	big_copy(*out, o.data(), o.size());
-	*out_len = (int64_t)o.size();
 	return 0;
 }
 
-extern "C" int lrzgpu_rzip_fd(lrzgpu_control *control, int fd_in, int fd_out)
+static int compress_fd(lrzgpu_control *control, int fd_in, int fd_out, bool with_magic)
 {
 	if (!control)
 		return LRZGPU_E_PARAM;
-	std::vector<uint8_t> buf;
-	int r = read_fd_all(fd_in, &buf);
-	if (r)
-		return r;
-	Input i;
-	static const uint8_t empty = 0;
-	i.host = buf.empty() ? &empty : buf.data();
-	i.n = (int64_t)buf.size();
-	std::vector<uint8_t> o;
-	r = run_compress(control, i, &o, false);
-	if (r)
-		return r;
-	return write_all(fd_out, o.data(), o.size());
+	return abi_guard([&] {
+		CompressSource s;
+		std::vector<uint8_t> spool;
+		int r = source_from_fd(fd_in, &s, &spool);
+		if (r)
+			return r;
+		FdSink sink;
+		sink.fd = fd_out;
+		sink.with_magic = with_magic;
+		return run_compress(control, s, sink, nullptr);
+	});
 }
 
-extern "C" int lrzgpu_compress_file(lrzgpu_control *control, int fd_in, int fd_out)
+extern "C" int lrzgpu_rzip_fd(lrzgpu_control *control, int fd_in, int fd_out) { return compress_fd(control, fd_in, fd_out, false); }
+
+extern "C" int lrzgpu_compress_file(lrzgpu_control *control, int fd_in, int fd_out) { return compress_fd(control, fd_in, fd_out, true); }
+
+// ---- chunk-sharded compression: one process per GPU, one file ------------------------------------
+extern "C" int lrzgpu_compress_chunks_dev(lrzgpu_control *control, const void *d_in, int64_t n, int first, int stride,
+					  const int64_t *victim_in, int with_md5, lrzgpu_chunk_fn on_chunk, void *ctx)
 {
-	if (!control)
+	if (!control || n < 0 || (!d_in && n) || stride < 1 || first < 0 || first >= stride || !on_chunk)
 		return LRZGPU_E_PARAM;
-	std::vector<uint8_t> buf;
-	int r = read_fd_all(fd_in, &buf);
-	if (r)
-		return r;
-	Input i;
-	static const uint8_t empty = 0;
-	i.host = buf.empty() ? &empty : buf.data();
-	i.n = (int64_t)buf.size();
-	std::vector<uint8_t> o;
-	r = run_compress(control, i, &o, true);
-	if (r)
-		return r;
-	return write_all(fd_out, o.data(), o.size());
+	return abi_guard([&] {
+		CompressSource s;
+		s.dev = (const uint8_t *)d_in;
+		s.n = n;
+		if (n == 0) {
+			static const uint8_t empty = 0;
+			s.dev = nullptr;
+			s.host = &empty;
+		}
+		ChunkSelect sel;
+		sel.first = first;
+		sel.stride = stride;
+		sel.victim_in = victim_in;
+		sel.with_md5 = with_md5 != 0;
+		sel.on_chunk = on_chunk;
+		sel.ctx = ctx;
+		MemorySink unused;
+		return run_compress(control, s, unused, &sel);
+	});
+}
+
+extern "C" int lrzgpu_compress_chunks(lrzgpu_control *control, const uint8_t *in, int64_t n, int first, int stride,
+				      const int64_t *victim_in, int with_md5, lrzgpu_chunk_fn on_chunk, void *ctx)
+{
+	if (!control || n < 0 || (!in && n) || stride < 1 || first < 0 || first >= stride || !on_chunk)
+		return LRZGPU_E_PARAM;
+	return abi_guard([&] {
+		CompressSource s;
+		static const uint8_t empty = 0;
+		s.host = in ? in : &empty;
+		s.n = n;
+		ChunkSelect sel;
+		sel.first = first;
+		sel.stride = stride;
+		sel.victim_in = victim_in;
+		sel.with_md5 = with_md5 != 0;
+		sel.on_chunk = on_chunk;
+		sel.ctx = ctx;
+		MemorySink unused;
+		return run_compress(control, s, unused, &sel);
+	});
+}
+
+// rank 0's half: the file from finished chunk images, in order (magic, chunks, MD5) -- host only
+extern "C" int lrzgpu_assemble_chunks(lrzgpu_control *control, int64_t st_size, int n_chunks, const uint8_t *const *chunk_img,
+				      const int64_t *chunk_len, const uint8_t md5[16], uint8_t **out, int64_t *out_len)
+{
+	if (!control || st_size < 0 || n_chunks < 1 || !chunk_img || !chunk_len || !md5 || !out || !out_len)
+		return LRZGPU_E_PARAM;
+	return abi_guard([&] {
+		Sizing s;
+		int r = compute_sizing(control, st_size, &s);
+		if (r)
+			return r;
+		size_t total = 21 + 16;
+		for (int c = 0; c < n_chunks; c++) {
+			if (chunk_len[c] < 0 || !chunk_img[c])
+				return LRZGPU_E_PARAM;
+			total += (size_t)chunk_len[c];
+		}
+		uint8_t *o = (uint8_t *)malloc(total);
+		if (!o)
+			return LRZGPU_E_NOMEM;
+		write_magic(o, s, st_size);
+		size_t at = 21;
+		for (int c = 0; c < n_chunks; c++) {
+			big_copy(o + at, chunk_img[c], (size_t)chunk_len[c]);
+			at += (size_t)chunk_len[c];
+		}
+		memcpy(o + at, md5, 16);
+		*out = o;
+		*out_len = (int64_t)total;
+		control->st_size = st_size;
+		control->stream_bufsize = s.stream_bufsize;
+		control->dictSize_used = s.dict_size;
+		control->threads_used = s.threads;
+		return 0;
+	});
 }
 
 // ---- host-only helpers (no device needed) ----------------------------------------------------
@@ -1379,38 +1774,40 @@ extern "C" int lrzgpu_container_store(lrzgpu_control *control, int64_t st_size, 
 {
 	if (!control || n_chunks < 1)
 		return LRZGPU_E_PARAM;
-	Sizing s;
-	int r = compute_sizing(control, st_size, &s);
-	if (r)
-		return r;
-	std::vector<uint8_t> o(21, 0);
-	for (int c = 0; c < n_chunks; c++) {
-		std::vector<uint8_t> s0(stream0[c], stream0[c] + stream0_len[c]);
-		const int cb = chunk_bytes_for(chunk_sizes[c]);
-		std::vector<BlockRef> refs;
-		block_order(s0, cb, stream1_len[c], s.stream_bufsize, &refs);
-		std::vector<DoneBlock> blocks;
-		for (const BlockRef &br : refs) {
-			DoneBlock b;
-			b.streamno = br.streamno;
-			b.c_type = CTYPE_NONE;
-			b.s_len = br.len;
-			const uint8_t *src = br.streamno == 0 ? stream0[c] : stream1[c];
-			if (br.streamno == 1 && br.off + br.len > stream1_len[c])
-				return LRZGPU_E_PARAM;
-			b.payload.assign(src + br.off, src + br.off + br.len);
-			blocks.push_back(std::move(b));
+	return abi_guard([&] {
+		Sizing s;
+		int r = compute_sizing(control, st_size, &s);
+		if (r)
+			return r;
+		std::vector<uint8_t> o(21, 0);
+		for (int c = 0; c < n_chunks; c++) {
+			std::vector<uint8_t> s0(stream0[c], stream0[c] + stream0_len[c]);
+			const int cb = chunk_bytes_for(chunk_sizes[c]);
+			std::vector<BlockRef> refs;
+			block_order(s0, cb, stream1_len[c], s.stream_bufsize, &refs);
+			std::vector<DoneBlock> blocks;
+			for (const BlockRef &br : refs) {
+				DoneBlock b;
+				b.streamno = br.streamno;
+				b.c_type = CTYPE_NONE;
+				b.s_len = br.len;
+				const uint8_t *src = br.streamno == 0 ? stream0[c] : stream1[c];
+				if (br.streamno == 1 && br.off + br.len > stream1_len[c])
+					return LRZGPU_E_PARAM;
+				b.payload.assign(src + br.off, src + br.off + br.len);
+				blocks.push_back(std::move(b));
+			}
+			write_chunk(&o, cb, c + 1 == n_chunks, chunk_sizes[c], blocks);
 		}
-		write_chunk(&o, cb, c + 1 == n_chunks, chunk_sizes[c], blocks);
-	}
-	o.insert(o.end(), md5, md5 + 16);
-	uint8_t magic[21];
-	write_magic(magic, s, st_size);
-	memcpy(o.data(), magic, 21);
-	*out = (uint8_t *)malloc(o.size());
-	if (!*out)
-		return LRZGPU_E_NOMEM;
-	big_copy(*out, o.data(), o.size());
-	*out_len = (int64_t)o.size();
-	return 0;
+		o.insert(o.end(), md5, md5 + 16);
+		uint8_t magic[21];
+		write_magic(magic, s, st_size);
+		memcpy(o.data(), magic, 21);
+		*out = (uint8_t *)malloc(o.size());
+		if (!*out)
+			return LRZGPU_E_NOMEM;
+		big_copy(*out, o.data(), o.size());
+		*out_len = (int64_t)o.size();
+		return 0;
+	});
 }

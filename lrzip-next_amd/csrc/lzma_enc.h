@@ -1,9 +1,10 @@
-// lzma_enc.h -- host-side LZMA parser + range coder of the MI355X path.
+// lzma_enc.h -- interface of the host half of the LZMA back end (lzma_parser.cpp, lzma_model.h,
+// lzma_rangecoder.h).
 //
 // The GPU match finder (lzma_mf.hip) produces, for every position of a block, the exact
 // (len, dist-1) list the reference encoder would receive from its multithreaded BT4 finder
-// (reference src/lzma/C/LzFindMt.c:1274-1317).  This encoder consumes those lists and emits the
-// raw LZMA stream of reference src/lzma/C/LzmaEnc.c (optimal parser, algo=1) bit for bit.
+// (reference src/lzma/C/LzFindMt.c:1274-1317).  The host parser consumes those lists and emits the
+// raw LZMA stream the reference's encoder (src/lzma/C/LzmaEnc.c) writes, bit for bit.
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -14,15 +15,11 @@ namespace lrzgpu {
 // Per-position match lists for one block, in position order:
 //   counts[i]  = number of u32 entries of position i (2 per (len, dist-1) pair, lengths increasing)
 //   pairs[]    = the entries of position 0, then position 1, ...
-// The encoder walks positions monotonically, so it keeps the running offset itself.
+// The parser walks positions monotonically and reads the lists in place.
 struct MatchLists {
 	const uint8_t *counts = nullptr; // n entries
 	const uint32_t *pairs = nullptr;
 	bool packed = false; // pairs[] holds one u32 per pair: len << 25 | dist-1 (counts[] still counts 2 per pair)
-	// Optional streaming hook: called before position `upto` is first read, so a producer that is
-	// still filling the arrays can block the consumer.  May be null.
-	void (*wait_ready)(void *ctx, size_t upto) = nullptr;
-	void *ctx = nullptr;
 };
 
 struct LzmaParams {

@@ -1,0 +1,873 @@
+// lzma_parser.cpp -- host half of the LZMA back end: price-driven parse of a block into literals / matches /
+// repeats from the GPU's per-position match lists, and the range coding of that parse.
+//
+// The bytes must equal what the reference encoder writes (src/lzma/C/LzmaEnc.c: GetOptimum 1219-1968 for
+// levels 5-9, GetOptimumFast 1970-2098 for levels 1-4, LzmaEnc_CodeOneBlock 2383-2680), so WHAT is decided
+// is fixed: which candidate edges exist at a position, their prices, which of two equal prices wins, how far
+// ahead the search may look, when the price tables are refreshed.  HOW it is computed is this file's own:
+//
+//   * The search is a shortest-path relaxation over a window of "arrival" nodes kept as parallel arrays
+//     (structure of arrays): cost[], via[] (one packed 64-bit edge descriptor), state[], reps[] (one 128-bit
+//     quadruple).  Relaxing an edge is branch-free -- compare, two conditional moves -- because whether a
+//     candidate beats the incumbent is a coin toss the branch predictor loses.
+//   * "Every length from a to b of one repeat / one match distance" is ONE span relaxation: the length
+//     prices are contiguous in the length (lzma_model.h), the nodes are contiguous in the arrival position,
+//     so eight candidate edges are priced, compared and merged per AVX2 step.
+//   * Match lists are consumed in place from the finder's packed stream (one 32-bit word per pair); nothing
+//     is copied or rewritten, a list that has to wait for the next parse is just a view that stays alive.
+//   * The chosen path is handed to the coder as a short queue of steps, separate from the search arrays.
+//   * The range coder is branch-free per coded bit (lzma_rangecoder.h).
+#include <immintrin.h>
+
+#include <cstring>
+#include <memory>
+
+#include "lzma_enc.h"
+#include "lzma_model.h"
+
+namespace lrzgpu {
+namespace {
+
+constexpr unsigned kWindow = 1u << 11;       // arrival nodes per search (the format's encoder looks this far)
+constexpr unsigned kWindowGuard = 64;        // the search is cut when this close to the end of the window
+constexpr uint32_t kLiteral = 0xFFFFFFFFu;   // step / edge code of a literal
+constexpr unsigned kRepSlots = 4;            // codes 0..3 are the repeat distances, 4 + d a fresh distance d
+constexpr unsigned kRefreshEvery = 64;       // matches (resp. repeat lengths) between price table refreshes
+
+// number of equal bytes of a[] and b[] in [from, limit)  (first mismatch index, limit if none)
+inline unsigned equal_until(const uint8_t *a, const uint8_t *b, unsigned from, unsigned limit)
+{
+	unsigned i = from;
+	while (i + 8 <= limit) {
+		uint64_t x, y;
+		memcpy(&x, a + i, 8);
+		memcpy(&y, b + i, 8);
+		x ^= y;
+		if (x)
+			return i + ((unsigned)__builtin_ctzll(x) >> 3);
+		i += 8;
+	}
+	while (i < limit && a[i] == b[i])
+		i++;
+	return i;
+}
+inline bool same2(const uint8_t *a, const uint8_t *b)
+{
+	uint16_t x, y;
+	memcpy(&x, a, 2);
+	memcpy(&y, b, 2);
+	return x == y;
+}
+
+// One position's match list, viewed in the finder's output (pairs sorted by increasing length).
+template <bool PACKED> struct PairView {
+	const uint32_t *w = nullptr;
+	unsigned count = 0; // pairs
+	inline unsigned len(unsigned k) const { return PACKED ? w[k] >> 25 : w[2 * k]; }
+	inline uint32_t dist(unsigned k) const { return PACKED ? w[k] & 0x1FFFFFFu : w[2 * k + 1]; }
+};
+
+// edge descriptor: how a node was reached.  `len` bytes with distance code `code`; `pre` != 0 means the edge
+// is a compound: pre == 1: one literal, then a repeat-0 match of `len`; pre >= 2: a match/repeat of pre - 1
+// bytes with `code`, one literal, then a repeat-0 match of `len`.
+inline uint64_t edge(unsigned len, uint32_t code, unsigned pre = 0) { return (uint64_t)code | ((uint64_t)len << 32) | ((uint64_t)pre << 48); }
+inline uint32_t edge_code(uint64_t e) { return (uint32_t)e; }
+inline unsigned edge_len(uint64_t e) { return (unsigned)(e >> 32) & 0xFFFF; }
+inline unsigned edge_pre(uint64_t e) { return (unsigned)(e >> 48); }
+
+struct Step {
+	uint32_t len, code;
+};
+
+template <bool PACKED> struct BlockEncoder {
+	// ---- input ----------------------------------------------------------------------------------
+	const uint8_t *data = nullptr;
+	size_t n = 0;
+	const uint8_t *counts = nullptr; // u32 entries per position (2 per pair)
+	const uint32_t *words = nullptr;
+	size_t fetch_pos = 0;            // next position whose list has not been taken yet
+	uint64_t fetch_off = 0;          // its offset into the finder stream, in u32 entries of the unpacked form
+	unsigned ahead = 0;              // positions taken from the finder beyond the coder's position
+
+	// ---- parameters --------------------------------------------------------------------------------
+	unsigned nice_len = 64; // "fast bytes": a match this long is taken without further search
+	unsigned pos_mask = 3;
+	unsigned dist_slots = 0;
+	bool greedy = false;
+
+	// ---- coder -----------------------------------------------------------------------------------------
+	RangeEncoder rc;
+	LzmaModel model;
+	PriceTables prices;
+	unsigned state = 0;
+	uint32_t reps[kRepSlots] = {1, 1, 1, 1};
+	unsigned matches_since_refresh = 0;
+	int rep_lens_until_refresh = (int)kRefreshEvery;
+
+	// ---- search window (structure of arrays) ---------------------------------------------------------------
+	alignas(32) uint32_t cost[kWindow + kLenMax + 16];
+	alignas(32) uint64_t via[kWindow + kLenMax + 16];
+	uint8_t node_state[kWindow + kLenMax + 16];
+	alignas(16) uint32_t node_reps[kWindow + kLenMax + 16][kRepSlots];
+
+	// a list fetched for the position after the parse it ended (a match of nice_len there cuts the search)
+	PairView<PACKED> held;
+	unsigned held_len = 0;
+	uint32_t avail_at_fetch = 0; // bytes from the last fetched position to the end of the block
+
+	Step queue[kWindow + 8];
+	unsigned q_head = 0, q_tail = 0;
+
+	// ---- finder stream -----------------------------------------------------------------------------------
+	inline PairView<PACKED> take()
+	{
+		ahead++;
+		avail_at_fetch = (uint32_t)(n - fetch_pos);
+		const unsigned c = counts[fetch_pos];
+		PairView<PACKED> v;
+		v.w = words + (PACKED ? (fetch_off >> 1) : fetch_off);
+		v.count = c >> 1;
+		fetch_off += c;
+		fetch_pos++;
+		return v;
+	}
+	inline void skip(unsigned k)
+	{
+		ahead += k;
+		uint64_t sum = 0;
+		const uint8_t *c = counts + fetch_pos;
+		for (unsigned i = 0; i < k; i++)
+			sum += c[i];
+		fetch_off += sum;
+		fetch_pos += k;
+	}
+	// longest length of a list; a longest pair of exactly nice_len is extended over the bytes that follow
+	// (the finder stops comparing there)
+	inline unsigned longest(const PairView<PACKED> &v) const
+	{
+		if (!v.count)
+			return 0;
+		unsigned len = v.len(v.count - 1);
+		if (len != nice_len)
+			return len;
+		const uint32_t room = avail_at_fetch > kLenMax ? kLenMax : avail_at_fetch;
+		const uint8_t *here = data + fetch_pos - 1;
+		return equal_until(here, here - v.dist(v.count - 1) - 1, len, room);
+	}
+
+	// ---- relaxation primitives ------------------------------------------------------------------------------
+	inline void relax(unsigned node, uint32_t c, uint64_t e)
+	{
+		const uint32_t old = cost[node];
+		const uint64_t olde = via[node];
+		const bool better = c < old;
+		cost[node] = better ? c : old;
+		via[node] = better ? e : olde;
+	}
+	// edges (len, code) for every len in [lo, hi] from node `from`: price = base + len_row[len]
+	inline void relax_span(unsigned from, unsigned lo, unsigned hi, uint32_t base, const uint32_t *len_row, uint32_t code)
+	{
+		const __m256i vbase = _mm256_set1_epi32((int)base);
+		const __m256i iota = _mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7);
+		const __m256i code64 = _mm256_set1_epi64x((long long)code);
+		for (unsigned l = lo; l <= hi; l += 8) {
+			const unsigned left = hi - l + 1; // lanes in use: min(left, 8)
+			const __m256i live = _mm256_cmpgt_epi32(_mm256_set1_epi32((int)left), iota);
+			const __m256i cand = _mm256_add_epi32(vbase, _mm256_loadu_si256((const __m256i *)(len_row + l)));
+			uint32_t *cp = cost + from + l;
+			uint64_t *vp = via + from + l;
+			const __m256i old = _mm256_loadu_si256((const __m256i *)cp);
+			// prices stay far below 2^31: a signed compare is an unsigned one
+			const __m256i win = _mm256_and_si256(_mm256_cmpgt_epi32(old, cand), live);
+			_mm256_storeu_si256((__m256i *)cp, _mm256_blendv_epi8(old, cand, win));
+			const __m256i lens = _mm256_add_epi32(_mm256_set1_epi32((int)l), iota);
+			const __m256i e_lo = _mm256_or_si256(_mm256_slli_epi64(_mm256_cvtepu32_epi64(_mm256_castsi256_si128(lens)), 32), code64);
+			const __m256i e_hi = _mm256_or_si256(_mm256_slli_epi64(_mm256_cvtepu32_epi64(_mm256_extracti128_si256(lens, 1)), 32), code64);
+			const __m256i w_lo = _mm256_cvtepi32_epi64(_mm256_castsi256_si128(win));
+			const __m256i w_hi = _mm256_cvtepi32_epi64(_mm256_extracti128_si256(win, 1));
+			_mm256_storeu_si256((__m256i *)vp, _mm256_blendv_epi8(_mm256_loadu_si256((const __m256i *)vp), e_lo, w_lo));
+			_mm256_storeu_si256((__m256i *)(vp + 4), _mm256_blendv_epi8(_mm256_loadu_si256((const __m256i *)(vp + 4)), e_hi, w_hi));
+		}
+	}
+
+	// ---- prices of the flag bits in front of a symbol ----------------------------------------------------------------
+	inline uint32_t price_short_rep(unsigned st, unsigned ps) const
+	{
+		return prices.bit.zero(model.is_rep0[st]) + prices.bit.zero(model.is_rep0_long[st][ps]);
+	}
+	inline uint32_t price_rep_choice(unsigned which, unsigned st, unsigned ps) const
+	{
+		if (which == 0)
+			return prices.bit.zero(model.is_rep0[st]) + prices.bit.one(model.is_rep0_long[st][ps]);
+		uint32_t pr = prices.bit.one(model.is_rep0[st]);
+		if (which == 1)
+			return pr + prices.bit.zero(model.is_rep1[st]);
+		return pr + prices.bit.one(model.is_rep1[st]) + prices.bit.bit(model.is_rep2[st], which - 2);
+	}
+	// everything of "a repeat-0 match follows" except its length
+	inline uint32_t price_rep0_after(unsigned st, unsigned ps) const
+	{
+		return prices.bit.one(model.is_match[st][ps]) + prices.bit.one(model.is_rep[st]) + prices.bit.zero(model.is_rep0[st]) +
+		       prices.bit.one(model.is_rep0_long[st][ps]);
+	}
+	inline uint32_t price_literal(uint32_t pos, unsigned st, const uint8_t *p, unsigned match_byte) const
+	{
+		const Prob *ctx = model.literal_context(pos, p[-1]);
+		return last_was_literal(st) ? prices.literal(ctx, p[0]) : prices.literal_matched(ctx, p[0], match_byte);
+	}
+
+	// ---- the parse -----------------------------------------------------------------------------------------
+	inline unsigned single(uint32_t code, Step *first)
+	{
+		first->len = 1;
+		first->code = code;
+		return 1;
+	}
+
+	// Compound edge "X of x_len bytes, one literal, repeat-0": X ends at here + x_len with distance `dist`;
+	// if at least two bytes after the literal continue at that distance, the whole thing is one candidate.
+	// `price_x` = price up to and including X.  Returns the node it reaches (0 if none).
+	inline unsigned try_literal_then_rep0(unsigned cur, const uint8_t *here, uint32_t position, unsigned x_len, uint32_t dist,
+					       unsigned st_after_x, uint32_t price_x, uint32_t room, uint32_t code)
+	{
+		const uint8_t *there = here - dist;
+		unsigned tail = x_len + 1; // the literal's index
+		unsigned limit = tail + nice_len;
+		if (limit > room)
+			limit = room;
+		tail += 2;
+		if (tail > limit || !same2(here + tail - 2, there + tail - 2))
+			return 0;
+		const unsigned end = equal_until(here, there, tail, limit);
+		const unsigned rep_len = end - x_len - 1;
+		const unsigned ps_lit = (position + x_len) & pos_mask;
+		uint32_t pr = price_x + prices.bit.zero(model.is_match[st_after_x][ps_lit]) +
+			      prices.literal_matched(model.literal_context(position + x_len, here[x_len - 1]), here[x_len], there[x_len]);
+		const unsigned st_lit = after_literal(st_after_x), ps_rep = (ps_lit + 1) & pos_mask;
+		pr += price_rep0_after(st_lit, ps_rep) + prices.rep_len.row[ps_rep][rep_len];
+		const unsigned node = cur + end;
+		relax(node, pr, edge(rep_len, code, x_len + 1));
+		return node;
+	}
+
+	unsigned plan(uint32_t position, Step *first)
+	{
+		// ---- the root: what can start at the coder's position -------------------------------------------
+		PairView<PACKED> list;
+		unsigned main_len;
+		if (ahead == 0) {
+			list = take();
+			main_len = longest(list);
+		} else {
+			list = held;
+			main_len = held_len;
+		}
+		uint32_t room = avail_at_fetch;
+		if (room < 2)
+			return single(kLiteral, first);
+		if (room > kLenMax)
+			room = kLenMax;
+		const uint8_t *here = data + fetch_pos - 1;
+
+		unsigned rep_len[kRepSlots] = {0, 0, 0, 0};
+		unsigned best_rep = 0;
+		for (unsigned i = 0; i < kRepSlots; i++) {
+			const uint8_t *there = here - reps[i];
+			if (!same2(here, there))
+				continue;
+			const unsigned len = equal_until(here, there, 2, room);
+			rep_len[i] = len;
+			if (len > rep_len[best_rep])
+				best_rep = i;
+			if (len == kLenMax)
+				break;
+		}
+		if (rep_len[best_rep] >= nice_len) {
+			first->len = rep_len[best_rep];
+			first->code = best_rep;
+			skip(first->len - 1);
+			return first->len;
+		}
+		if (main_len >= nice_len) {
+			first->len = main_len;
+			first->code = list.dist(list.count - 1) + kRepSlots;
+			skip(main_len - 1);
+			return main_len;
+		}
+		const unsigned cur_byte = here[0], match_byte = here[-(ptrdiff_t)reps[0]];
+		unsigned frontier = rep_len[best_rep] > main_len ? rep_len[best_rep] : main_len; // furthest node with an edge into it
+		if (frontier < 2 && cur_byte != match_byte)
+			return single(kLiteral, first);
+
+		const unsigned ps0 = position & pos_mask;
+		node_state[0] = (uint8_t)state;
+		memcpy(node_reps[0], reps, sizeof(reps));
+		{
+			const Prob m = model.is_match[state][ps0];
+			cost[1] = prices.bit.zero(m) + price_literal(position, state, here, match_byte);
+			via[1] = edge(1, kLiteral);
+			const uint32_t as_match = prices.bit.one(m), as_rep = as_match + prices.bit.one(model.is_rep[state]);
+			if (match_byte == cur_byte && rep_len[0] == 0) {
+				relax(1, as_rep + price_short_rep(state, ps0), edge(1, 0));
+				if (frontier < 2) {
+					const uint32_t code = edge_code(via[1]);
+					cost[1] = kPriceInfinite;
+					return single(code, first);
+				}
+			}
+			for (unsigned i = 0; i < kRepSlots; i++)
+				if (rep_len[i] >= 2)
+					relax_span(0, 2, rep_len[i], as_rep + price_rep_choice(i, state, ps0), prices.rep_len.row[ps0], i);
+			// fresh distances: lengths up to rep_len[0] are never cheaper than the repeat, they are not tried
+			unsigned lo = rep_len[0] + 1;
+			if (lo < 2)
+				lo = 2;
+			if (lo <= main_len)
+				relax_matches(0, list, list.count, lo, main_len, as_match + prices.bit.zero(model.is_rep[state]), ps0, nullptr, 0, 0, 0, 0, &frontier);
+		}
+
+		// ---- expand node after node until the frontier is reached -----------------------------------------
+		unsigned cur = 0;
+		for (;;) {
+			if (++cur == frontier)
+				break;
+			if (cur >= kWindow - kWindowGuard) {
+				// out of window: stop at the cheapest node at or beyond here (the later one on a tie)
+				unsigned best = cur;
+				uint32_t c = cost[cur];
+				for (unsigned j = cur + 1; j <= frontier; j++)
+					if (cost[j] <= c) {
+						c = cost[j];
+						best = j;
+					}
+				if (best != cur)
+					skip(best - cur);
+				cur = best;
+				break;
+			}
+			const PairView<PACKED> fresh = take();
+			unsigned new_len = longest(fresh);
+			if (new_len >= nice_len) { // a match worth taking outright starts here: the parse ends at this node
+				held = fresh;
+				held_len = new_len;
+				break;
+			}
+			position++;
+
+			// -- how this node was reached decides the coder state and the repeat distances here
+			const uint64_t e = via[cur];
+			const unsigned elen = edge_len(e), epre = edge_pre(e);
+			const uint32_t ecode = edge_code(e);
+			unsigned st;
+			uint32_t r[kRepSlots];
+			{
+				unsigned origin = cur - elen;
+				if (elen == 1 && !epre) { // literal or short repeat: distances unchanged
+					st = node_state[origin];
+					st = ecode == 0 ? after_short_rep(st) : after_literal(st);
+					memcpy(r, node_reps[origin], sizeof(r));
+				} else {
+					if (epre) {
+						origin -= epre;
+						st = epre == 1 ? (ecode < kRepSlots ? 8u : 7u) : 8u; // ... literal, then a repeat (or, pre == 1, whatever `code` says)
+					} else {
+						st = node_state[origin];
+						st = ecode < kRepSlots ? after_rep(st) : after_match(st);
+					}
+					const uint32_t *o = node_reps[origin];
+					if (ecode < kRepSlots) { // move the used distance to the front
+						r[0] = o[ecode];
+						unsigned k = 1;
+						for (unsigned i = 0; i < kRepSlots; i++)
+							if (i != ecode)
+								r[k++] = o[i];
+					} else {
+						r[0] = ecode - kRepSlots + 1;
+						r[1] = o[0];
+						r[2] = o[1];
+						r[3] = o[2];
+					}
+				}
+			}
+			node_state[cur] = (uint8_t)st;
+			memcpy(node_reps[cur], r, sizeof(r));
+
+			here = data + fetch_pos - 1;
+			const unsigned cb = here[0], mb = here[-(ptrdiff_t)r[0]];
+			const unsigned ps = position & pos_mask;
+			const uint32_t here_cost = cost[cur];
+			const Prob m = model.is_match[st][ps];
+			const uint32_t as_match = here_cost + prices.bit.one(m), as_rep = as_match + prices.bit.one(model.is_rep[st]);
+
+			// -- literal.  Not priced when the next node already has an edge and the byte equals the repeat-0
+			// byte (a repeat will cover it), nor when the flag bit alone already costs more than the incumbent.
+			uint32_t lit_cost = here_cost + prices.bit.zero(m);
+			bool lit_priced = false, lit_won = false;
+			if (!((cost[cur + 1] < kPriceInfinite && mb == cb) || lit_cost > cost[cur + 1])) {
+				lit_cost += price_literal(position, st, here, mb);
+				lit_priced = true;
+				if (lit_cost < cost[cur + 1]) {
+					cost[cur + 1] = lit_cost;
+					via[cur + 1] = edge(1, kLiteral);
+					lit_won = true;
+				}
+			}
+			// -- short repeat (one byte at repeat-0), only straight after a literal
+			if (last_was_literal(st) && mb == cb && as_rep < cost[cur + 1]) {
+				const uint64_t inc = via[cur + 1];
+				if (edge_len(inc) < 2 || edge_code(inc) != 0) {
+					const uint32_t c = as_rep + price_short_rep(st, ps);
+					if (c < cost[cur + 1]) {
+						cost[cur + 1] = c;
+						via[cur + 1] = edge(1, 0);
+						lit_won = false;
+					}
+				}
+			}
+
+			uint32_t room_full = avail_at_fetch;
+			if (room_full > kWindow - 1 - cur)
+				room_full = kWindow - 1 - cur;
+			if (room_full < 2)
+				continue;
+			const unsigned room_nice = room_full <= nice_len ? room_full : nice_len;
+
+			// -- literal, then repeat-0
+			if (!lit_won && lit_priced && mb != cb && room_full > 2) {
+				const uint8_t *there = here - r[0];
+				if (same2(here + 1, there + 1)) {
+					unsigned limit = nice_len + 1;
+					if (limit > room_full)
+						limit = room_full;
+					const unsigned end = equal_until(here, there, 3, limit);
+					const unsigned st2 = after_literal(st), ps2 = (position + 1) & pos_mask;
+					const unsigned node = cur + end;
+					if (frontier < node)
+						frontier = node;
+					relax(node, lit_cost + price_rep0_after(st2, ps2) + prices.rep_len.row[ps2][end - 1], edge(end - 1, 0, 1));
+				}
+			}
+
+			// -- repeats
+			unsigned match_from = 2; // shortest fresh-distance length worth pricing
+			for (unsigned i = 0; i < kRepSlots; i++) {
+				const uint8_t *there = here - r[i];
+				if (!same2(here, there))
+					continue;
+				const unsigned len = equal_until(here, there, 2, room_nice);
+				if (frontier < cur + len)
+					frontier = cur + len;
+				const uint32_t base = as_rep + price_rep_choice(i, st, ps);
+				relax_span(cur, 2, len, base, prices.rep_len.row[ps], i);
+				if (i == 0)
+					match_from = len + 1;
+				const unsigned node = try_literal_then_rep0(cur, here, position, len, r[i], after_rep(st), base + prices.rep_len.row[ps][len], room_full, i);
+				if (frontier < node)
+					frontier = node;
+			}
+
+			// -- fresh distances
+			unsigned pairs = fresh.count;
+			if (new_len > room_nice) { // the list may reach past what can still be used: clip it
+				new_len = room_nice;
+				pairs = 0;
+				while (new_len > fresh.len(pairs))
+					pairs++;
+				pairs++; // the first pair at least that long stands for new_len
+			}
+			if (new_len >= match_from) {
+				if (frontier < cur + new_len)
+					frontier = cur + new_len;
+				relax_matches(cur, fresh, pairs, match_from, new_len, as_match + prices.bit.zero(model.is_rep[st]), ps, here, position, st, room_full, 1, &frontier);
+			}
+		}
+
+		// ---- the window is clean again for the next parse; walk the winning path back ----------------------
+		for (unsigned k = 1; k <= frontier; k++)
+			cost[k] = kPriceInfinite;
+		return trace_back(cur, first);
+	}
+
+	// edges of fresh distances from node `cur`: for every length lo..hi the nearest distance that reaches it
+	// (pair k covers the lengths above pair k-1's up to its own; the last usable pair is clipped to hi),
+	// plus, with `compound`, the "match, literal, repeat-0" edge at the full length of every pair.
+	inline void relax_matches(unsigned cur, const PairView<PACKED> &list, unsigned pairs, unsigned lo, unsigned hi, uint32_t base,
+				  unsigned ps, const uint8_t *here, uint32_t position, unsigned st, uint32_t room_full, int compound,
+				  unsigned *frontier)
+	{
+		unsigned k = 0;
+		while (lo > list.len(k) && k + 1 < pairs)
+			k++;
+		const uint32_t *len_row = prices.match_len.row[ps];
+		unsigned len = lo;
+		for (; k < pairs; k++) {
+			unsigned top = list.len(k);
+			if (k + 1 == pairs || top > hi)
+				top = hi;
+			const uint32_t d = list.dist(k);
+			const uint32_t code = d + kRepSlots;
+			// lengths 2, 3, 4 have their own distance contexts; from 5 on the distance price is one constant
+			for (; len <= top && len < kLenMin + kLenToDistStates - 1; len++)
+				relax(cur + len, base + len_row[len] + prices.distance(len - kLenMin, d), edge(len, code));
+			if (len <= top) {
+				relax_span(cur, len, top, base + prices.distance(kLenToDistStates - 1, d), len_row, code);
+				len = top + 1;
+			}
+			if (compound) {
+				const uint32_t price_x = base + len_row[top] + prices.distance(len_dist_state(top), d);
+				const unsigned node = try_literal_then_rep0(cur, here, position, top, d + 1, after_match(st), price_x, room_full, code);
+				if (*frontier < node)
+					*frontier = node;
+			}
+			if (top == hi)
+				break;
+		}
+	}
+
+	// from node `cur` back to node 0: the steps in coding order go to the queue, the first one to the caller
+	unsigned trace_back(unsigned cur, Step *first)
+	{
+		Step tmp[kWindow + 8];
+		unsigned k = 0;
+		while (cur) {
+			const uint64_t e = via[cur];
+			const unsigned len = edge_len(e), pre = edge_pre(e);
+			const uint32_t code = edge_code(e);
+			if (!pre) {
+				tmp[k++] = Step{len, code};
+				cur -= len;
+			} else if (pre == 1) {
+				tmp[k++] = Step{len, code}; // the repeat-0 (its code is 0) ...
+				tmp[k++] = Step{1, kLiteral}; // ... after one literal
+				cur -= len + 1;
+			} else {
+				tmp[k++] = Step{len, 0};
+				tmp[k++] = Step{1, kLiteral};
+				tmp[k++] = Step{pre - 1, code};
+				cur -= len + pre;
+			}
+		}
+		*first = tmp[--k];
+		q_head = q_tail = 0;
+		while (k)
+			queue[q_tail++] = tmp[--k];
+		return first->len;
+	}
+
+	// ---- levels 1-4: greedy with one position of look-ahead (reference GetOptimumFast) -----------------------------
+	static inline bool much_nearer(uint32_t small_dist, uint32_t big_dist) { return (big_dist >> 7) > small_dist; }
+	unsigned plan_greedy(Step *first)
+	{
+		PairView<PACKED> list;
+		unsigned main_len;
+		if (ahead == 0) {
+			list = take();
+			main_len = longest(list);
+		} else {
+			list = held;
+			main_len = held_len;
+		}
+		uint32_t room = avail_at_fetch;
+		if (room < 2)
+			return single(kLiteral, first);
+		if (room > kLenMax)
+			room = kLenMax;
+		const uint8_t *here = data + fetch_pos - 1;
+		unsigned rep_best = 0, rep_which = 0;
+		for (unsigned i = 0; i < kRepSlots; i++) {
+			const uint8_t *there = here - reps[i];
+			if (!same2(here, there))
+				continue;
+			const unsigned len = equal_until(here, there, 2, room);
+			if (len >= nice_len) {
+				first->len = len;
+				first->code = i;
+				skip(len - 1);
+				return len;
+			}
+			if (len > rep_best) {
+				rep_which = i;
+				rep_best = len;
+			}
+		}
+		if (main_len >= nice_len) {
+			first->len = main_len;
+			first->code = list.dist(list.count - 1) + kRepSlots;
+			skip(main_len - 1);
+			return main_len;
+		}
+		uint32_t main_dist = 0;
+		if (main_len >= 2) {
+			unsigned k = list.count - 1;
+			main_dist = list.dist(k);
+			// one byte shorter but more than 128 times nearer is the better deal
+			while (k > 0 && main_len == list.len(k - 1) + 1 && much_nearer(list.dist(k - 1), main_dist)) {
+				k--;
+				main_len--;
+				main_dist = list.dist(k);
+			}
+			if (main_len == 2 && main_dist >= 0x80)
+				main_len = 1;
+		}
+		if (rep_best >= 2 && (rep_best + 1 >= main_len || (rep_best + 2 >= main_len && main_dist >= (1u << 9)) ||
+				      (rep_best + 3 >= main_len && main_dist >= (1u << 15)))) {
+			first->len = rep_best;
+			first->code = rep_which;
+			skip(rep_best - 1);
+			return rep_best;
+		}
+		if (main_len < 2 || room <= 2)
+			return single(kLiteral, first);
+		// look one position ahead: a clearly better match there makes this byte a literal
+		held = take();
+		held_len = longest(held);
+		if (held_len >= 2) {
+			const uint32_t next_dist = held.dist(held.count - 1);
+			if ((held_len >= main_len && next_dist < main_dist) || (held_len == main_len + 1 && !much_nearer(main_dist, next_dist)) ||
+			    held_len > main_len + 1 || (held_len + 1 >= main_len && main_len >= 3 && much_nearer(next_dist, main_dist)))
+				return single(kLiteral, first);
+		}
+		here = data + fetch_pos - 1;
+		for (unsigned i = 0; i < kRepSlots; i++) {
+			const uint8_t *there = here - reps[i];
+			if (!same2(here, there))
+				continue;
+			const unsigned limit = main_len - 1;
+			if (equal_until(here, there, 2, limit) >= limit)
+				return single(kLiteral, first);
+		}
+		first->len = main_len;
+		first->code = main_dist + kRepSlots;
+		if (main_len != 2)
+			skip(main_len - 2);
+		return main_len;
+	}
+
+	// ---- coding one step -------------------------------------------------------------------------------------------
+	inline void code_step(uint32_t pos, const Step &s)
+	{
+		const unsigned ps = pos & pos_mask;
+		Prob *flag = &model.is_match[state][ps];
+		if (s.code == kLiteral) {
+			rc.encode(flag, 0);
+			const uint8_t *p = data + pos;
+			Prob *ctx = model.literal_context(pos, p[-1]);
+			if (last_was_literal(state))
+				rc.encode_tree<8>(ctx, p[0]);
+			else {
+				unsigned offs = 0x100, sym = p[0] | 0x100u, mb = p[-(ptrdiff_t)reps[0]];
+				do {
+					mb <<= 1;
+					Prob *pr = ctx + offs + (mb & offs) + (sym >> 8);
+					const unsigned b = (sym >> 7) & 1;
+					sym <<= 1;
+					offs &= ~(mb ^ sym);
+					rc.encode(pr, b);
+				} while (sym < 0x10000);
+			}
+			state = after_literal(state);
+			return;
+		}
+		rc.encode(flag, 1);
+		if (s.code < kRepSlots) {
+			rc.encode(&model.is_rep[state], 1);
+			if (s.code == 0) {
+				rc.encode(&model.is_rep0[state], 0);
+				rc.encode(&model.is_rep0_long[state][ps], s.len != 1);
+				if (s.len == 1) {
+					state = after_short_rep(state);
+					return;
+				}
+			} else {
+				rc.encode(&model.is_rep0[state], 1);
+				rc.encode(&model.is_rep1[state], s.code != 1);
+				if (s.code != 1)
+					rc.encode(&model.is_rep2[state], s.code - 2);
+				const uint32_t d = reps[s.code];
+				for (unsigned i = s.code; i > 0; i--)
+					reps[i] = reps[i - 1];
+				reps[0] = d;
+			}
+			model.rep_len.encode(rc, s.len, ps);
+			--rep_lens_until_refresh;
+			state = after_rep(state);
+			return;
+		}
+		rc.encode(&model.is_rep[state], 0);
+		state = after_match(state);
+		model.match_len.encode(rc, s.len, ps);
+		const uint32_t d = s.code - kRepSlots;
+		reps[3] = reps[2];
+		reps[2] = reps[1];
+		reps[1] = reps[0];
+		reps[0] = d + 1;
+		matches_since_refresh++;
+		const unsigned sl = dist_slot(d);
+		rc.encode_tree<6>(model.slot[len_dist_state(s.len)], sl);
+		if (d >= 4) {
+			const unsigned nb = (sl >> 1) - 1;
+			const uint32_t base = (uint32_t)(2 | (sl & 1)) << nb;
+			if (d < kNearDistances)
+				rc.encode_tree_reverse(model.near_footer + base, nb, d - base);
+			else {
+				rc.encode_direct((d - base) >> kAlignBits, nb - kAlignBits);
+				rc.encode_tree_reverse(model.align, kAlignBits, d & (kAlignSize - 1));
+			}
+		}
+	}
+
+	void refresh_all()
+	{
+		prices.refresh_align(model);
+		prices.refresh_distances(model, dist_slots);
+		matches_since_refresh = 0;
+		prices.match_len.refresh(model.match_len, prices.bit, 1u << model.pb, nice_len);
+	}
+
+	void setup(const LzmaParams &prm)
+	{
+		unsigned fb = (unsigned)prm.fb;
+		if (fb < 5)
+			fb = 5;
+		if (fb > kLenMax)
+			fb = kLenMax;
+		nice_len = fb;
+		greedy = prm.fast;
+		unsigned i;
+		for (i = 7; i < 32; i++)
+			if (prm.dict_size <= (1u << i))
+				break;
+		dist_slots = i * 2;
+		model.reset((unsigned)prm.lc, (unsigned)prm.lp, (unsigned)prm.pb);
+		pos_mask = (1u << prm.pb) - 1;
+		for (unsigned k = 0; k < sizeof(cost) / sizeof(cost[0]); k++)
+			cost[k] = kPriceInfinite;
+		memset(via, 0, sizeof(via));
+		refresh_all();
+		prices.rep_len.refresh(model.rep_len, prices.bit, 1u << model.pb, nice_len);
+	}
+
+	void run()
+	{
+		if (n == 0) {
+			rc.finish();
+			return;
+		}
+		// the first byte has no context and no history: always a plain literal
+		(void)take();
+		rc.encode(&model.is_match[0][0], 0);
+		rc.encode_tree<8>(model.literal.data(), data[0]);
+		ahead--;
+		uint32_t pos = 1;
+		if (fetch_pos < n)
+			for (;;) {
+				Step s;
+				if (q_head != q_tail)
+					s = queue[q_head++];
+				else if (greedy)
+					plan_greedy(&s);
+				else
+					plan(pos, &s);
+				code_step(pos, s);
+				pos += s.len;
+				ahead -= s.len;
+				if (ahead == 0) { // the coder has caught up with the finder: the only moment tables may change
+					if (!greedy && matches_since_refresh >= kRefreshEvery)
+						refresh_all();
+					if (!greedy && rep_lens_until_refresh <= 0) {
+						rep_lens_until_refresh = (int)kRefreshEvery;
+						prices.rep_len.refresh(model.rep_len, prices.bit, 1u << model.pb, nice_len);
+					}
+					if (fetch_pos == n || rc.overflow)
+						break; // (an overflow ends in LZ_ERROR_OUTPUT_EOF whatever follows)
+				}
+			}
+		rc.finish();
+	}
+};
+
+template <bool PACKED>
+int encode_with(const LzmaParams &prm, const uint8_t *src, size_t n, const MatchLists &ml, uint8_t *dest, size_t dest_cap, size_t *dest_len)
+{
+	std::unique_ptr<BlockEncoder<PACKED>> e(new (std::nothrow) BlockEncoder<PACKED>());
+	if (!e)
+		return LZ_ERROR_MEM;
+	e->data = src;
+	e->n = n;
+	e->counts = ml.counts;
+	e->words = ml.pairs;
+	e->rc.out = dest;
+	e->rc.cap = dest_cap;
+	e->setup(prm);
+	e->run();
+	if (e->rc.overflow) {
+		*dest_len = dest_cap;
+		return LZ_ERROR_OUTPUT_EOF;
+	}
+	*dest_len = e->rc.len;
+	return LZ_OK;
+}
+
+} // namespace
+
+// hash masks the reference derives for a block (LzFind.c:347-373, 432-442): smallest 2^k - 1 covering
+// min(dictionary, expected size), halved, at most 2^24 - 1 worth of bits for 4 hash bytes, at least 16 bits
+static uint32_t hash_mask_common(uint32_t dict_size, uint64_t expected_size, uint32_t always_set)
+{
+	uint32_t best = 0xFFFFFFFFu;
+	const uint64_t sizes[2] = {dict_size, expected_size < dict_size ? expected_size : dict_size};
+	for (uint64_t sz : sizes) {
+		uint32_t hs = (uint32_t)sz;
+		if (hs)
+			hs--;
+		hs |= hs >> 1;
+		hs |= hs >> 2;
+		hs |= hs >> 4;
+		hs |= hs >> 8;
+		hs >>= 1;
+		if (hs >= (1u << 24))
+			hs >>= 1;
+		hs |= 0xFFFF | always_set;
+		if (hs < best)
+			best = hs;
+	}
+	return best;
+}
+uint32_t lzma_hash_mask(uint32_t dict_size, uint64_t expected_size) { return hash_mask_common(dict_size, expected_size, 0); }
+// the 5-byte hash of the HC5 finder (levels 1-4) always keeps its low 18 bits (kLzHash_CrcShift_2)
+uint32_t lzma_hash_mask5(uint32_t dict_size, uint64_t expected_size) { return hash_mask_common(dict_size, expected_size, (256u << 10) - 1); }
+
+// 5-byte properties: lc/lp/pb packed, then the dictionary rounded up to 2^k or 3 * 2^(k-1) below 2 MiB,
+// to a whole MiB above (LzmaEnc_WriteProperties, LzmaEnc.c:3037-3070)
+void lzma_write_props(const LzmaParams &prm, uint8_t props[5])
+{
+	const uint32_t dict = prm.dict_size;
+	uint32_t v;
+	props[0] = (uint8_t)((prm.pb * 5 + prm.lp) * 9 + prm.lc);
+	if (dict >= (1u << 21)) {
+		const uint32_t mib = (1u << 20) - 1;
+		v = (dict + mib) & ~mib;
+		if (v < dict)
+			v = dict;
+	} else {
+		v = 1u << 12; // 2^12, 3 * 2^11 ... : i = 22, 23, ... in (2 + (i & 1)) << (i >> 1)
+		for (unsigned i = 11 * 2; (v = (uint32_t)(2 + (i & 1)) << (i >> 1)) < dict; i++) {
+		}
+	}
+	for (int k = 0; k < 4; k++)
+		props[1 + k] = (uint8_t)(v >> (8 * k));
+}
+
+int lzma_encode_block(const LzmaParams &prm, const uint8_t *src, size_t n, const MatchLists &ml, uint8_t *dest, size_t dest_cap,
+		      size_t *dest_len)
+{
+	if (prm.lc > 8 || prm.lp > 4 || prm.pb > 4 || prm.lc < 0 || prm.lp < 0 || prm.pb < 0)
+		return LZ_ERROR_PARAM;
+	if ((prm.level < 5) != prm.fast) // algo 0 <=> levels 1-4 here (LzmaEncProps_Normalize)
+		return LZ_ERROR_PARAM;
+	if (n >= 0xFFFFFFFFu)
+		return LZ_ERROR_PARAM;
+	return ml.packed ? encode_with<true>(prm, src, n, ml, dest, dest_cap, dest_len) : encode_with<false>(prm, src, n, ml, dest, dest_cap, dest_len);
+}
+
+} // namespace lrzgpu

@@ -33,20 +33,23 @@ struct Block {
 // CRC-32/IEEE, slice-by-8 (the chunk trailer of src/rzip.c:741-761)
 uint32_t crc32_host(uint32_t crc, const uint8_t *p, size_t n)
 {
-	static uint32_t T[8][256];
-	static std::atomic<bool> ready{false};
-	if (!ready.load()) {
-		for (uint32_t i = 0; i < 256; i++) {
-			uint32_t r = i;
-			for (int j = 0; j < 8; j++)
-				r = (r >> 1) ^ (0xEDB88320u & (0u - (r & 1)));
-			T[0][i] = r;
+	struct Tables {
+		uint32_t t[8][256];
+		Tables()
+		{
+			for (uint32_t i = 0; i < 256; i++) {
+				uint32_t r = i;
+				for (int j = 0; j < 8; j++)
+					r = (r >> 1) ^ (0xEDB88320u & (0u - (r & 1)));
+				t[0][i] = r;
+			}
+			for (uint32_t i = 0; i < 256; i++)
+				for (int k = 1; k < 8; k++)
+					t[k][i] = (t[k - 1][i] >> 8) ^ t[0][t[k - 1][i] & 0xFF];
 		}
-		for (uint32_t i = 0; i < 256; i++)
-			for (int k = 1; k < 8; k++)
-				T[k][i] = (T[k - 1][i] >> 8) ^ T[0][T[k - 1][i] & 0xFF];
-		ready.store(true);
-	}
+	};
+	static const Tables tables; // function-local static: initialised once, thread-safe
+	const uint32_t(*T)[256] = tables.t;
 	crc = ~crc;
 	while (n >= 8) {
 		uint32_t a, b;
@@ -76,40 +79,49 @@ size_t zstd_decompress(void *dst, size_t cap, const void *src, size_t n, bool *o
 {
 	typedef size_t (*Fn)(void *, size_t, const void *, size_t);
 	typedef unsigned (*Err)(size_t);
-	static Fn fn = nullptr;
-	static Err is_err = nullptr;
-	static std::atomic<int> state{0};
-	if (state.load() == 0) {
-		void *h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_GLOBAL);
-		if (h) {
-			fn = (Fn)dlsym(h, "ZSTD_decompress");
-			is_err = (Err)dlsym(h, "ZSTD_isError");
+	struct Lib {
+		Fn fn = nullptr;
+		Err is_err = nullptr;
+		Lib()
+		{
+			void *h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_GLOBAL);
+			if (h) {
+				fn = (Fn)dlsym(h, "ZSTD_decompress");
+				is_err = (Err)dlsym(h, "ZSTD_isError");
+			}
 		}
-		state.store(fn && is_err ? 1 : 2);
-	}
-	if (state.load() != 1) {
+	};
+	static const Lib lib; // function-local static: bound once, thread-safe
+	if (!lib.fn || !lib.is_err) {
 		*ok = false;
 		return 0;
 	}
-	const size_t r = fn(dst, cap, src, n);
-	*ok = !is_err(r);
+	const size_t r = lib.fn(dst, cap, src, n);
+	*ok = !lib.is_err(r);
 	return r;
 }
 
 // one stream of a chunk -> its bytes; blocks are decoded by `nthreads` workers
+// `limit`: the most bytes this stream can legitimately hold (derived from the file size in the magic);
+// every length here comes from the untrusted image, so sums are checked before they can wrap
 int stream_bytes(const uint8_t *img, const std::vector<Block> &blocks, unsigned lc, unsigned lp, unsigned pb, int nthreads,
-		 std::vector<uint8_t> *out)
+		 size_t limit, std::vector<uint8_t> *out)
 {
 	size_t total = 0;
 	std::vector<size_t> at(blocks.size());
 	for (size_t i = 0; i < blocks.size(); i++) {
 		at[i] = total;
+		if (blocks[i].u_len > limit - total)
+			return LRZGPU_E_FORMAT;
+		if (blocks[i].c_type == 3 && blocks[i].c_len != blocks[i].u_len)
+			return LRZGPU_E_FORMAT;
 		total += blocks[i].u_len;
 	}
 	out->resize(total);
 	std::atomic<size_t> next{0};
 	std::atomic<int> err{0};
 	auto work = [&] {
+		try {
 		for (;;) {
 			const size_t i = next.fetch_add(1);
 			if (i >= blocks.size() || err.load())
@@ -130,6 +142,11 @@ int stream_bytes(const uint8_t *img, const std::vector<Block> &blocks, unsigned 
 					err = LRZGPU_E_FORMAT;
 			} else
 				err = LRZGPU_E_PARAM; // other back ends are outside this library
+		}
+		} catch (const std::bad_alloc &) { // thread body: nothing may escape
+			err = LRZGPU_E_NOMEM;
+		} catch (...) {
+			err = LRZGPU_E_INTERNAL;
 		}
 	};
 	std::vector<std::thread> th;
@@ -209,7 +226,7 @@ static int decompress_impl(const uint8_t *img, int64_t n, uint8_t **out, int64_t
 				const size_t nxt = (size_t)val(img + h + 1 + 2 * cb, cb);
 				b.off = h + hlen;
 				if (b.c_len) {
-					if (b.off + b.c_len > (size_t)n) {
+					if (b.c_len > (size_t)n - b.off) { // b.off <= n was checked above; no wrap
 						rc = LRZGPU_E_FORMAT;
 						break;
 					}
@@ -220,7 +237,7 @@ static int decompress_impl(const uint8_t *img, int64_t n, uint8_t **out, int64_t
 					end = h + hlen;
 				if (!nxt)
 					break;
-				if (base + nxt <= h) { // chains only run forward
+				if (nxt > (size_t)n - base || base + nxt <= h) { // inside the image, and chains only run forward
 					rc = LRZGPU_E_FORMAT;
 					break;
 				}
@@ -230,8 +247,15 @@ static int decompress_impl(const uint8_t *img, int64_t n, uint8_t **out, int64_t
 		if (rc)
 			break;
 		std::vector<uint8_t> s0, s1;
-		if ((rc = stream_bytes(img, blocks[0], lc, lp, pb, host_threads, &s0)) != 0 ||
-		    (rc = stream_bytes(img, blocks[1], lc, lp, pb, host_threads, &s1)) != 0)
+		// what is left of the file bounds both streams: literals byte for byte, tokens by 3 + cb <= 11
+		// bytes per token that covers at least one byte, plus the 7-byte tail
+		const size_t left = (size_t)(st_size - at);
+		if (left > (size_t)-1 / 16) {
+			rc = LRZGPU_E_FORMAT;
+			break;
+		}
+		if ((rc = stream_bytes(img, blocks[0], lc, lp, pb, host_threads, 12 * left + 4096, &s0)) != 0 ||
+		    (rc = stream_bytes(img, blocks[1], lc, lp, pb, host_threads, left, &s1)) != 0)
 			break;
 		// token replay
 		size_t i = 0, lit = 0;
@@ -385,7 +409,7 @@ extern "C" int lrzgpu_file_info(const uint8_t *img, int64_t n, lrzgpu_info *info
 				const size_t c_len = (size_t)val(img + h + 1, cb), u_len = (size_t)val(img + h + 1 + cb, cb);
 				const size_t nxt = (size_t)val(img + h + 1 + 2 * cb, cb);
 				if (c_len) {
-					if (h + hlen + c_len > (size_t)n)
+					if (c_len > (size_t)n - (h + hlen))
 						return LRZGPU_E_FORMAT;
 					info->blocks++;
 					if (c_type == 6)
@@ -397,7 +421,7 @@ extern "C" int lrzgpu_file_info(const uint8_t *img, int64_t n, lrzgpu_info *info
 				}
 				if (!nxt)
 					break;
-				if (base + nxt <= h)
+				if (nxt > (size_t)n - base || base + nxt <= h)
 					return LRZGPU_E_FORMAT;
 				h = base + nxt;
 			}

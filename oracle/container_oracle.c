@@ -411,7 +411,7 @@ int lrzo_compress_buffer(const lrzo_params *prm, const uchar *in, i64 n, lrzo_lz
 
 	{
 		struct plan_out po;
-		make_plan(prm, n, &po);
+		make_plan(prm, prm->file_size > n ? prm->file_size : n, &po);
 		d.threads = po.threads;
 		d.dict_size = po.dict_size;
 		d.bufsize = po.bufsize;

@@ -121,6 +121,9 @@ typedef struct {
 	int verbose;
 	int zstd;                  /* --zstd back end (src/stream.c:167-230) instead of LZMA */
 	int zstd_level;            /* --zstd-level 1..22, 0 = from -L (src/main.c:87, 692-711, 822-828) */
+	i64 file_size;             /* timing samples only: when > n, in[0..n) is the head of a file of this size --
+	                              chunking and block sizing are those of the whole file, the chunks inside the
+	                              head are compressed, and the image returned is not a complete .lrz */
 } lrzo_params;
 /* ZSTD_compress of the host's libzstd (the oracle has no zstd of its own: the reference links the
  * system library too, so parity is against the same build). */

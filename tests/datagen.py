@@ -61,3 +61,29 @@ KINDS = {
     "text": text_like, "random": random_bytes, "few": few_symbols, "phrases": phrase_mix,
     "sparse": sparse_repeats, "zeros": lambda n, seed=0: bytes(n), "longrange": long_range,
 }
+
+
+def text_alnum(n, seed=1, nwords=5000):
+    """Word-list pseudo text over the 62-symbol alphabet bench.py uses (the tag space does not collapse)."""
+    abc = np.frombuffer(b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789", dtype=np.uint8)
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(2, 10, size=nwords)
+    words = [abc[rng.integers(0, 62, size=int(l))].tobytes() + b" " for l in lens]
+    out = bytearray()
+    while len(out) < n:
+        idx = rng.integers(0, nwords, size=65536)
+        out += b"".join(words[i] for i in idx)
+    return bytes(out[:n])
+
+
+def cfg3(n, base, seed=1, mutate_every=65536):
+    """BASELINE config 3 shape: a seeded text base block repeated to n bytes, one seeded byte
+    mutation per 64 KiB in every copy after the first."""
+    b = np.frombuffer(text_alnum(base, seed), dtype=np.uint8)
+    a = np.tile(b, -(-n // base))[:n].copy()
+    rng = np.random.default_rng(seed + 7919)
+    cells = (n - base) // mutate_every
+    if cells > 0:
+        pos = base + np.arange(cells, dtype=np.int64) * mutate_every + rng.integers(0, mutate_every, size=cells)
+        a[pos] = rng.integers(0, 256, size=cells, dtype=np.uint8)
+    return a.tobytes()

@@ -25,7 +25,8 @@ class Params(C.Structure):
     _fields_ = [("compression_level", C.c_int), ("rzip_level", C.c_int), ("no_compress", C.c_int),
                 ("threads", C.c_int), ("processors", C.c_int), ("ramsize", C.c_int64), ("window", C.c_int64),
                 ("lz4_test", C.c_int), ("threshold", C.c_int), ("nobemt", C.c_int), ("dict_size", C.c_uint32),
-                ("workers", C.c_int), ("verbose", C.c_int), ("zstd", C.c_int), ("zstd_level", C.c_int)]
+                ("workers", C.c_int), ("verbose", C.c_int), ("zstd", C.c_int), ("zstd_level", C.c_int),
+                ("file_size", C.c_int64)]
 
 
 class FileStats(C.Structure):
@@ -75,7 +76,7 @@ def lib():
         L.lrzo_lzma_hash_mask.argtypes = [C.c_uint32, C.c_uint64]
         L.lrzo_lzma_hash_mask.restype = C.c_uint32
         L.lrzo_params_default.argtypes = [C.POINTER(Params)]
-        L.lrzo_compress_buffer.argtypes = [C.POINTER(Params), C.c_char_p, C.c_int64, C.c_void_p,
+        L.lrzo_compress_buffer.argtypes = [C.POINTER(Params), C.c_void_p, C.c_int64, C.c_void_p,
                                            C.POINTER(C.POINTER(C.c_ubyte)), C.POINTER(C.c_int64),
                                            C.POINTER(FileStats)]
         L.lrzo_plan.argtypes = [C.POINTER(Params), C.c_int64, C.POINTER(FileStats)]
@@ -174,8 +175,9 @@ def lzma_uncompress_ref(comp: bytes, props: bytes, out_len: int):
     return rc, dst.raw[:dlen.value]
 
 
-def compress_buffer(data: bytes, **kw):
-    """Whole-file oracle compress -> (.lrz bytes, FileStats)."""
+def compress_buffer(data, **kw):
+    """Whole-file oracle compress -> (.lrz bytes, FileStats).  data: bytes, or a numpy uint8 array
+    (no copy: multi-GiB inputs)."""
     L = lib()
     p = Params()
     L.lrzo_params_default(C.byref(p))
@@ -194,10 +196,18 @@ def compress_buffer(data: bytes, **kw):
     out = C.POINTER(C.c_ubyte)()
     olen = C.c_int64()
     fs = FileStats()
-    rc = L.lrzo_compress_buffer(C.byref(p), data, len(data), fn, C.byref(out), C.byref(olen), C.byref(fs))
+    if isinstance(data, (bytes, bytearray)):
+        keep = bytes(data)  # alive until the call returns
+        src, n = C.cast(C.c_char_p(keep), C.c_void_p), len(keep)
+    else:
+        src, n = C.c_void_p(data.ctypes.data), int(data.size)
+    rc = L.lrzo_compress_buffer(C.byref(p), src, n, fn, C.byref(out), C.byref(olen), C.byref(fs))
     if rc != 0:
         raise RuntimeError("lrzo_compress_buffer rc=%d" % rc)
-    res = C.string_at(out, olen.value)
+    if olen.value < (1 << 31) - 1:
+        res = C.string_at(out, olen.value)
+    else:  # string_at() takes a C int
+        res = bytes(memoryview((C.c_ubyte * olen.value).from_address(C.addressof(out.contents))).cast("B"))
     C.CDLL(None).free(out)
     return res, fs
 

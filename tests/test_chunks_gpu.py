@@ -1,0 +1,132 @@
+"""Multi-chunk files: chunks scanned concurrently on one GPU, the victim_round chain across chunks
+(src/rzip.c:308), chunk-sharded compression for one-process-per-GPU runs, bounded-memory fd path.
+Everything is compared byte for byte with the oracle driver."""
+import ctypes as C
+import hashlib
+import importlib.util
+import os
+
+import pytest
+
+import datagen
+
+pytestmark = pytest.mark.gpu
+
+RAM = 80 * 100 << 20
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("lrz_bench_prof2", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def _profile(B, bench):
+    p = bench.Profile()
+    B.lib().lrzgpu_profile_get.argtypes = [C.POINTER(bench.Profile)]
+    B.lib().lrzgpu_profile_get(C.byref(p))
+    return p
+
+
+@pytest.fixture(scope="module")
+def cfg3_small():
+    """BASELINE config 3 at reduced size with the SAME chunk count: 8 chunks (-w 1: 7 x 100 MiB + 60 MiB),
+    50 MiB base block so that every chunk holds internal long-range redundancy."""
+    return datagen.cfg3(7 * 104857600 + 60 * 1048576, 50 * 1048576, seed=3)
+
+
+def test_cfg3_reduced_concurrent_chunks(B, O, cfg3_small):
+    data = cfg3_small
+    want, fs = O.compress_buffer(data, compression_level=7, threads=8, processors=16, ramsize=RAM, window=1, workers=16)
+    assert fs.n_chunks == 8
+    got, ctl = B.compress_buffer(data, level=7, threads=8, processors=16, ramsize=RAM, window=1, host_threads=16, gpu_slots=6)
+    assert ctl.stream_bufsize == fs.stream_bufsize
+    assert bytes(ctl.hash_resblock) == hashlib.md5(data).digest()
+    assert got == want
+    # one scanner (the chunks strictly one after the other) writes the same bytes
+    got1, _ = B.compress_buffer(data[:3 * 104857600 + 5], level=7, threads=8, processors=16, ramsize=RAM, window=1, host_threads=16, scan_slots=1)
+    want1, _ = O.compress_buffer(data[:3 * 104857600 + 5], compression_level=7, threads=8, processors=16, ramsize=RAM, window=1, workers=16)
+    assert got1 == want1
+    assert B.decompress_buffer(got, host_threads=16) == data
+
+
+def test_victim_round_chain_rescans(B, O):
+    """27-symbol text collapses the tag space (the XOR tag only sees byte-count parities), buckets fill to
+    max_chain_len and insert_hash()'s static victim_round moves: a chunk that was scanned ahead of its
+    predecessor with the predicted value 0 has to be scanned again.  Same bytes as the serial chain."""
+    bench = _bench()
+    data = datagen.long_range(250 * 1048576 + 4097, seed=14, base_frac=0.08, mutate_every=300007)
+    want, fs = O.compress_buffer(data, compression_level=7, threads=4, processors=8, ramsize=RAM, window=1, workers=16)
+    assert fs.n_chunks == 3
+    B.lib().lrzgpu_profile_reset()
+    got, _ = B.compress_buffer(data, level=7, threads=4, processors=8, ramsize=RAM, window=1, host_threads=16, scan_slots=3)
+    assert got == want
+    p = _profile(B, bench)
+    assert p.victim_rescans >= 1
+    B.lib().lrzgpu_profile_reset()
+    got, _ = B.compress_buffer(data, level=7, threads=4, processors=8, ramsize=RAM, window=1, host_threads=16, scan_slots=1)
+    assert got == want
+    assert _profile(B, bench).victim_rescans == 0
+
+
+def _sharded(B, data, world, **kw):
+    """What bench.py --gpus N does, all ranks played by this one process: chunk k -> rank k % world,
+    the victim_round chain checked by the owner of the file, wrong guesses redone, images laid out."""
+    plan = B.make_control(**kw)
+    cs = C.c_int64()
+    assert B.lib().lrzgpu_plan(C.byref(plan), len(data), C.byref(cs)) == 0
+    n_chunks = max(1, -(-len(data) // cs.value)) if cs.value else 1
+    images, chain, md5 = {}, {}, None
+    for r in range(world):
+        got, ctl = B.compress_chunks(data, first=r, stride=world, with_md5=(r == 0), host_threads=8, **kw)
+        if r == 0:
+            md5 = bytes(ctl.hash_resblock)
+        for k, (vin, vout, img) in got.items():
+            assert k % world == r
+            images[k], chain[k] = img, (vin, vout)
+    assert sorted(images) == list(range(n_chunks))
+    redone = 0
+    for k in range(1, n_chunks):
+        if chain[k][0] != chain[k - 1][1]:
+            victim = [-1] * n_chunks
+            victim[k] = chain[k - 1][1]
+            got, _ = B.compress_chunks(data, first=k, stride=max(n_chunks, k + 1), victim_in=victim, host_threads=8, **kw)
+            vin, vout, img = got[k]
+            assert vin == chain[k - 1][1]
+            images[k], chain[k] = img, (vin, vout)
+            redone += 1
+    out, _ = B.assemble_chunks([images[k] for k in range(n_chunks)], len(data), md5, **kw)
+    return out, redone
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_chunk_sharded_equals_single_process(B, O, world):
+    kw = dict(level=7, threads=4, processors=8, ramsize=RAM, window=1)
+    data = datagen.cfg3(3 * 104857600 + 12345, 40 * 1048576, seed=5)
+    want, fs = O.compress_buffer(data, compression_level=7, threads=4, processors=8, ramsize=RAM, window=1, workers=16)
+    assert fs.n_chunks == 4
+    got, _ = _sharded(B, data, world, **kw)
+    assert got == want
+
+
+def test_chunk_sharded_with_moving_victim_round(B, O):
+    kw = dict(level=7, threads=4, processors=8, ramsize=RAM, window=1)
+    data = datagen.long_range(250 * 1048576 + 4097, seed=14, base_frac=0.08, mutate_every=300007)
+    want, _ = O.compress_buffer(data, compression_level=7, threads=4, processors=8, ramsize=RAM, window=1, workers=16)
+    got, redone = _sharded(B, data, 3, **kw)
+    assert got == want and redone >= 1
+
+
+def test_fd_path_streams_chunks(B, O, tmp_path):
+    """Regular files are read chunk by chunk and written chunk by chunk (src/rzip.c:1057-1107,
+    src/stream.c:1772-1821): same bytes as the memory-to-memory call, at an output offset too."""
+    data = datagen.cfg3(2 * 104857600 + 999, 30 * 1048576, seed=9)
+    want, _ = O.compress_buffer(data, compression_level=7, threads=4, processors=8, ramsize=RAM, window=1, workers=16)
+    src = tmp_path / "in.bin"
+    src.write_bytes(data)
+    B.compress_file(str(src), str(tmp_path / "a.lrz"), level=7, threads=4, processors=8, ramsize=RAM, window=1, host_threads=16)
+    assert (tmp_path / "a.lrz").read_bytes() == want
+    B.compress_file(str(src), str(tmp_path / "b.part"), rzip_only_fd=True, level=7, threads=4, processors=8, ramsize=RAM,
+                    window=1, host_threads=16)
+    assert (tmp_path / "b.part").read_bytes() == want[21:]

@@ -116,3 +116,40 @@ def test_library_decoder_survives_fuzz(B, O):
         except RuntimeError:
             continue
         assert out == data, k
+
+
+def _crafted_image(cb, c_type, c_len, u_len, nxt, st_size=64, payload=b"\0" * 64):
+    """A minimal .lrz whose first stream-0 block header carries the given (possibly absurd) lengths."""
+    le = lambda v: (v & ((1 << (8 * cb)) - 1)).to_bytes(cb, "little")
+    magic = bytearray(21)
+    magic[0:4] = b"LRZI"
+    magic[4], magic[5] = 0, 14
+    magic[6:14] = st_size.to_bytes(8, "little")
+    magic[14] = 1
+    magic[17] = 1
+    img = bytes(magic) + bytes([cb, 1]) + le(st_size)
+    img += bytes([3]) + le(0) + le(0) + le(2 * (1 + 3 * cb))  # stream 0 initial header -> first block
+    img += bytes([3]) + le(0) + le(0) + le(0)                  # stream 1 initial header, empty
+    img += bytes([c_type]) + le(c_len) + le(u_len) + le(nxt) + payload + b"\0" * 16
+    return img
+
+
+@pytest.mark.parametrize("c_type", [3, 6, 10])
+def test_library_decoder_rejects_wrapping_lengths(B, c_type):
+    """Lengths near 2^64 in an 8-byte-wide header must be rejected, not wrap past the bounds checks
+    (the image is untrusted input): error return, no crash, no allocation of the wrapped size."""
+    big = (1 << 64) - 64
+    cases = [
+        _crafted_image(8, c_type, big, big, 0),            # c_len wraps b.off + c_len
+        _crafted_image(8, c_type, 64, big, 0),             # u_len wraps the running total
+        _crafted_image(8, c_type, 64, 64, big),            # next-header offset wraps base + nxt
+        _crafted_image(8, c_type, 64, (1 << 63) + 5, 0),   # u_len far beyond st_size
+        _crafted_image(8, 3, 16, 64, 0),                   # stored block with c_len != u_len
+    ]
+    for img in cases:
+        with pytest.raises(RuntimeError):
+            B.decompress_buffer(img, host_threads=2)
+        try:  # the -i walk sees the same headers: error or figures, never a crash
+            B.file_info(img)
+        except RuntimeError:
+            pass
