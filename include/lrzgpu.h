@@ -60,6 +60,8 @@ typedef struct lrzgpu_control {
 	int zstd_level;             /* --zstd-level 1..22, 0 = from -L (src/main.c:87, 692-711, 822-828) */
 	/* execution (no influence on the bytes produced; appended) */
 	int scan_slots;             /* rzip chunks scanned concurrently on the GPU, 0 = default (8)      */
+	/* stream API only (input, appended) */
+	int eof;                    /* control->eof: set before the last chunk's open_stream_out (src/rzip.c:1173-1174) */
 } lrzgpu_control;
 
 void lrzgpu_control_init(lrzgpu_control *c); /* initialise_control() defaults, src/lrzip.c:1813-1857 */
@@ -101,6 +103,47 @@ int lrzgpu_compress_chunks_dev(lrzgpu_control *control, const void *d_in, int64_
 			       const int64_t *victim_in, int with_md5, lrzgpu_chunk_fn on_chunk, void *ctx);
 int lrzgpu_assemble_chunks(lrzgpu_control *control, int64_t st_size, int n_chunks, const uint8_t *const *chunk_img,
 			   const int64_t *chunk_len, const uint8_t md5[16], uint8_t **out, int64_t *out_len);
+
+/* ---- stream layer, compress side: src/include/stream.h:14-32 kept call for call ---------------------
+ * For a caller that produces the two rzip streams itself (the reference's hash_search() through
+ * put_header/put_literal/put_match, src/rzip.c:184-265): the same functions with the same argument lists,
+ * `rzip_control` -> `lrzgpu_control`, bool/void -> int (0 = ok, negative = error instead of fatal()).
+ *   prepare_streamout_threads  src/stream.c:1090-1118   ring of threads + 1 block slots (1 under -n)
+ *   open_stream_out            src/stream.c:1140-1348   one per chunk; the first call fixes threads /
+ *                              dictionary / stream_bufsize from control->st_size, -p, -m (set st_size first);
+ *                              control->eof is latched for the chunk header; returns the sinfo handle
+ *   write_stream               src/stream.c:2198-2216   append to stream 0 (tokens) or 1 (literals); a full
+ *                              buffer is handed to the back end (lz4 gate, GPU finder, host parser)
+ *   flush_buffer               src/stream.c:1878-1881   hand the current (partial) buffer off now
+ *   close_stream_out           src/stream.c:2253-2282   flush stream 0 then 1, empty blocks included
+ *   close_streamout_threads    src/stream.c:1121-1136   wait for every block; leaves fd at the end of the
+ *                              last chunk (the caller appends the hash and rewrites the magic)
+ * Blocks reach the file strictly in hand-off order with the chunk header in front of a chunk's first
+ * block (compthread, src/stream.c:1716-1821).  The output fd must be seekable. */
+int lrzgpu_prepare_streamout_threads(lrzgpu_control *control);
+int lrzgpu_close_streamout_threads(lrzgpu_control *control);
+void *lrzgpu_open_stream_out(lrzgpu_control *control, int f, unsigned int n, int64_t chunk_limit, char cbytes);
+int lrzgpu_flush_buffer(lrzgpu_control *control, void *sinfo, int stream);
+int lrzgpu_write_stream(lrzgpu_control *control, void *ss, int streamno, const uint8_t *p, int64_t len);
+int lrzgpu_close_stream_out(lrzgpu_control *control, void *ss);
+
+/* The per-block back-end dispatch seam: static int lzma_compress_buf(rzip_control*, struct compress_thread*,
+ * int current_thread), src/stream.c:429-494 (and zstd_compress_buf 167-230 under LRZGPU_FLAG_ZSTD), called
+ * by compthread (src/stream.c:1633-1648).  Same contract: s_buf is malloc()ed and owned by *cthread; on
+ * success with a smaller result the old s_buf is freed, the new one installed, c_len / c_type (6 LZMA,
+ * 10 zstd) set; "left uncompressed" (lz4 gate said no, incompressible, does not fit) also returns 0 with
+ * *cthread untouched; -1 = a resource was missing -- the reference's caller then waits for its predecessor
+ * and tries once more (src/stream.c:1667-1714).  SZ_ERROR_MEM lowers control->compression_level and retries
+ * like the reference (src/stream.c:462-467).  The calling thread keeps its device buffers between calls. */
+typedef struct lrzgpu_compress_thread { /* struct compress_thread, src/stream.c:67-76 (no semaphore/salt) */
+	uint8_t *s_buf;   /* uncompressed buffer -> compressed buffer */
+	uint8_t c_type;   /* 3 = CTYPE_NONE on entry */
+	int64_t s_len;    /* data length uncompressed */
+	int64_t c_len;    /* data length compressed (= s_len on entry) */
+	void *sinfo;
+	int streamno;
+} lrzgpu_compress_thread;
+int lrzgpu_lzma_compress_buf(lrzgpu_control *control, lrzgpu_compress_thread *cthread, int current_thread);
 
 /* ---- rzip stage -------------------------------------------------------------------------------
  * hash_search(), src/rzip.c:586-762: scan one chunk resident in HBM.  Emits the two rzip streams
@@ -162,6 +205,14 @@ int64_t lrzgpu_lzma_match_lists_hc5(const uint8_t *src, size_t n, uint32_t dictS
 int lrzgpu_lzma_encode_with_lists(unsigned char *dest, size_t *destLen, const unsigned char *src, size_t srcLen,
 				  const uint8_t *counts, const uint32_t *pairs, int level, unsigned dictSize,
 				  int lc, int lp, int pb, int fb);
+
+/* The same with the list formats the pipeline moves over PCIe (lzma_mf.hip k_gather): 0 = the couples above;
+ * 1 = bit 31 of every len word carries the finder's tail flag ("after this match and one literal byte the next
+ * two bytes continue at the same distance"); 2 = one u32 per pair, flag << 31 | (len - 2) << 25 | dist-1
+ * (dictSize <= 32 MiB, fb <= 65).  counts[] counts two entries per pair in every format. */
+int lrzgpu_lzma_encode_with_lists_fmt(unsigned char *dest, size_t *destLen, const unsigned char *src, size_t srcLen,
+				      const uint8_t *counts, const uint32_t *pairs, int list_format, int level,
+				      unsigned dictSize, int lc, int lp, int pb, int fb);
 
 /* ---- host-only pieces of the stream layer (usable without a device) ----------------------------
  * lrzgpu_plan: the sizing open_stream_out()/rzip_fd() derive before the first chunk

@@ -20,7 +20,7 @@ class Control(C.Structure):
                 ("gpu_slots", C.c_int), ("verbose", C.c_int), ("st_size", C.c_int64),
                 ("hash_resblock", C.c_uint8 * 16), ("lzma_properties", C.c_uint8 * 5), ("dictSize_used", C.c_uint32),
                 ("stream_bufsize", C.c_int64), ("threads_used", C.c_int), ("zstd_level", C.c_int),
-                ("scan_slots", C.c_int)]
+                ("scan_slots", C.c_int), ("eof", C.c_int)]
 
 
 class ScanStats(C.Structure):
@@ -82,6 +82,79 @@ def lib():
         L.lrzgpu_trim.restype = None
         _lib = L
     return _lib
+
+
+class CompressThread(C.Structure):
+    _fields_ = [("s_buf", C.c_void_p), ("c_type", C.c_uint8), ("s_len", C.c_int64), ("c_len", C.c_int64),
+                ("sinfo", C.c_void_p), ("streamno", C.c_int)]
+
+
+def lzma_compress_buf(block: bytes, ctl=None, **kw):
+    """The back-end dispatch seam (lzma_compress_buf / zstd_compress_buf contract) on one block ->
+    (return code, c_type, result bytes)."""
+    c = ctl if ctl is not None else make_control(**kw)
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    n = len(block)
+    buf = libc.malloc(max(n, 1))
+    C.memmove(buf, block, n)
+    t = CompressThread(buf, 3, n, n, None, 1)
+    f = lib().lrzgpu_lzma_compress_buf
+    f.argtypes = [C.POINTER(Control), C.POINTER(CompressThread), C.c_int]
+    rc = f(C.byref(c), C.byref(t), 0)
+    out = C.string_at(t.s_buf, t.c_len) if rc == 0 else b""
+    _LIBC_FREE(t.s_buf)
+    return rc, t.c_type, out
+
+
+def stream_out_file(path_out, chunks, st_size, **kw):
+    """Drives the stream.h surface the way rzip_fd()/rzip_chunk()/hash_search() do: chunks = [(chunk_size,
+    chunk_bytes, stream0 bytes, stream1 bytes)]; tokens are replayed through write_stream exactly in the order
+    put_literal/put_match issue them (src/rzip.c:208-265).  Writes chunks at offset 21 of path_out (no magic, no
+    hash) -> Control."""
+    L = lib()
+    c = make_control(**kw)
+    c.st_size = st_size
+    L.lrzgpu_open_stream_out.restype = C.c_void_p
+    L.lrzgpu_open_stream_out.argtypes = [C.POINTER(Control), C.c_int, C.c_uint, C.c_int64, C.c_char]
+    L.lrzgpu_write_stream.argtypes = [C.POINTER(Control), C.c_void_p, C.c_int, C.c_char_p, C.c_int64]
+    L.lrzgpu_close_stream_out.argtypes = [C.POINTER(Control), C.c_void_p]
+    fo = os.open(path_out, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
+    try:
+        os.write(fo, bytes(21))
+        if L.lrzgpu_prepare_streamout_threads(C.byref(c)) != 0:
+            raise RuntimeError("prepare_streamout_threads")
+        for k, (chunk_size, cb, s0, s1) in enumerate(chunks):
+            c.eof = 1 if k + 1 == len(chunks) else 0
+            ss = L.lrzgpu_open_stream_out(C.byref(c), fo, 2, chunk_size, bytes([cb]))
+            if not ss:
+                raise RuntimeError("open_stream_out")
+            i = lit = 0
+            while i + 3 <= len(s0):
+                head, ln = s0[i], s0[i + 1] | (s0[i + 2] << 8)
+                if head == 0 and ln == 0:  # terminator: the CRC follows
+                    rc = L.lrzgpu_write_stream(C.byref(c), ss, 0, s0[i:], len(s0) - i)
+                    i = len(s0)
+                elif head == 0:
+                    rc = L.lrzgpu_write_stream(C.byref(c), ss, 0, s0[i:i + 3], 3)
+                    rc = rc or L.lrzgpu_write_stream(C.byref(c), ss, 1, s1[lit:lit + ln], ln)
+                    lit += ln
+                    i += 3
+                else:
+                    rc = L.lrzgpu_write_stream(C.byref(c), ss, 0, s0[i:i + 3 + cb], 3 + cb)
+                    i += 3 + cb
+                if rc:
+                    raise RuntimeError("write_stream rc=%d" % rc)
+            if L.lrzgpu_close_stream_out(C.byref(c), ss) != 0:
+                raise RuntimeError("close_stream_out")
+        rc = L.lrzgpu_close_streamout_threads(C.byref(c))
+        if rc != 0:
+            raise RuntimeError("close_streamout_threads rc=%d" % rc)
+        end = os.lseek(fo, 0, os.SEEK_CUR)
+    finally:
+        os.close(fo)
+    return c, end
 
 
 CHUNK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.POINTER(C.c_ubyte), C.c_int64)
@@ -179,7 +252,37 @@ def lzma_match_lists_hc5(data: bytes, dict_size=1 << 22, fb=32, cut=16, device=0
     return counts[:n], pairs[:total]
 
 
-def lzma_encode_with_lists(data: bytes, counts, pairs, level=7, dict_size=1 << 25, fb=64, lc=3, lp=0, pb=2, cap=None):
+def tail_flags(data: bytes, counts, pairs):
+    """What lzma_mf.hip k_gather computes per pair: do the two bytes after the match and one literal continue at
+    the same distance?  (numpy; for feeding the flagged / packed list formats without a GPU)"""
+    import numpy as np
+    a = np.frombuffer(data, dtype=np.uint8)
+    n = len(a)
+    counts = np.asarray(counts, dtype=np.int64)
+    pos = np.repeat(np.arange(n, dtype=np.int64), counts[:n] // 2)
+    ln = pairs[0::2].astype(np.int64)
+    d1 = pairs[1::2].astype(np.int64) + 1
+    at = pos + ln + 1
+    ok = at + 2 <= n
+    at = np.where(ok, at, 0)
+    src = np.where(ok, at - d1, 0)
+    return ok & (a[at] == a[src]) & (a[np.minimum(at + 1, n - 1)] == a[np.minimum(src + 1, n - 1)])
+
+
+def format_lists(data: bytes, counts, pairs, list_format):
+    """plain (len, dist-1) couples -> list format 1 (flag in bit 31 of len) or 2 (one packed word per pair)."""
+    import numpy as np
+    if list_format == 0:
+        return pairs
+    f = tail_flags(data, counts, pairs).astype(np.uint32)
+    if list_format == 1:
+        out = np.array(pairs, dtype=np.uint32, copy=True)
+        out[0::2] |= f << np.uint32(31)
+        return out
+    return (f << np.uint32(31)) | ((pairs[0::2] - np.uint32(2)) << np.uint32(25)) | pairs[1::2]
+
+
+def lzma_encode_with_lists(data: bytes, counts, pairs, level=7, dict_size=1 << 25, fb=64, lc=3, lp=0, pb=2, cap=None, list_format=0):
     import numpy as np
     n = len(data)
     if cap is None:
@@ -192,8 +295,14 @@ def lzma_encode_with_lists(data: bytes, counts, pairs, level=7, dict_size=1 << 2
         counts = np.zeros(1, dtype=np.uint8)
     if pairs.size == 0:
         pairs = np.zeros(1, dtype=np.uint32)
-    rc = lib().lrzgpu_lzma_encode_with_lists(dst, C.byref(dlen), data, n, counts.ctypes.data, pairs.ctypes.data,
-                                             level, dict_size, lc, lp, pb, fb)
+    if list_format:
+        f = lib().lrzgpu_lzma_encode_with_lists_fmt
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                      C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int]
+        rc = f(dst, C.byref(dlen), data, n, counts.ctypes.data, pairs.ctypes.data, list_format, level, dict_size, lc, lp, pb, fb)
+    else:
+        rc = lib().lrzgpu_lzma_encode_with_lists(dst, C.byref(dlen), data, n, counts.ctypes.data, pairs.ctypes.data,
+                                                 level, dict_size, lc, lp, pb, fb)
     return rc, dst.raw[:dlen.value]
 
 

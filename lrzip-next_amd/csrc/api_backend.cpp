@@ -13,6 +13,7 @@
 #include "lz4_gate.h"
 #include "lzma_enc.h"
 #include "lzma_mf.h"
+#include "pools.h"
 #include "profile.h"
 
 using namespace lrzgpu;
@@ -41,23 +42,45 @@ int select_device(int device)
 
 // ---- lz4 gate: src/stream.c:2325-2380 -------------------------------------------------------
 
+// The per-block entry points are called block after block from the same compthreads (src/stream.c:1633-1648):
+// each calling thread keeps its device buffers between calls (taken from / returned to the process-wide pools
+// when the thread ends); nothing is hipMalloc()ed or hipFree()d per call.
+struct ThreadBuffers {
+	DevBuf small, block;
+	int device = -1;
+	bool ensure(int dev, size_t block_bytes)
+	{
+		if (device != dev) {
+			small.release();
+			block.release();
+			device = dev;
+		}
+		if (!small.p && !small.alloc(256, dev))
+			return false;
+		if (block_bytes && block.cap < block_bytes && !block.alloc(block_bytes, dev))
+			return false;
+		return true;
+	}
+};
+static ThreadBuffers &thread_buffers()
+{
+	thread_local ThreadBuffers b;
+	return b;
+}
+
 static int lz4_size_dev(const uint8_t *d_src, int src_size, int dst_capacity, int stop_below = 0)
 {
-	Lz4Job job{d_src, src_size, dst_capacity, stop_below}, *d_job = nullptr;
-	int *d_res = nullptr, res = -1;
-	if (hipMalloc(&d_job, sizeof(job)) != hipSuccess)
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	ThreadBuffers &tb = thread_buffers();
+	if (!tb.ensure(dev, 0))
 		return LRZGPU_E_NOMEM;
-	if (hipMalloc(&d_res, sizeof(int)) != hipSuccess) {
-		(void)hipFree(d_job);
-		return LRZGPU_E_NOMEM;
-	}
-	int rc = 0;
+	Lz4Job job{d_src, src_size, dst_capacity, stop_below}, *d_job = (Lz4Job *)tb.small.p;
+	int *d_res = (int *)(tb.small.p + 64), res = -1;
 	if (hipMemcpy(d_job, &job, sizeof(job), hipMemcpyHostToDevice) != hipSuccess || lz4_sizes_device(d_job, 1, d_res, 0) != 0 ||
 	    hipMemcpy(&res, d_res, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
-		rc = LRZGPU_E_HIP;
-	(void)hipFree(d_job);
-	(void)hipFree(d_res);
-	return rc ? rc : res;
+		return LRZGPU_E_HIP;
+	return res;
 }
 
 extern "C" int lrzgpu_lz4_compresses_dev(const void *d_buf, int64_t s_len, int threshold, int device)
@@ -86,16 +109,12 @@ extern "C" int lrzgpu_lz4_compresses(const uint8_t *s_buf, int64_t s_len, int th
 		return rc;
 	if (s_len < 0)
 		return LRZGPU_E_PARAM;
-	uint8_t *d = nullptr;
-	if (hipMalloc(&d, (size_t)s_len + 16) != hipSuccess)
+	ThreadBuffers &tb = thread_buffers();
+	if (!tb.ensure(device, (size_t)s_len + 16))
 		return LRZGPU_E_NOMEM;
-	if (s_len && hipMemcpy(d, s_buf, (size_t)s_len, hipMemcpyHostToDevice) != hipSuccess) {
-		(void)hipFree(d);
+	if (s_len && hipMemcpy(tb.block.p, s_buf, (size_t)s_len, hipMemcpyHostToDevice) != hipSuccess)
 		return LRZGPU_E_HIP;
-	}
-	int v = lrzgpu_lz4_compresses_dev(d, s_len, threshold, device);
-	(void)hipFree(d);
-	return v;
+	return lrzgpu_lz4_compresses_dev(tb.block.p, s_len, threshold, device);
 }
 
 static int lz4_size_host(const uint8_t *src, int src_size, int dst_capacity, int stop_below, int device);
@@ -117,16 +136,12 @@ static int lz4_size_host(const uint8_t *src, int src_size, int dst_capacity, int
 		return rc;
 	if (src_size < 0)
 		return 0;
-	uint8_t *d = nullptr;
-	if (hipMalloc(&d, (size_t)src_size + 16) != hipSuccess)
+	ThreadBuffers &tb = thread_buffers();
+	if (!tb.ensure(device, (size_t)src_size + 16))
 		return LRZGPU_E_NOMEM;
-	if (src_size && hipMemcpy(d, src, (size_t)src_size, hipMemcpyHostToDevice) != hipSuccess) {
-		(void)hipFree(d);
+	if (src_size && hipMemcpy(tb.block.p, src, (size_t)src_size, hipMemcpyHostToDevice) != hipSuccess)
 		return LRZGPU_E_HIP;
-	}
-	int v = lz4_size_dev(d, src_size, dst_capacity, stop_below);
-	(void)hipFree(d);
-	return v;
+	return lz4_size_dev(tb.block.p, src_size, dst_capacity, stop_below);
 }
 
 // ---- LZMA: src/lzma/include/LzmaLib.h:95-112 --------------------------------------------------
@@ -137,19 +152,20 @@ static int64_t match_lists_impl(const uint8_t *src, size_t n, uint32_t dictSize,
 	int rc = select_device(device);
 	if (rc)
 		return rc;
-	MfWorkspace *w = nullptr;
-	double per_pos = n ? (double)pairs_cap / (double)n : 16.0;
+	double per_pos = n ? (double)pairs_cap / (double)n : 16.0, got_per_pos = 0;
 	if (per_pos < 4)
 		per_pos = 4;
-	if (mf_workspace_create(&w, n ? n : 1, per_pos) != 0) {
-		mf_workspace_destroy(w);
+	MfWorkspace *w = WorkspacePool::get().take_mf(n ? n : 1, per_pos, device, &got_per_pos);
+	if (!w)
 		return LRZGPU_E_NOMEM;
-	}
-	uint8_t *d_src = nullptr;
+	ThreadBuffers &tb = thread_buffers();
 	int64_t ret = LRZGPU_E_HIP;
 	unsigned long long total = 0;
-	if (hipMalloc(&d_src, n + 16) == hipSuccess && (n == 0 || hipMemcpy(d_src, src, n, hipMemcpyHostToDevice) == hipSuccess)) {
-		int r = mf_run_device(w, d_src, n, dictSize, fb, cutValue, 0, &total, false, hc5);
+	if (!tb.ensure(device, n + 16))
+		ret = LRZGPU_E_NOMEM;
+	else if (n == 0 || hipMemcpy(tb.block.p, src, n, hipMemcpyHostToDevice) == hipSuccess) {
+		const uint8_t *d_src = tb.block.p;
+		int r = mf_run_device(w, d_src, n, dictSize, fb, cutValue, 0, &total, 0, hc5);
 		if (r == 0) {
 			if (total > pairs_cap)
 				ret = LRZGPU_E_NOMEM;
@@ -159,9 +175,7 @@ static int64_t match_lists_impl(const uint8_t *src, size_t n, uint32_t dictSize,
 		} else
 			ret = r == -4 ? LRZGPU_E_NOMEM : LRZGPU_E_INTERNAL;
 	}
-	if (d_src)
-		(void)hipFree(d_src);
-	mf_workspace_destroy(w);
+	WorkspacePool::get().give_mf(w, got_per_pos, device);
 	return ret;
 }
 
@@ -175,6 +189,33 @@ extern "C" int64_t lrzgpu_lzma_match_lists_hc5(const uint8_t *src, size_t n, uin
 					       uint8_t *counts, uint32_t *pairs, size_t pairs_cap, int device)
 {
 	return match_lists_impl(src, n, dictSize, fb, cutValue, counts, pairs, pairs_cap, device, true);
+}
+
+extern "C" int lrzgpu_lzma_encode_with_lists_fmt(unsigned char *dest, size_t *destLen, const unsigned char *src, size_t srcLen,
+						 const uint8_t *counts, const uint32_t *pairs, int list_format, int level, unsigned dictSize,
+						 int lc, int lp, int pb, int fb)
+{
+	if (list_format < 0 || list_format > 2)
+		return LZ_ERROR_PARAM;
+	LzmaParams p;
+	p.level = level;
+	p.dict_size = dictSize;
+	p.lc = lc;
+	p.lp = lp;
+	p.pb = pb;
+	p.fb = fb;
+	p.fast = level >= 0 && level < 5; // algo 0
+	if (list_format == 2 && (dictSize > (1u << 25) || fb > 65))
+		return LZ_ERROR_PARAM;
+	MatchLists ml;
+	ml.counts = counts;
+	ml.pairs = pairs;
+	ml.tail_flags = list_format != 0;
+	ml.packed = list_format == 2;
+	size_t out_len = 0;
+	int r = lzma_encode_block(p, src, srcLen, ml, dest, *destLen, &out_len);
+	*destLen = out_len;
+	return r;
 }
 
 extern "C" int lrzgpu_lzma_encode_with_lists(unsigned char *dest, size_t *destLen, const unsigned char *src, size_t srcLen,

@@ -109,6 +109,20 @@ static bool tracing()
 	return t != 0;
 }
 
+// LRZGPU_TRACE=2: one line per block milestone (seconds since the run started) for timeline analysis
+static double g_trace_t0 = 0;
+static bool tracing_events()
+{
+	static int t = (getenv("LRZGPU_TRACE") && atoi(getenv("LRZGPU_TRACE")) >= 2) ? 1 : 0;
+	return t != 0;
+}
+#define TRACE_EVENT(what, j)                                                                                                        \
+	do {                                                                                                                        \
+		if (tracing_events())                                                                                               \
+			fprintf(stderr, "ev %.3f %s chunk %d stream %d off %lld len %lld\n", now_s() - g_trace_t0, what, (j)->chunk->index, \
+				(j)->ref.streamno, (long long)(j)->ref.off, (long long)(j)->ref.len);                                 \
+	} while (0)
+
 static hipError_t make_stream(hipStream_t *s, bool high_priority = false)
 {
 	if (high_priority) {
@@ -283,6 +297,7 @@ struct Pipeline {
 				enc_queue.pop_front();
 			}
 			const double te0 = now_s();
+			TRACE_EVENT("enc_start", j);
 			if (!j->cancelled && sz.zstd) {
 				// zstd_compress_buf(), src/stream.c:167-230: dlen = round_up_page(s_len); "does not fit" and
 				// "not smaller" both leave the block stored
@@ -310,6 +325,7 @@ struct Pipeline {
 				ml.counts = j->counts.data();
 				ml.pairs = j->pairs.data();
 				ml.packed = j->packed;
+				ml.tail_flags = true;
 				// dlen = round_up_page(s_len * 1.02), src/stream.c:443
 				size_t cap = (size_t)((double)j->ref.len * 1.02);
 				cap = (cap + kPage - 1) / kPage * kPage;
@@ -333,6 +349,7 @@ struct Pipeline {
 				enc_busy += t_last_enc - te0;
 				enc_wait += te0 - tw0;
 			}
+			TRACE_EVENT("enc_end", j);
 			mark_finished(j, true);
 		}
 	}
@@ -404,7 +421,8 @@ struct Pipeline {
 		}
 		LzmaParams lp;
 		const bool lzma_ok = lzma_normalize(lp, sz.level, sz.dict_size, 3, 0, 2, sz.level < 7 ? 32 : 64) == LZ_OK;
-		const bool pack = lzma_ok && lp.dict_size <= (1u << 25) && lp.fb <= 127;
+		// lists with the tail flag; one word per pair when the format allows it (lzma_mf.hip k_gather)
+		const bool pack = lzma_ok && lp.dict_size <= (1u << 25) && lp.fb <= 65;
 		for (;;) {
 			Job *j = nullptr;
 			{
@@ -420,6 +438,7 @@ struct Pipeline {
 				held++; // released in mark_finished
 			}
 			const double tw0 = now_s();
+			TRACE_EVENT("gpu_start", j);
 			const int64_t n = j->ref.len;
 			j->done.streamno = j->ref.streamno;
 			j->done.s_len = n;
@@ -478,7 +497,7 @@ struct Pipeline {
 							return;
 						}
 					}
-					int r = mf_run_device(ws, d_blk, (size_t)n, lp.dict_size, (uint32_t)lp.fb, lp.cut(), s, &total, pack, lp.fast);
+					int r = mf_run_device(ws, d_blk, (size_t)n, lp.dict_size, (uint32_t)lp.fb, lp.cut(), s, &total, pack ? 2 : 1, lp.fast);
 					if (r == 0)
 						break;
 					if (r == -4 && attempt < 3) { // pool too small for this data: grow and retry
@@ -503,6 +522,7 @@ struct Pipeline {
 					return;
 				}
 			}
+			TRACE_EVENT("gpu_end", j);
 			int act;
 			{
 				std::lock_guard<std::mutex> lk(mu);
@@ -617,8 +637,10 @@ struct Feeder {
 			return 0;
 		{
 			std::lock_guard<std::mutex> lk(P.mu);
-			for (Job *j : jobs)
+			for (Job *j : jobs) {
 				P.gpu_queue.push_back(j);
+				TRACE_EVENT("submit", j);
+			}
 			P.cv_jobs.notify_all();
 		}
 		Lz4Batch b;
@@ -687,6 +709,7 @@ struct Feeder {
 				for (size_t i = 0; i < b.jobs.size(); i++) {
 					b.jobs[i]->lz4_size = res[i];
 					b.jobs[i]->lz4_ready = true;
+					TRACE_EVENT("gate_done", b.jobs[i]);
 					if (P.route(b.jobs[i]) == 1)
 						raw.push_back(b.jobs[i]);
 				}
@@ -1304,6 +1327,7 @@ int Run::run()
 			scan_slots, P.n_encoders, P.n_gpu_workers);
 
 	t0 = now_s();
+	g_trace_t0 = t0;
 	P.start();
 	std::vector<std::thread> side;
 	const bool want_md5 = !sel || sel->with_md5;

@@ -19,7 +19,11 @@ namespace lrzgpu {
 struct MatchLists {
 	const uint8_t *counts = nullptr; // n entries
 	const uint32_t *pairs = nullptr;
-	bool packed = false; // pairs[] holds one u32 per pair: len << 25 | dist-1 (counts[] still counts 2 per pair)
+	// tail_flags: the producer also answered, per pair, "do the two bytes after this match and one literal continue
+	// at the same distance?" (lzma_mf.hip k_gather): bit 31 of the len word.
+	// packed (implies tail_flags): pairs[] holds one u32 per pair: flag << 31 | (len - 2) << 25 | dist-1
+	// (counts[] still counts 2 per pair).
+	bool packed = false, tail_flags = false;
 };
 
 struct LzmaParams {

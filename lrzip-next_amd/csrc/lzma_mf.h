@@ -30,8 +30,9 @@ struct MfWorkspace {
 // pool_per_pos: u32 pool entries reserved per input byte (typical text needs ~6-10).
 int mf_workspace_create(MfWorkspace **out, size_t max_n, double pool_per_pos);
 void mf_workspace_destroy(MfWorkspace *w);
-// pack: pool_out holds one u32 per pair (len << 25 | dist-1), total_entries/2 words; needs dict <= 32 MiB
+// mode: 0 plain (len, dist-1) couples; 1 the same with the tail flag in bit 31 of len; 2 one u32 per pair
+// (flag << 31 | (len - 2) << 25 | dist-1, total_entries/2 words; needs dict <= 32 MiB and fb <= 65) -- see k_gather
 int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict, uint32_t fb, uint32_t cut,
-		  hipStream_t s, unsigned long long *total_entries, bool pack = false, bool hc5 = false);
+		  hipStream_t s, unsigned long long *total_entries, int mode = 0, bool hc5 = false);
 
 } // namespace lrzgpu

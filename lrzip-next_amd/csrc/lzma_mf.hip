@@ -468,11 +468,29 @@ struct CountToU64 {
 	__host__ __device__ unsigned long long operator()(const uint8_t &c) const { return (unsigned long long)c; }
 };
 
-// pack != 0: one u32 per (len, dist-1) pair = len << 25 | dist-1 (dictionaries up to 32 MiB, len < 128):
-// halves the PCIe volume of the lists; the host parser unpacks on the fly.
+// Output formats of the position-ordered lists (`mode`):
+//   0  plain: (len, dist-1) u32 couples, as MatchFinderMt_GetMatches returns them
+//   1  flagged: the same with bit 31 of `len` = the tail flag
+//   2  packed + flagged: one u32 per pair = flag << 31 | (len - 2) << 25 | dist-1 (dictionaries up to 32 MiB,
+//      len <= 65): halves the PCIe volume of the lists; the host parser reads them in place
+// The tail flag answers the one question the optimal parser asks about the block's bytes at EVERY candidate
+// distance of EVERY position -- "after this match and one more (literal) byte, do the next two bytes continue at
+// the same distance?" (the match + literal + repeat-0 candidate, reference LzmaEnc.c:1900-1960).  On the host
+// that is a random access up to a dictionary behind per pair, a cache miss each, and the answer is "no" 99.9%
+// of the time; here it is two more loads of a thread that holds the pair anyway.
+__device__ inline uint32_t tail_flag(const uint8_t *__restrict__ src, uint32_t n, uint32_t pos, uint32_t len, uint32_t dist1)
+{
+	const uint64_t a = (uint64_t)pos + len + 1; // first byte after the literal
+	if (a + 2 > n)
+		return 0;
+	const uint8_t *p = src + a, *q = p - dist1 - 1;
+	return (p[0] == q[0] && p[1] == q[1]) ? 1u : 0u;
+}
+
 __global__ void __launch_bounds__(256) k_gather(const uint8_t *__restrict__ counts, const uint64_t *__restrict__ tmp_start,
 						const unsigned long long *__restrict__ offsets, const uint32_t *__restrict__ pool,
-						uint32_t *__restrict__ out, uint32_t n, unsigned long long pool_cap, int pack)
+						uint32_t *__restrict__ out, uint32_t n, unsigned long long pool_cap, int mode,
+						const uint8_t *__restrict__ src)
 {
 	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	uint32_t stride = gridDim.x * blockDim.x;
@@ -481,10 +499,16 @@ __global__ void __launch_bounds__(256) k_gather(const uint8_t *__restrict__ coun
 		if (!c || tmp_start[i] + c > pool_cap || offsets[i] + c > pool_cap)
 			continue;
 		const uint32_t *s = pool + tmp_start[i];
-		if (pack) {
+		if (mode == 2) {
 			uint32_t *d = out + (offsets[i] >> 1);
 			for (uint32_t k = 0; k < c; k += 2)
-				d[k >> 1] = (s[k] << 25) | s[k + 1];
+				d[k >> 1] = (tail_flag(src, n, i, s[k], s[k + 1]) << 31) | ((s[k] - 2) << 25) | s[k + 1];
+		} else if (mode == 1) {
+			uint32_t *d = out + offsets[i];
+			for (uint32_t k = 0; k < c; k += 2) {
+				d[k] = s[k] | (tail_flag(src, n, i, s[k], s[k + 1]) << 31);
+				d[k + 1] = s[k + 1];
+			}
 		} else {
 			uint32_t *d = out + offsets[i];
 			for (uint32_t k = 0; k < c; k++)
@@ -571,9 +595,9 @@ static inline int grid_for(size_t n, int block) // ~8 blocks per CU, grid-stride
 // Runs the finder on d_src[0..n) (device). Results stay on the device in w->counts / w->pool_out;
 // *total_entries receives the number of u32 entries.
 int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict, uint32_t fb, uint32_t cut,
-		  hipStream_t s, unsigned long long *total_entries, bool pack, bool hc5)
+		  hipStream_t s, unsigned long long *total_entries, int mode, bool hc5)
 {
-	if (pack && (dict > (1u << 25) || fb > 127))
+	if (mode < 0 || mode > 2 || (mode == 2 && (dict > (1u << 25) || fb > 65)))
 		return -3;
 	if (n > w->max_n || n >= 0xFFFFFFF0ull)
 		return -2;
@@ -662,7 +686,7 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 		hipcub::TransformInputIterator<unsigned long long, CountToU64, const uint8_t *> it(w->counts, CountToU64());
 		HIPCHK(hipcub::DeviceScan::ExclusiveSum(w->cub_tmp, tb, it, (unsigned long long *)w->offsets, (int)n, s));
 		hipLaunchKernelGGL(k_gather, dim3(grid_for(n, 256)), dim3(256), 0, s, w->counts, w->tmp_start,
-				   (const unsigned long long *)w->offsets, w->pool_tmp, w->pool_out, (uint32_t)n, w->pool_cap, pack ? 1 : 0);
+				   (const unsigned long long *)w->offsets, w->pool_tmp, w->pool_out, (uint32_t)n, w->pool_cap, mode, d_src);
 		hipLaunchKernelGGL(k_total, dim3(1), dim3(1), 0, s, w->counts, (const unsigned long long *)w->offsets, (uint32_t)n, d_total);
 	}
 	t_all.stop();

@@ -192,8 +192,10 @@ struct LzmaModel {
 struct PriceTables {
 	BitPrices bit;
 	LenPrices match_len, rep_len;
-	uint32_t slot[kLenToDistStates][kDistSlots];
-	uint32_t near_dist[kLenToDistStates][kNearDistances];
+	// distance prices, the four length contexts of one slot / one near distance adjacent: the parser prices a
+	// pair for every length it covers with one 128-bit load (lengths 2, 3, 4 and "5 or more" differ only here)
+	alignas(16) uint32_t slot[kDistSlots][kLenToDistStates];
+	alignas(16) uint32_t near_dist[kNearDistances][kLenToDistStates];
 	uint32_t align[kAlignSize];
 
 	// literal coded plainly: 8 tree levels, all node indices known from the symbol
@@ -260,18 +262,17 @@ struct PriceTables {
 				}
 				if (sl >= 14) // far distance: (sl/2 - 1) footer bits, all but the 4 align bits at one bit each
 					pr += (uint32_t)((sl >> 1) - 1 - kAlignBits) << kPriceBitShift;
-				slot[ls][sl] = pr;
+				slot[sl][ls] = pr;
 			}
-			uint32_t *nd = near_dist[ls];
 			for (unsigned d = 0; d < 4; d++)
-				nd[d] = slot[ls][d];
+				near_dist[d][ls] = slot[d][ls];
 			for (unsigned d = 4; d < kNearDistances; d++)
-				nd[d] = slot[ls][dist_slot(d)] + footer[d];
+				near_dist[d][ls] = slot[dist_slot(d)][ls] + footer[d];
 		}
 	}
 	inline uint32_t distance(unsigned len_state, uint32_t d) const
 	{
-		return d < kNearDistances ? near_dist[len_state][d] : slot[len_state][dist_slot(d)] + align[d & (kAlignSize - 1)];
+		return d < kNearDistances ? near_dist[d][len_state] : slot[dist_slot(d)][len_state] + align[d & (kAlignSize - 1)];
 	}
 };
 

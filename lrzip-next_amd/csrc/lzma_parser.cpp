@@ -25,6 +25,21 @@
 #include "lzma_enc.h"
 #include "lzma_model.h"
 
+// tools/parser_prof.sh builds this file with -DLZMA_PARSER_PROF: cycle laps per section of the search
+#ifdef LZMA_PARSER_PROF
+#include <x86intrin.h>
+#include <cstdio>
+static unsigned long long g_lap[16], g_lap_last;
+#define LAP(k)                                 \
+	do {                                   \
+		unsigned long long n_ = __rdtsc(); \
+		g_lap[k] += n_ - g_lap_last;       \
+		g_lap_last = n_;                   \
+	} while (0)
+#else
+#define LAP(k) ((void)0)
+#endif
+
 namespace lrzgpu {
 namespace {
 
@@ -60,11 +75,16 @@ inline bool same2(const uint8_t *a, const uint8_t *b)
 }
 
 // One position's match list, viewed in the finder's output (pairs sorted by increasing length).
-template <bool PACKED> struct PairView {
+// FORMAT (lzma_mf.hip k_gather): 0 plain (len, dist-1) couples; 1 the same with the tail flag in bit 31 of len;
+// 2 one word per pair: flag << 31 | (len - 2) << 25 | dist-1.
+template <int FORMAT> struct PairView {
+	static constexpr bool kPacked = FORMAT == 2, kFlagged = FORMAT != 0;
 	const uint32_t *w = nullptr;
 	unsigned count = 0; // pairs
-	inline unsigned len(unsigned k) const { return PACKED ? w[k] >> 25 : w[2 * k]; }
-	inline uint32_t dist(unsigned k) const { return PACKED ? w[k] & 0x1FFFFFFu : w[2 * k + 1]; }
+	inline unsigned len(unsigned k) const { return kPacked ? ((w[k] >> 25) & 63) + 2 : (kFlagged ? w[2 * k] & 0x7FFFFFFFu : w[2 * k]); }
+	inline uint32_t dist(unsigned k) const { return kPacked ? w[k] & 0x1FFFFFFu : w[2 * k + 1]; }
+	// "after this match and one literal the next two bytes continue at the same distance" (only if kFlagged)
+	inline bool tail(unsigned k) const { return (kPacked ? w[k] : w[2 * k]) >> 31; }
 };
 
 // edge descriptor: how a node was reached.  `len` bytes with distance code `code`; `pre` != 0 means the edge
@@ -79,7 +99,8 @@ struct Step {
 	uint32_t len, code;
 };
 
-template <bool PACKED> struct BlockEncoder {
+template <int FORMAT> struct BlockEncoder {
+	static constexpr bool PACKED = FORMAT == 2;
 	// ---- input ----------------------------------------------------------------------------------
 	const uint8_t *data = nullptr;
 	size_t n = 0;
@@ -111,7 +132,7 @@ template <bool PACKED> struct BlockEncoder {
 	alignas(16) uint32_t node_reps[kWindow + kLenMax + 16][kRepSlots];
 
 	// a list fetched for the position after the parse it ended (a match of nice_len there cuts the search)
-	PairView<PACKED> held;
+	PairView<FORMAT> held;
 	unsigned held_len = 0;
 	uint32_t avail_at_fetch = 0; // bytes from the last fetched position to the end of the block
 
@@ -119,12 +140,34 @@ template <bool PACKED> struct BlockEncoder {
 	unsigned q_head = 0, q_tail = 0;
 
 	// ---- finder stream -----------------------------------------------------------------------------------
-	inline PairView<PACKED> take()
+	// The search looks at the block's bytes at every candidate distance of every position ("does the match go on
+	// after one literal?"): random addresses up to a dictionary back, a cache miss each.  The lists of the
+	// positions ahead are already in the stream, so those lines are requested kPrefetchAhead positions early.
+	static constexpr unsigned kPrefetchAhead = 12;
+	size_t pf_pos = 0;
+	uint64_t pf_off = 0;
+	inline void prefetch_targets()
 	{
+		if (FORMAT != 0)
+			return; // the finder answered the question itself (tail flags): nothing to fetch
+		while (pf_pos < fetch_pos + kPrefetchAhead && pf_pos < n) {
+			const unsigned c = counts[pf_pos];
+			PairView<FORMAT> v;
+			v.w = words + pf_off;
+			const uint8_t *q = data + pf_pos;
+			for (unsigned k = 0; k < (c >> 1); k++)
+				__builtin_prefetch(q + v.len(k) - v.dist(k));
+			pf_off += c;
+			pf_pos++;
+		}
+	}
+	inline PairView<FORMAT> take()
+	{
+		prefetch_targets();
 		ahead++;
 		avail_at_fetch = (uint32_t)(n - fetch_pos);
 		const unsigned c = counts[fetch_pos];
-		PairView<PACKED> v;
+		PairView<FORMAT> v;
 		v.w = words + (PACKED ? (fetch_off >> 1) : fetch_off);
 		v.count = c >> 1;
 		fetch_off += c;
@@ -140,10 +183,14 @@ template <bool PACKED> struct BlockEncoder {
 			sum += c[i];
 		fetch_off += sum;
 		fetch_pos += k;
+		if (pf_pos < fetch_pos) { // the skipped positions need no look-ahead any more
+			pf_pos = fetch_pos;
+			pf_off = fetch_off;
+		}
 	}
 	// longest length of a list; a longest pair of exactly nice_len is extended over the bytes that follow
 	// (the finder stops comparing there)
-	inline unsigned longest(const PairView<PACKED> &v) const
+	inline unsigned longest(const PairView<FORMAT> &v) const
 	{
 		if (!v.count)
 			return 0;
@@ -190,6 +237,34 @@ template <bool PACKED> struct BlockEncoder {
 		}
 	}
 
+	// edges (len, code) of one fresh distance for every len in [lo, hi]: price = base + len_row[len] + the distance
+	// price of the length's context, `dist4` = those four prices (lengths 2, 3, 4, 5+)
+	inline void relax_pair(unsigned from, unsigned lo, unsigned hi, uint32_t base, const uint32_t *len_row, __m128i dist4, uint32_t code)
+	{
+		const __m256i iota = _mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7);
+		const __m256i code64 = _mm256_set1_epi64x((long long)code);
+		const __m256i vbase = _mm256_add_epi32(_mm256_set1_epi32((int)base), _mm256_castsi128_si256(dist4)); // lanes 0..3 valid
+		const __m256i three = _mm256_set1_epi32((int)kLenToDistStates - 1);
+		for (unsigned l = lo; l <= hi; l += 8) {
+			const unsigned left = hi - l + 1;
+			const __m256i lens = _mm256_add_epi32(_mm256_set1_epi32((int)l), iota);
+			const __m256i ctx = _mm256_min_epu32(_mm256_sub_epi32(lens, _mm256_set1_epi32((int)kLenMin)), three);
+			const __m256i live = _mm256_cmpgt_epi32(_mm256_set1_epi32((int)left), iota);
+			const __m256i cand = _mm256_add_epi32(_mm256_permutevar8x32_epi32(vbase, ctx), _mm256_loadu_si256((const __m256i *)(len_row + l)));
+			uint32_t *cp = cost + from + l;
+			uint64_t *vp = via + from + l;
+			const __m256i old = _mm256_loadu_si256((const __m256i *)cp);
+			const __m256i win = _mm256_and_si256(_mm256_cmpgt_epi32(old, cand), live);
+			_mm256_storeu_si256((__m256i *)cp, _mm256_blendv_epi8(old, cand, win));
+			const __m256i e_lo = _mm256_or_si256(_mm256_slli_epi64(_mm256_cvtepu32_epi64(_mm256_castsi256_si128(lens)), 32), code64);
+			const __m256i e_hi = _mm256_or_si256(_mm256_slli_epi64(_mm256_cvtepu32_epi64(_mm256_extracti128_si256(lens, 1)), 32), code64);
+			const __m256i w_lo = _mm256_cvtepi32_epi64(_mm256_castsi256_si128(win));
+			const __m256i w_hi = _mm256_cvtepi32_epi64(_mm256_extracti128_si256(win, 1));
+			_mm256_storeu_si256((__m256i *)vp, _mm256_blendv_epi8(_mm256_loadu_si256((const __m256i *)vp), e_lo, w_lo));
+			_mm256_storeu_si256((__m256i *)(vp + 4), _mm256_blendv_epi8(_mm256_loadu_si256((const __m256i *)(vp + 4)), e_hi, w_hi));
+		}
+	}
+
 	// ---- prices of the flag bits in front of a symbol ----------------------------------------------------------------
 	inline uint32_t price_short_rep(unsigned st, unsigned ps) const
 	{
@@ -227,8 +302,9 @@ template <bool PACKED> struct BlockEncoder {
 	// Compound edge "X of x_len bytes, one literal, repeat-0": X ends at here + x_len with distance `dist`;
 	// if at least two bytes after the literal continue at that distance, the whole thing is one candidate.
 	// `price_x` = price up to and including X.  Returns the node it reaches (0 if none).
+	// `known`: -1 = look at the bytes; 0 / 1 = the finder's tail flag for exactly this (x_len, dist).
 	inline unsigned try_literal_then_rep0(unsigned cur, const uint8_t *here, uint32_t position, unsigned x_len, uint32_t dist,
-					       unsigned st_after_x, uint32_t price_x, uint32_t room, uint32_t code)
+					       unsigned st_after_x, uint32_t price_x, uint32_t room, uint32_t code, int known = -1)
 	{
 		const uint8_t *there = here - dist;
 		unsigned tail = x_len + 1; // the literal's index
@@ -236,7 +312,7 @@ template <bool PACKED> struct BlockEncoder {
 		if (limit > room)
 			limit = room;
 		tail += 2;
-		if (tail > limit || !same2(here + tail - 2, there + tail - 2))
+		if (tail > limit || (known >= 0 ? !known : !same2(here + tail - 2, there + tail - 2)))
 			return 0;
 		const unsigned end = equal_until(here, there, tail, limit);
 		const unsigned rep_len = end - x_len - 1;
@@ -253,7 +329,7 @@ template <bool PACKED> struct BlockEncoder {
 	unsigned plan(uint32_t position, Step *first)
 	{
 		// ---- the root: what can start at the coder's position -------------------------------------------
-		PairView<PACKED> list;
+		PairView<FORMAT> list;
 		unsigned main_len;
 		if (ahead == 0) {
 			list = take();
@@ -345,8 +421,10 @@ template <bool PACKED> struct BlockEncoder {
 				cur = best;
 				break;
 			}
-			const PairView<PACKED> fresh = take();
+			LAP(0);
+			const PairView<FORMAT> fresh = take();
 			unsigned new_len = longest(fresh);
+			LAP(1);
 			if (new_len >= nice_len) { // a match worth taking outright starts here: the parse ends at this node
 				held = fresh;
 				held_len = new_len;
@@ -391,6 +469,7 @@ template <bool PACKED> struct BlockEncoder {
 			}
 			node_state[cur] = (uint8_t)st;
 			memcpy(node_reps[cur], r, sizeof(r));
+			LAP(2);
 
 			here = data + fetch_pos - 1;
 			const unsigned cb = here[0], mb = here[-(ptrdiff_t)r[0]];
@@ -425,6 +504,7 @@ template <bool PACKED> struct BlockEncoder {
 				}
 			}
 
+			LAP(3);
 			uint32_t room_full = avail_at_fetch;
 			if (room_full > kWindow - 1 - cur)
 				room_full = kWindow - 1 - cur;
@@ -448,6 +528,7 @@ template <bool PACKED> struct BlockEncoder {
 				}
 			}
 
+			LAP(4);
 			// -- repeats
 			unsigned match_from = 2; // shortest fresh-distance length worth pricing
 			for (unsigned i = 0; i < kRepSlots; i++) {
@@ -466,6 +547,7 @@ template <bool PACKED> struct BlockEncoder {
 					frontier = node;
 			}
 
+			LAP(5);
 			// -- fresh distances
 			unsigned pairs = fresh.count;
 			if (new_len > room_nice) { // the list may reach past what can still be used: clip it
@@ -483,15 +565,20 @@ template <bool PACKED> struct BlockEncoder {
 		}
 
 		// ---- the window is clean again for the next parse; walk the winning path back ----------------------
+		LAP(0);
 		for (unsigned k = 1; k <= frontier; k++)
 			cost[k] = kPriceInfinite;
-		return trace_back(cur, first);
+		{
+			const unsigned r_ = trace_back(cur, first);
+			LAP(7);
+			return r_;
+		}
 	}
 
 	// edges of fresh distances from node `cur`: for every length lo..hi the nearest distance that reaches it
 	// (pair k covers the lengths above pair k-1's up to its own; the last usable pair is clipped to hi),
 	// plus, with `compound`, the "match, literal, repeat-0" edge at the full length of every pair.
-	inline void relax_matches(unsigned cur, const PairView<PACKED> &list, unsigned pairs, unsigned lo, unsigned hi, uint32_t base,
+	inline void relax_matches(unsigned cur, const PairView<FORMAT> &list, unsigned pairs, unsigned lo, unsigned hi, uint32_t base,
 				  unsigned ps, const uint8_t *here, uint32_t position, unsigned st, uint32_t room_full, int compound,
 				  unsigned *frontier)
 	{
@@ -506,16 +593,26 @@ template <bool PACKED> struct BlockEncoder {
 				top = hi;
 			const uint32_t d = list.dist(k);
 			const uint32_t code = d + kRepSlots;
-			// lengths 2, 3, 4 have their own distance contexts; from 5 on the distance price is one constant
-			for (; len <= top && len < kLenMin + kLenToDistStates - 1; len++)
-				relax(cur + len, base + len_row[len] + prices.distance(len - kLenMin, d), edge(len, code));
+			// the distance price in the four length contexts: near distances from one table, far ones slot + align
+			alignas(16) uint32_t dp[4];
+			__m128i dist4;
+			if (d < kNearDistances)
+				dist4 = _mm_load_si128((const __m128i *)prices.near_dist[d]);
+			else
+				dist4 = _mm_add_epi32(_mm_load_si128((const __m128i *)prices.slot[dist_slot(d)]), _mm_set1_epi32((int)prices.align[d & (kAlignSize - 1)]));
+			// a node reached through this pair reads the byte that follows the match source (its repeat-0 byte)
+			// when it is expanded, `top` positions from now: have the line on its way
+			__builtin_prefetch(data + fetch_pos - 1 + top - d - 1);
 			if (len <= top) {
-				relax_span(cur, len, top, base + prices.distance(kLenToDistStates - 1, d), len_row, code);
+				relax_pair(cur, len, top, base, len_row, dist4, code);
 				len = top + 1;
 			}
 			if (compound) {
-				const uint32_t price_x = base + len_row[top] + prices.distance(len_dist_state(top), d);
-				const unsigned node = try_literal_then_rep0(cur, here, position, top, d + 1, after_match(st), price_x, room_full, code);
+				_mm_store_si128((__m128i *)dp, dist4);
+				const uint32_t price_x = base + len_row[top] + dp[len_dist_state(top)];
+				// the flag speaks for the pair's own length; a clipped last pair has to look at the bytes
+				const int known = PairView<FORMAT>::kFlagged && top == list.len(k) ? (int)list.tail(k) : -1;
+				const unsigned node = try_literal_then_rep0(cur, here, position, top, d + 1, after_match(st), price_x, room_full, code, known);
 				if (*frontier < node)
 					*frontier = node;
 			}
@@ -558,7 +655,7 @@ template <bool PACKED> struct BlockEncoder {
 	static inline bool much_nearer(uint32_t small_dist, uint32_t big_dist) { return (big_dist >> 7) > small_dist; }
 	unsigned plan_greedy(Step *first)
 	{
-		PairView<PACKED> list;
+		PairView<FORMAT> list;
 		unsigned main_len;
 		if (ahead == 0) {
 			list = take();
@@ -766,11 +863,14 @@ template <bool PACKED> struct BlockEncoder {
 					s = queue[q_head++];
 				else if (greedy)
 					plan_greedy(&s);
-				else
+				else {
+					LAP(8);
 					plan(pos, &s);
+				}
 				code_step(pos, s);
 				pos += s.len;
 				ahead -= s.len;
+				LAP(9);
 				if (ahead == 0) { // the coder has caught up with the finder: the only moment tables may change
 					if (!greedy && matches_since_refresh >= kRefreshEvery)
 						refresh_all();
@@ -778,6 +878,7 @@ template <bool PACKED> struct BlockEncoder {
 						rep_lens_until_refresh = (int)kRefreshEvery;
 						prices.rep_len.refresh(model.rep_len, prices.bit, 1u << model.pb, nice_len);
 					}
+					LAP(10);
 					if (fetch_pos == n || rc.overflow)
 						break; // (an overflow ends in LZ_ERROR_OUTPUT_EOF whatever follows)
 				}
@@ -786,10 +887,10 @@ template <bool PACKED> struct BlockEncoder {
 	}
 };
 
-template <bool PACKED>
+template <int FORMAT>
 int encode_with(const LzmaParams &prm, const uint8_t *src, size_t n, const MatchLists &ml, uint8_t *dest, size_t dest_cap, size_t *dest_len)
 {
-	std::unique_ptr<BlockEncoder<PACKED>> e(new (std::nothrow) BlockEncoder<PACKED>());
+	std::unique_ptr<BlockEncoder<FORMAT>> e(new (std::nothrow) BlockEncoder<FORMAT>());
 	if (!e)
 		return LZ_ERROR_MEM;
 	e->data = src;
@@ -799,7 +900,21 @@ int encode_with(const LzmaParams &prm, const uint8_t *src, size_t n, const Match
 	e->rc.out = dest;
 	e->rc.cap = dest_cap;
 	e->setup(prm);
+#ifdef LZMA_PARSER_PROF
+	g_lap_last = __rdtsc();
+#endif
 	e->run();
+#ifdef LZMA_PARSER_PROF
+	{
+		static const char *nm[] = {"matches + loop ends", "take list", "enter node", "literal + short rep", "literal, rep0", "repeats", "-", "reset + trace back", "root (plan start)", "code step", "table refresh"};
+		unsigned long long tot = 0;
+		for (int k = 0; k < 11; k++)
+			tot += g_lap[k];
+		for (int k = 0; k < 11; k++)
+			fprintf(stderr, "%-22s %6.2f%%  %.1f cyc/byte\n", nm[k], 100.0 * g_lap[k] / tot, (double)g_lap[k] / n);
+		fprintf(stderr, "total %.1f cyc/byte (each lap costs ~25-30 cycles itself)\n", (double)tot / n);
+	}
+#endif
 	if (e->rc.overflow) {
 		*dest_len = dest_cap;
 		return LZ_ERROR_OUTPUT_EOF;
@@ -867,7 +982,11 @@ int lzma_encode_block(const LzmaParams &prm, const uint8_t *src, size_t n, const
 		return LZ_ERROR_PARAM;
 	if (n >= 0xFFFFFFFFu)
 		return LZ_ERROR_PARAM;
-	return ml.packed ? encode_with<true>(prm, src, n, ml, dest, dest_cap, dest_len) : encode_with<false>(prm, src, n, ml, dest, dest_cap, dest_len);
+	if (ml.packed)
+		return encode_with<2>(prm, src, n, ml, dest, dest_cap, dest_len);
+	if (ml.tail_flags)
+		return encode_with<1>(prm, src, n, ml, dest, dest_cap, dest_len);
+	return encode_with<0>(prm, src, n, ml, dest, dest_cap, dest_len);
 }
 
 } // namespace lrzgpu

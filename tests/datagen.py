@@ -87,3 +87,28 @@ def cfg3(n, base, seed=1, mutate_every=65536):
         pos = base + np.arange(cells, dtype=np.int64) * mutate_every + rng.integers(0, mutate_every, size=cells)
         a[pos] = rng.integers(0, 256, size=cells, dtype=np.uint8)
     return a.tobytes()
+
+
+def victim_mover(n, hash_index, seed=1, every=65536, count_limit=None):
+    """Random bytes with, every `every` bytes, a fresh PERMUTATION of one fixed 31-byte multiset.  rzip's tag is
+    the XOR of per-byte table values, blind to order: all those windows carry the same tag but never match
+    (31 equal bytes are needed), so they pile up in the hash table until max_chain_len of them are met and
+    insert_hash()'s round-robin victim counter (the static of src/rzip.c:308) advances.  The multiset is chosen
+    so that the tag has its 20 low bits set: it stays a candidate however far the tag masks have tightened."""
+    rng = np.random.default_rng(seed)
+    hx = np.array(hash_index, dtype=np.uint64)
+    while True:
+        cand = rng.integers(0, 256, size=(1 << 18, 31), dtype=np.uint8)
+        t = np.bitwise_xor.reduce(hx[cand], axis=1)
+        hit = np.nonzero((t & np.uint64(0xFFFFF)) == np.uint64(0xFFFFF))[0]
+        if len(hit):
+            ms = cand[hit[0]]
+            break
+    a = rng.integers(0, 256, size=n, dtype=np.uint8)
+    k = 0
+    for at in range(every // 2, n - 64, every):
+        if count_limit is not None and k >= count_limit:
+            break
+        a[at:at + 31] = rng.permutation(ms)
+        k += 1
+    return a.tobytes()

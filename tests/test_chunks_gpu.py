@@ -51,12 +51,20 @@ def test_cfg3_reduced_concurrent_chunks(B, O, cfg3_small):
     assert B.decompress_buffer(got, host_threads=16) == data
 
 
+def _moving_victim_data(O):
+    """Three -w1 chunks whose victim_round does not come back to 0 (checked with the oracle's own scan)."""
+    data = datagen.victim_mover(2 * 104857600 + 20 * 1048576, O.hash_index(), seed=3, every=32768)
+    vr = O.rzip_chunk(data[:104857600], level=7)[4]
+    assert vr != 0, "generator no longer moves victim_round: pick another seed"
+    return data
+
+
 def test_victim_round_chain_rescans(B, O):
-    """27-symbol text collapses the tag space (the XOR tag only sees byte-count parities), buckets fill to
-    max_chain_len and insert_hash()'s static victim_round moves: a chunk that was scanned ahead of its
-    predecessor with the predicted value 0 has to be scanned again.  Same bytes as the serial chain."""
+    """Permutations of one 31-byte multiset share a tag without ever matching: they pile up in the table until
+    insert_hash()'s static victim_round moves (src/rzip.c:308-343).  A chunk that was scanned ahead of its
+    predecessor with the predicted value 0 then has to be scanned again; same bytes as the serial chain."""
     bench = _bench()
-    data = datagen.long_range(250 * 1048576 + 4097, seed=14, base_frac=0.08, mutate_every=300007)
+    data = _moving_victim_data(O)
     want, fs = O.compress_buffer(data, compression_level=7, threads=4, processors=8, ramsize=RAM, window=1, workers=16)
     assert fs.n_chunks == 3
     B.lib().lrzgpu_profile_reset()
@@ -112,7 +120,7 @@ def test_chunk_sharded_equals_single_process(B, O, world):
 
 def test_chunk_sharded_with_moving_victim_round(B, O):
     kw = dict(level=7, threads=4, processors=8, ramsize=RAM, window=1)
-    data = datagen.long_range(250 * 1048576 + 4097, seed=14, base_frac=0.08, mutate_every=300007)
+    data = _moving_victim_data(O)
     want, _ = O.compress_buffer(data, compression_level=7, threads=4, processors=8, ramsize=RAM, window=1, workers=16)
     got, redone = _sharded(B, data, 3, **kw)
     assert got == want and redone >= 1

@@ -27,11 +27,15 @@ def main():
         rc, want, _ = O.lzma_compress_ref(data, level=level, dict_size=dict_size)
         assert rc == 0
         pickle.dump((data, counts, pairs, want), open(cache, "wb"))
+    fmt = int(os.environ.get("LIST_FORMAT", "0"))
+    if fmt:
+        pairs = B.format_lists(data, counts, pairs, fmt)
     best = 1e9
     for _ in range(reps):
         t0 = time.time()
-        rc, got = B.lzma_encode_with_lists(data, counts, pairs, level=level, dict_size=dict_size, fb=fb)
+        rc, got = B.lzma_encode_with_lists(data, counts, pairs, level=level, dict_size=dict_size, fb=fb, list_format=fmt)
         best = min(best, time.time() - t0)
+    print("fmt %d " % fmt, end="")
     print("%s %.1f MiB L%d: %.3f s  %.2f MiB/s  %s (%d -> %d bytes, %.2f pairs/pos)" % (
         kind, mib, level, best, mib / best, "BIT-EXACT" if (rc == 0 and got == want) else "MISMATCH rc=%d" % rc, n, len(got), len(pairs) / 2 / n))
 
