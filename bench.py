@@ -37,13 +37,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def load_bindings():
-    name = "lrzip_next_amd_bindings"
-    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "lrzip-next_amd", "bindings.py"))
+def load_module(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "lrzip-next_amd", rel))
     mod = importlib.util.module_from_spec(spec)
     sys.modules[name] = mod
     spec.loader.exec_module(mod)
     return mod
+
+
+def load_bindings():
+    return load_module("lrzip_next_amd_bindings", "bindings.py")
 
 
 class Profile(C.Structure):
@@ -238,6 +241,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     B = load_bindings()
+    SH = load_module("lrzip_next_amd_sharded", "sharded.py")
     L = B.lib()
     L.lrzgpu_profile_get.argtypes = [C.POINTER(Profile)]
     if L.lrzgpu_device_count() < 1:
@@ -283,57 +287,20 @@ def main():
 
     def step_sharded():
         """chunk k -> rank k % world; chunk images handed to rank 0 over RCCL; rank 0 lays out the file."""
-        images = {}
-        chain = {}
-        ctl = None
-        md5 = None
-        for attempt in range(n_chunks + 1):
-            if attempt == 0 and rank < n_chunks:
-                got, ctl = B.compress_chunks(dev_ptr=buf.data_ptr(), n=n_bytes, first=rank, stride=world, victim_in=None,
-                                             with_md5=(rank == 0), ctl=fresh_ctl())
-                md5 = bytes(ctl.hash_resblock)
-                for k, (vin, vout, img) in got.items():
-                    images[k] = img
-                    chain[k] = (vin, vout)
-            # everyone learns (victim_in, victim_out, length) of every chunk
-            meta = torch.zeros((n_chunks, 3), dtype=torch.int64, device=dev)
-            for k, (vin, vout) in chain.items():
-                meta[k, 0], meta[k, 1], meta[k, 2] = vin, vout, len(images[k])
-            dist.all_reduce(meta, op=dist.ReduceOp.SUM)
-            m = meta.cpu().tolist()
-            # the chain of src/rzip.c:308: chunk k must have started from what chunk k-1 left
-            want = [0] + [m[k - 1][1] for k in range(1, n_chunks)]
-            bad = [k for k in range(n_chunks) if m[k][0] != want[k]]
-            if not bad:
-                break
-            # redo only the FIRST wrong chunk (its new end value decides about its successors), on its owner
-            k0 = bad[0]
-            victim = [-1] * n_chunks
-            victim[k0] = want[k0]
-            if k0 % world == rank:
-                # only chunk k0: select it alone through (first, stride) = (k0, n_chunks)
-                got, _ = B.compress_chunks(dev_ptr=buf.data_ptr(), n=n_bytes, first=k0, stride=max(n_chunks, k0 + 1),
-                                           victim_in=victim, with_md5=False, ctl=fresh_ctl())
-                vin, vout, img = got[k0]
-                images[k0] = img
-                chain[k0] = (vin, vout)
-        # chunk hand-off to rank 0, in file order
-        out = None
-        if rank == 0:
-            imgs = []
-            for k in range(n_chunks):
-                if k % world == 0:
-                    imgs.append(images[k])
-                else:
-                    t = torch.empty(m[k][2], dtype=torch.uint8, device=dev)
-                    dist.recv(t, src=k % world)
-                    imgs.append(t.cpu().numpy().tobytes())
-            out, ctl = B.assemble_chunks(imgs, n_bytes, md5, ctl=fresh_ctl())
-        else:
-            for k in range(rank, n_chunks, world):
-                t = torch.frombuffer(bytearray(images[k]), dtype=torch.uint8).to(dev)
-                dist.send(t, dst=0)
-        return out, ctl
+        state = {"ctl": None, "md5": None}
+
+        def compress_fn(first, stride, victim_in):
+            first_call = victim_in is None
+            got, ctl = B.compress_chunks(dev_ptr=buf.data_ptr(), n=n_bytes, first=first, stride=stride, victim_in=victim_in,
+                                         with_md5=(rank == 0 and first_call), ctl=fresh_ctl())
+            if first_call:
+                state["ctl"], state["md5"] = ctl, bytes(ctl.hash_resblock)
+            return got
+
+        imgs, _ = SH.compress_sharded(compress_fn, n_chunks, rank, world, dist, torch, dev)
+        if rank != 0:
+            return None, state["ctl"]
+        return B.assemble_chunks(imgs, n_bytes, state["md5"], ctl=fresh_ctl())
 
     one_step = step_single if world == 1 else step_sharded
 

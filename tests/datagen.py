@@ -112,3 +112,38 @@ def victim_mover(n, hash_index, seed=1, every=65536, count_limit=None):
         a[at:at + 31] = rng.permutation(ms)
         k += 1
     return a.tobytes()
+
+
+def source_tree_tar(copies, tree_bytes, seed=1):
+    """BASELINE config 4 shape: an (uncompressed) tar of `copies` copies of one seeded synthetic source tree --
+    a few hundred text files of 1..64 KiB (identifiers, punctuation, indentation, newlines) under per-copy
+    directory names, so headers differ and contents repeat at tree distance."""
+    import io
+    import tarfile
+    rng = np.random.default_rng(seed)
+    words = [w for w in text_alnum(40000, seed + 1).split(b" ") if w]
+    punct = [b"(", b")", b";", b" = ", b", ", b"{", b"}", b"->", b"[i]", b" + ", b"// "]
+    files = []
+    total = 0
+    while total < tree_bytes:
+        size = int(rng.integers(1024, 65536))
+        lines, got = [], 0
+        while got < size:
+            k = int(rng.integers(2, 9))
+            idx = rng.integers(0, len(words), size=k)
+            pidx = rng.integers(0, len(punct), size=k)
+            line = b"\t" * int(rng.integers(0, 4)) + b"".join(words[i] + punct[p] for i, p in zip(idx, pidx)) + b"\n"
+            lines.append(line)
+            got += len(line)
+        body = b"".join(lines)[:size]
+        files.append(("src/mod%03d/file%04d.c" % (len(files) // 16, len(files)), body))
+        total += size
+    out = io.BytesIO()
+    with tarfile.open(fileobj=out, mode="w", format=tarfile.USTAR_FORMAT) as tf:
+        for c in range(copies):
+            for name, body in files:
+                ti = tarfile.TarInfo("tree_%02d/%s" % (c, name))
+                ti.size = len(body)
+                ti.mtime = 1700000000 + c
+                tf.addfile(ti, io.BytesIO(body))
+    return out.getvalue()

@@ -1,0 +1,85 @@
+"""BASELINE.json's configurations on the GPU, each at the flags SURVEY 8(d) maps it to.  The default sizes keep
+the whole GPU suite inside minutes and are compared byte for byte with the oracle; LRZGPU_FULL_CONFIGS=1 adds
+the full-size runs (10 / 16 / 32 GiB) as property tests -- block types, sizes, CRC/MD5 and a round trip through
+the library's decoder (tools/full_configs.sh runs them and keeps the log under profiles/)."""
+import hashlib
+import os
+
+import pytest
+
+import datagen
+
+pytestmark = pytest.mark.gpu
+
+FULL = os.environ.get("LRZGPU_FULL_CONFIGS") == "1"
+RAM = 80 * 100 << 20
+
+
+def test_cfg1_text_rzip_only_whole_file(B, O):
+    """cfg 1: 256 MiB of text, -n (rzip only, blocks stored), -w 3 -p1: one chunk, the whole-file path."""
+    data = datagen.text_alnum(256 << 20, seed=11)
+    want, fs = O.compress_buffer(data, no_compress=1, threads=1, processors=1, ramsize=RAM, window=3)
+    assert fs.n_chunks == 1
+    got, ctl = B.compress_buffer(data, no_compress=True, threads=1, processors=1, ramsize=RAM, window=3)
+    assert bytes(ctl.hash_resblock) == hashlib.md5(data).digest()
+    assert got == want
+    info = B.file_info(got)
+    assert info.chunks == 1 and info.blocks_lzma == 0 and info.st_size == len(data)
+
+
+def test_cfg4_source_tree_tar_zstd15(B, O):
+    """cfg 4 at reduced size: tar of copies of one source tree, --zstd --zstd-level 15 (=> rzip level 6), several
+    chunks; zstd blocks through the host libzstd like the reference."""
+    data = datagen.source_tree_tar(16, 24 << 20, seed=7)  # ~ 400 MiB, tree distance 24 MiB
+    assert len(data) > 3 * 104857600
+    kw = dict(level=7, threads=8, processors=16, ramsize=RAM, window=1, zstd=True, zstd_level=15)
+    want, fs = O.compress_buffer(data, compression_level=7, threads=8, processors=16, ramsize=RAM, window=1, zstd=1, zstd_level=15, workers=16)
+    assert fs.n_chunks >= 4
+    got, ctl = B.compress_buffer(data, host_threads=16, **kw)
+    assert got == want
+    assert got[17] == (6 << 4) + 4 and got[18] == 15 and got[19] >> 4 == 6  # strategy 6 | zstd, level 15, rzip level 6
+    assert B.decompress_buffer(got, host_threads=16) == data
+
+
+def test_cfg5_random_lz4_early_out(B, O):
+    """cfg 5 at 1 GiB: incompressible input, every literal block must come out stored (CTYPE 3) through the lz4
+    gate; -L7, one chunk."""
+    import numpy as np
+    data = np.random.default_rng(5).integers(0, 256, size=1 << 30, dtype=np.uint8).tobytes()
+    kw = dict(level=7, threads=16, processors=16, ramsize=24 << 30)
+    want, fs = O.compress_buffer(data, compression_level=7, threads=16, processors=16, ramsize=24 << 30, workers=16)
+    got, ctl = B.compress_buffer(data, host_threads=16, **kw)
+    assert got == want
+    info = B.file_info(got)
+    assert info.chunks == 1 and info.blocks_lzma <= 1 and info.stream_c_len[1] == info.stream_u_len[1]
+
+
+@pytest.mark.skipif(not FULL, reason="full-size configuration (LRZGPU_FULL_CONFIGS=1)")
+def test_cfg5_full_32gib_random(B):
+    import torch
+    n = 32 << 30
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    buf = torch.empty(n + 256, dtype=torch.uint8, device="cuda")
+    step = 1 << 30
+    for o in range(0, n, step):
+        buf[o:o + step] = torch.randint(0, 256, (step,), generator=g, device="cuda", dtype=torch.int16).to(torch.uint8)
+    buf[n:] = 0
+    torch.cuda.synchronize()
+    ram = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    out, ctl = B.compress_device(buf.data_ptr(), n, level=7, threads=os.cpu_count(), processors=os.cpu_count(), ramsize=ram, window=328,
+                                 copy=False)
+    info = B.file_info_ptr(out) if hasattr(B, "file_info_ptr") else None
+    back = B.decompress_buffer(out)
+    assert hashlib.md5(back).digest() == bytes(ctl.hash_resblock)
+    assert len(back) == n and torch.equal(torch.frombuffer(bytearray(back[:1 << 28]), dtype=torch.uint8), buf[:1 << 28].cpu())
+
+
+@pytest.mark.skipif(not FULL, reason="full-size configuration (LRZGPU_FULL_CONFIGS=1)")
+def test_cfg4_full_10gib_zstd_round_trip(B):
+    data = datagen.source_tree_tar(40, 256 << 20, seed=7)  # ~10 GiB
+    ram = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    got, ctl = B.compress_buffer(data, level=7, threads=os.cpu_count(), processors=os.cpu_count(), ramsize=ram, window=26, zstd=True, zstd_level=15)
+    info = B.file_info(got)
+    assert info.chunks == -(-len(data) // (26 * 104857600))
+    assert B.decompress_buffer(got) == data

@@ -1,6 +1,8 @@
-"""CPU (gloo, world_size 2) test of the chunk-per-rank path: sharding, the victim_round speculation
-protocol, gather to rank 0 and container assembly.  The chunk scanner plugged in here is the ORACLE
-(no GPU in this container); on the GPU box the same orchestration drives lrzgpu_hash_search."""
+"""CPU (gloo, world_size 2) test of the one-file-across-ranks path: chunk ownership, the victim_round chain
+protocol, the chunk hand-off to rank 0 and the product's own file assembly (lrzgpu_assemble_chunks).
+There is no GPU in this container, so the per-chunk compressor plugged into the orchestration is built from the
+ORACLE scan + the product's host-only container layout; on the GPU box bench.py plugs in
+lrzgpu_compress_chunks_dev (tests/test_chunks_gpu.py plays all ranks in one process against the real thing)."""
 import hashlib
 import importlib.util
 import os
@@ -29,37 +31,63 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
-    import torch.distributed as dist
+RAM = (2 << 20) * 3 // 2  # max_chunk = ramsize/3*2 = 2 MiB
+
+
+def _data():
     sys.path.insert(0, HERE)
     import datagen
     import oracle_lib as O
-    P = _load("lrz_parallel", "lrzip-next_amd/parallel.py")
+    # 6 chunks; permutations of one multiset make victim_round really move between chunks
+    return datagen.long_range(3 * 1048576 + 123, seed=2, base_frac=0.2) + datagen.victim_mover(8 << 20, O.hash_index(), seed=5, every=4096)[:8 << 20]
+
+
+def _chunk_image(B, O, data, ranges, k, victim_in):
+    """One chunk's bytes as they stand in the -n file: oracle scan from victim_in + the product's stored-block
+    layout of that one chunk, chunk header patched to this chunk's place in the file (eof flag)."""
+    off, n = ranges[k]
+    s0, s1, st, crc, vr_out = O.rzip_chunk(data[off:off + n], level=7, chunk_bytes=B.chunk_bytes_for(n), victim_round=victim_in)
+    one = bytearray(B.container_store(n, [n], [s0], [s1], bytes(16), no_compress=True, threads=1, ramsize=RAM)[21:-16])
+    one[1] = 1 if k + 1 == len(ranges) else 0
+    return vr_out, bytes(one)
+
+
+def _ranges(n, chunk):
+    out, off = [], 0
+    while off < n:
+        out.append((off, min(chunk, n - off)))
+        off += chunk
+    return out or [(0, 0)]
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, HERE)
+    import oracle_lib as O
+    SH = _load("lrzip_next_amd_sharded", "lrzip-next_amd/sharded.py")
     B = _load("lrzip_next_amd_bindings", "lrzip-next_amd/bindings.py")
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     try:
-        # 5 chunks; a pattern that drives the round-robin victim path so victim_round really moves
-        pat = (b"0123456789abcdefghijklmnopqrstu" * 40 + b"XYZ") * 900
-        data = datagen.long_range(5 * 1048576 + 123, seed=2, base_frac=0.2) + pat
-        ram = (2 << 20) * 3 // 2  # max_chunk = ramsize/3*2 = 2 MiB
-        ctl, chunk = B.plan(len(data), no_compress=True, threads=1, ramsize=ram)
-        ranges = P.chunk_ranges(len(data), chunk)
+        data = _data()
+        ctl, chunk = B.plan(len(data), no_compress=True, threads=1, ramsize=RAM)
+        ranges = _ranges(len(data), chunk)
         calls = []
 
-        def chunk_fn(k, vr_in):
-            off, n = ranges[k]
-            s0, s1, st, crc, vr_out = O.rzip_chunk(data[off:off + n], level=7, chunk_bytes=B.chunk_bytes_for(n),
-                                                   victim_round=vr_in)
-            calls.append((k, vr_in, vr_out))
-            return (s0, s1), vr_out
+        def compress_fn(first, stride, victim_in):
+            got = {}
+            for k in range(first, len(ranges), stride):
+                vin = victim_in[k] if victim_in is not None and victim_in[k] >= 0 else 0
+                vout, img = _chunk_image(B, O, data, ranges, k, vin)
+                calls.append((k, vin, vout))
+                got[k] = (vin, vout, img)
+            return got
 
-        payloads, stats = P.run_sharded(chunk_fn, len(ranges), rank, world, dist)
+        imgs, redone = SH.compress_sharded(compress_fn, len(ranges), rank, world, dist, torch, torch.device("cpu"), max_rounds=len(ranges))
         if rank == 0:
-            got = B.container_store(len(data), [n for _, n in ranges], [p[0] for p in payloads],
-                                    [p[1] for p in payloads], hashlib.md5(data).digest(), no_compress=True,
-                                    threads=1, ramsize=ram)
-            want, fs = O.compress_buffer(data, no_compress=1, threads=1, ramsize=ram)
-            q.put(("result", got == want, len(ranges), fs.n_chunks, stats["reruns"]))
+            got, _ = B.assemble_chunks(imgs, len(data), hashlib.md5(data).digest(), no_compress=True, threads=1, ramsize=RAM)
+            want, fs = O.compress_buffer(data, no_compress=1, threads=1, ramsize=RAM)
+            q.put(("result", got == want, len(ranges), fs.n_chunks, redone))
         q.put(("calls", rank, calls))
     finally:
         dist.destroy_process_group()
@@ -79,26 +107,28 @@ def test_two_ranks_chunk_sharding_and_victim_round_protocol():
         assert p.exitcode == 0
     res = [m for m in msgs if m[0] == "result"][0]
     assert res[1], "sharded .lrz differs from the single-process oracle"
-    assert res[2] == res[3] >= 3
+    assert res[2] == res[3] >= 5
+    assert res[4] >= 1, "the data was meant to break the victim_round prediction at least once"
     calls = {m[1]: m[2] for m in msgs if m[0] == "calls"}
-    # both ranks did work, on disjoint chunk sets
     k0 = {c[0] for c in calls[0]}
     k1 = {c[0] for c in calls[1]}
-    assert k0 and k1 and not (k0 & k1)
+    assert k0 and k1 and not (k0 & k1)  # both ranks did work, on disjoint chunk sets
 
 
-def test_shard_helpers():
-    P = _load("lrz_parallel", "lrzip-next_amd/parallel.py")
-    assert P.shard_chunks(5, 2) == [[0, 2, 4], [1, 3]]
-    assert P.shard_chunks(3, 8)[3:] == [[]] * 5
-    assert P.chunk_ranges(0, 100) == [(0, 0)]
-    assert P.chunk_ranges(250, 100) == [(0, 100), (100, 100), (200, 50)]
-    # single-process path with a forced mis-speculation: chunk 1 leaves victim_round 3
+def test_single_rank_chain_redo():
+    """world 1, no process group: a forced wrong prediction is redone until the chain is consistent."""
+    import torch
+    SH = _load("lrzip_next_amd_sharded", "lrzip-next_amd/sharded.py")
     seen = []
 
-    def fn(k, vr):
-        seen.append((k, vr))
-        return ("p%d@%d" % (k, vr), 3 if k == 1 else vr)
+    def compress_fn(first, stride, victim_in):
+        got = {}
+        for k in range(first, 4, stride):
+            vin = victim_in[k] if victim_in is not None and victim_in[k] >= 0 else 0
+            seen.append((k, vin))
+            got[k] = (vin, 3 if k == 1 else vin, b"p%d@%d" % (k, vin))
+        return got
 
-    payloads, stats = P.run_sharded(fn, 4)
-    assert payloads == ["p0@0", "p1@0", "p2@3", "p3@3"] and stats["reruns"] >= 1
+    imgs, redone = SH.compress_sharded(compress_fn, 4, 0, 1, None, torch, torch.device("cpu"))
+    assert imgs == [b"p0@0", b"p1@0", b"p2@3", b"p3@3"] and redone == 2
+    assert SH.owner(5, 2) == 1
