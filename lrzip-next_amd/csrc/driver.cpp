@@ -228,6 +228,11 @@ struct Pipeline {
 	double mf_busy = 0, d2h_busy = 0, blk_busy = 0, enc_busy = 0, enc_wait = 0;
 	std::vector<std::thread> threads;
 
+	// the waiting block that comes first in the FILE (chunks are scanned side by side and their blocks arrive
+	// interleaved): chunks then complete one after the other and are laid out / written while later ones are
+	// still being encoded, instead of all at the very end
+	static Job *take_first(std::deque<Job *> &q);
+
 	void fail(int e)
 	{
 		std::lock_guard<std::mutex> lk(mu);
@@ -293,8 +298,7 @@ struct Pipeline {
 				cv_enc.wait(lk, [&] { return !enc_queue.empty() || closing || err; });
 				if (err || (enc_queue.empty() && closing))
 					return;
-				j = enc_queue.front();
-				enc_queue.pop_front();
+				j = take_first(enc_queue);
 			}
 			const double te0 = now_s();
 			TRACE_EVENT("enc_start", j);
@@ -433,8 +437,7 @@ struct Pipeline {
 					cleanup();
 					return;
 				}
-				j = gpu_queue.front();
-				gpu_queue.pop_front();
+				j = take_first(gpu_queue);
 				held++; // released in mark_finished
 			}
 			const double tw0 = now_s();
@@ -590,6 +593,19 @@ struct Pipeline {
 		});
 	}
 };
+
+Job *Pipeline::take_first(std::deque<Job *> &q)
+{
+	size_t best = 0;
+	for (size_t i = 1; i < q.size(); i++) {
+		const Job *a = q[i], *b = q[best];
+		if (a->chunk->index < b->chunk->index || (a->chunk->index == b->chunk->index && a->ref.streamno == b->ref.streamno && a->ref.off < b->ref.off))
+			best = i;
+	}
+	Job *j = q[best];
+	q.erase(q.begin() + (long)best);
+	return j;
+}
 
 // What a scanner thread needs to feed blocks to the pipeline while its scan is running.
 struct Feeder {
@@ -1406,21 +1422,27 @@ int Run::run()
 		}
 		t_blocks = now_s();
 		cc->stream1.release();
-		// ordered container assembly of this chunk
+		// ordered container assembly of this chunk, straight into the sink's memory where it offers some
 		std::vector<DoneBlock> blocks;
-		size_t total = 2 + (size_t)cc->chunk_bytes * 7 + 2;
-		for (Job *j : cc->file_order) {
-			total += 1 + 3 * 8 + j->done.payload.size();
+		for (Job *j : cc->file_order)
 			blocks.push_back(std::move(j->done));
+		const size_t total = chunk_image_size(cc->chunk_bytes, blocks);
+		uint8_t *space = (sel && sel->on_chunk) ? nullptr : out.append_space(total);
+		if (space) {
+			write_chunk_raw(space, cc->chunk_bytes, cc->last, cc->size, blocks);
+		} else {
+			std::unique_ptr<uint8_t, void (*)(void *)> img((uint8_t *)malloc(total ? total : 1), free);
+			if (!img)
+				ret = LRZGPU_E_NOMEM;
+			else {
+				write_chunk_raw(img.get(), cc->chunk_bytes, cc->last, cc->size, blocks);
+				if (sel && sel->on_chunk) {
+					if (sel->on_chunk(sel->ctx, cc->index, cc->vr_in, cc->vr_out, img.get(), (int64_t)total) != 0)
+						ret = LRZGPU_E_IO;
+				} else if (out.put(img.get(), total) != 0)
+					ret = LRZGPU_E_IO;
+			}
 		}
-		std::vector<uint8_t> img;
-		img.reserve(total);
-		write_chunk(&img, cc->chunk_bytes, cc->last, cc->size, blocks);
-		if (sel && sel->on_chunk) {
-			if (sel->on_chunk(sel->ctx, cc->index, cc->vr_in, cc->vr_out, img.data(), (int64_t)img.size()) != 0)
-				ret = LRZGPU_E_IO;
-		} else if (out.put(img.data(), img.size()) != 0)
-			ret = LRZGPU_E_IO;
 		cc->jobs.clear();
 		cc->file_order.clear();
 		std::vector<uint8_t>().swap(cc->stream0);
@@ -1494,21 +1516,47 @@ int run_compress(lrzgpu_control *ctl, const CompressSource &in, CompressSink &ou
 }
 
 // ---- sinks ----------------------------------------------------------------------------------------
+MemorySink::~MemorySink() { free(p); }
+uint8_t *MemorySink::append_space(size_t n)
+{
+	if (len + n > cap) {
+		size_t want = cap + cap / 2;
+		if (want < len + n)
+			want = len + n;
+		if (want < ((size_t)1 << 20))
+			want = (size_t)1 << 20;
+		uint8_t *q = (uint8_t *)realloc(p, want);
+		if (!q)
+			return nullptr;
+		p = q;
+		cap = want;
+	}
+	uint8_t *r = p + len;
+	len += n;
+	return r;
+}
 int MemorySink::begin(size_t placeholder)
 {
-	buf.assign(placeholder, 0);
+	len = 0;
+	uint8_t *q = append_space(placeholder);
+	if (!q)
+		return -1;
+	memset(q, 0, placeholder);
 	return 0;
 }
-int MemorySink::put(const uint8_t *p, size_t n)
+int MemorySink::put(const uint8_t *q, size_t n)
 {
-	buf.insert(buf.end(), p, p + n);
+	uint8_t *d = append_space(n);
+	if (!d)
+		return -1;
+	memcpy(d, q, n);
 	return 0;
 }
 int MemorySink::finish(const uint8_t *head, size_t n)
 {
-	if (buf.size() < n)
+	if (len < n)
 		return -1;
-	memcpy(buf.data(), head, n);
+	memcpy(p, head, n);
 	return 0;
 }
 
@@ -1586,11 +1634,8 @@ static int compress_to_malloc(lrzgpu_control *control, const CompressSource &src
 	int r = run_compress(control, src, sink, nullptr);
 	if (r)
 		return r;
-	*out = (uint8_t *)malloc(sink.buf.size() ? sink.buf.size() : 1);
-	if (!*out)
-		return LRZGPU_E_NOMEM;
-	big_copy(*out, sink.buf.data(), sink.buf.size());
-	*out_len = (int64_t)sink.buf.size();
+	*out_len = (int64_t)sink.len;
+	*out = sink.release(); // the image as the sink built it: no copy
 	return 0;
 }
 

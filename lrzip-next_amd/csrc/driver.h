@@ -25,13 +25,31 @@ struct CompressSink {
 	virtual int begin(size_t placeholder) = 0;
 	virtual int put(const uint8_t *p, size_t n) = 0;
 	virtual int finish(const uint8_t *head, size_t n) = 0;
+	// n bytes of appended space to be filled in place by the caller (nullptr: not offered, use put())
+	virtual uint8_t *append_space(size_t n)
+	{
+		(void)n;
+		return nullptr;
+	}
 	virtual ~CompressSink() {}
 };
+// the image in one malloc()ed buffer that is handed to the caller as it is (no copy at the end); grows by
+// realloc(), which moves multi-GiB buffers by remapping pages
 struct MemorySink : CompressSink {
-	std::vector<uint8_t> buf;
+	uint8_t *p = nullptr;
+	size_t len = 0, cap = 0;
 	int begin(size_t placeholder) override;
-	int put(const uint8_t *p, size_t n) override;
+	int put(const uint8_t *q, size_t n) override;
 	int finish(const uint8_t *head, size_t n) override;
+	uint8_t *append_space(size_t n) override;
+	uint8_t *release() // ownership to the caller (free())
+	{
+		uint8_t *r = p;
+		p = nullptr;
+		len = cap = 0;
+		return r;
+	}
+	~MemorySink() override;
 };
 struct FdSink : CompressSink {
 	int fd = -1;

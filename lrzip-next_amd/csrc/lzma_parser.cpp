@@ -19,6 +19,7 @@
 //   * The range coder is branch-free per coded bit (lzma_rangecoder.h).
 #include <immintrin.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -40,7 +41,19 @@ static unsigned long long g_lap[16], g_lap_last;
 #define LAP(k) ((void)0)
 #endif
 
+// The file is built twice (csrc/Makefile): for x86-64-v3 (AVX2) and for x86-64-v4 (AVX-512: the relaxation
+// primitives use mask registers -- compare into a mask, masked stores -- and half the instructions); the public
+// entry point picks at run time what the host CPU has.
+#if defined(__AVX512F__) && defined(__AVX512VL__) && defined(__AVX512BW__) && defined(__AVX512DQ__)
+#define LZMA_ISA_NS isa_v4
+#define LZMA_HAVE_AVX512 1
+#else
+#define LZMA_ISA_NS isa_v3
+#define LZMA_HAVE_AVX512 0
+#endif
+
 namespace lrzgpu {
+namespace LZMA_ISA_NS {
 namespace {
 
 constexpr unsigned kWindow = 1u << 11;       // arrival nodes per search (the format's encoder looks this far)
@@ -212,6 +225,44 @@ template <int FORMAT> struct BlockEncoder {
 		via[node] = better ? e : olde;
 	}
 	// edges (len, code) for every len in [lo, hi] from node `from`: price = base + len_row[len]
+#if LZMA_HAVE_AVX512
+	inline void relax_span(unsigned from, unsigned lo, unsigned hi, uint32_t base, const uint32_t *len_row, uint32_t code)
+	{
+		const __m256i vbase = _mm256_set1_epi32((int)base);
+		const __m256i iota = _mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7);
+		const __m512i code64 = _mm512_set1_epi64((long long)code);
+		for (unsigned l = lo; l <= hi; l += 8) {
+			const unsigned left = hi - l + 1;
+			const __mmask8 live = (__mmask8)(left >= 8 ? 0xFF : (1u << left) - 1);
+			const __m256i cand = _mm256_add_epi32(vbase, _mm256_loadu_si256((const __m256i *)(len_row + l)));
+			uint32_t *cp = cost + from + l;
+			const __mmask8 win = _mm256_mask_cmplt_epu32_mask(live, cand, _mm256_loadu_si256((const __m256i *)cp));
+			_mm256_mask_storeu_epi32(cp, win, cand);
+			const __m256i lens = _mm256_add_epi32(_mm256_set1_epi32((int)l), iota);
+			_mm512_mask_storeu_epi64(via + from + l, win, _mm512_or_si512(_mm512_slli_epi64(_mm512_cvtepu32_epi64(lens), 32), code64));
+		}
+	}
+	// edges (len, code) of one fresh distance for every len in [lo, hi]: price = base + len_row[len] + the distance
+	// price of the length's context, `dist4` = those four prices (lengths 2, 3, 4, 5+)
+	inline void relax_pair(unsigned from, unsigned lo, unsigned hi, uint32_t base, const uint32_t *len_row, __m128i dist4, uint32_t code)
+	{
+		const __m256i iota = _mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7);
+		const __m512i code64 = _mm512_set1_epi64((long long)code);
+		const __m256i vbase = _mm256_add_epi32(_mm256_set1_epi32((int)base), _mm256_castsi128_si256(dist4)); // lanes 0..3 valid
+		const __m256i three = _mm256_set1_epi32((int)kLenToDistStates - 1);
+		for (unsigned l = lo; l <= hi; l += 8) {
+			const unsigned left = hi - l + 1;
+			const __mmask8 live = (__mmask8)(left >= 8 ? 0xFF : (1u << left) - 1);
+			const __m256i lens = _mm256_add_epi32(_mm256_set1_epi32((int)l), iota);
+			const __m256i ctx = _mm256_min_epu32(_mm256_sub_epi32(lens, _mm256_set1_epi32((int)kLenMin)), three);
+			const __m256i cand = _mm256_add_epi32(_mm256_permutevar8x32_epi32(vbase, ctx), _mm256_loadu_si256((const __m256i *)(len_row + l)));
+			uint32_t *cp = cost + from + l;
+			const __mmask8 win = _mm256_mask_cmplt_epu32_mask(live, cand, _mm256_loadu_si256((const __m256i *)cp));
+			_mm256_mask_storeu_epi32(cp, win, cand);
+			_mm512_mask_storeu_epi64(via + from + l, win, _mm512_or_si512(_mm512_slli_epi64(_mm512_cvtepu32_epi64(lens), 32), code64));
+		}
+	}
+#else
 	inline void relax_span(unsigned from, unsigned lo, unsigned hi, uint32_t base, const uint32_t *len_row, uint32_t code)
 	{
 		const __m256i vbase = _mm256_set1_epi32((int)base);
@@ -264,6 +315,7 @@ template <int FORMAT> struct BlockEncoder {
 			_mm256_storeu_si256((__m256i *)(vp + 4), _mm256_blendv_epi8(_mm256_loadu_si256((const __m256i *)(vp + 4)), e_hi, w_hi));
 		}
 	}
+#endif
 
 	// ---- prices of the flag bits in front of a symbol ----------------------------------------------------------------
 	inline uint32_t price_short_rep(unsigned st, unsigned ps) const
@@ -923,7 +975,26 @@ int encode_with(const LzmaParams &prm, const uint8_t *src, size_t n, const Match
 	return LZ_OK;
 }
 
+
 } // namespace
+
+int encode_block(const LzmaParams &prm, const uint8_t *src, size_t n, const MatchLists &ml, uint8_t *dest, size_t dest_cap, size_t *dest_len)
+{
+	if (ml.packed)
+		return encode_with<2>(prm, src, n, ml, dest, dest_cap, dest_len);
+	if (ml.tail_flags)
+		return encode_with<1>(prm, src, n, ml, dest, dest_cap, dest_len);
+	return encode_with<0>(prm, src, n, ml, dest, dest_cap, dest_len);
+}
+
+} // namespace LZMA_ISA_NS
+} // namespace lrzgpu
+
+#if !LZMA_HAVE_AVX512 // the ISA-independent rest lives in the baseline build only
+namespace lrzgpu {
+namespace isa_v4 {
+int encode_block(const LzmaParams &prm, const uint8_t *src, size_t n, const MatchLists &ml, uint8_t *dest, size_t dest_cap, size_t *dest_len);
+}
 
 // hash masks the reference derives for a block (LzFind.c:347-373, 432-442): smallest 2^k - 1 covering
 // min(dictionary, expected size), halved, at most 2^24 - 1 worth of bits for 4 hash bytes, at least 16 bits
@@ -982,11 +1053,10 @@ int lzma_encode_block(const LzmaParams &prm, const uint8_t *src, size_t n, const
 		return LZ_ERROR_PARAM;
 	if (n >= 0xFFFFFFFFu)
 		return LZ_ERROR_PARAM;
-	if (ml.packed)
-		return encode_with<2>(prm, src, n, ml, dest, dest_cap, dest_len);
-	if (ml.tail_flags)
-		return encode_with<1>(prm, src, n, ml, dest, dest_cap, dest_len);
-	return encode_with<0>(prm, src, n, ml, dest, dest_cap, dest_len);
+	static const bool v4 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512bw") &&
+			       __builtin_cpu_supports("avx512dq") && !getenv("LRZGPU_NO_AVX512");
+	return v4 ? isa_v4::encode_block(prm, src, n, ml, dest, dest_cap, dest_len) : isa_v3::encode_block(prm, src, n, ml, dest, dest_cap, dest_len);
 }
 
 } // namespace lrzgpu
+#endif

@@ -201,43 +201,52 @@ void block_order(const std::vector<uint8_t> &stream0, int chunk_bytes, int64_t s
 	blocks->push_back(BlockRef{1, start[1], fill[1]});
 }
 
-static void put_val(std::vector<uint8_t> &o, size_t at, int64_t v, int n)
+static void put_val(uint8_t *o, size_t at, int64_t v, int n)
 {
-	if (o.size() < at + (size_t)n)
-		o.resize(at + (size_t)n);
 	for (int i = 0; i < n; i++)
 		o[at + i] = i < 8 ? (uint8_t)((uint64_t)v >> (8 * i)) : 0;
 }
 
-void write_chunk(std::vector<uint8_t> *outp, int cb, bool eof, int64_t chunk_size, const std::vector<DoneBlock> &blocks)
+size_t chunk_image_size(int cb, const std::vector<DoneBlock> &blocks)
 {
-	std::vector<uint8_t> &o = *outp;
-	size_t pos = o.size();
-	o.push_back((uint8_t)cb);
-	o.push_back(eof ? 1 : 0);
-	pos += 2;
-	put_val(o, pos, chunk_size < kPage ? kPage : chunk_size, cb); // sinfo->size, src/stream.c:1150-1152, 1747
-	pos += (size_t)cb;
-	const size_t initial_pos = pos;
+	size_t total = 2 + (size_t)cb + 2 * (1 + 3 * (size_t)cb);
+	for (const DoneBlock &b : blocks)
+		total += 1 + 3 * (size_t)cb + b.payload.size();
+	return total;
+}
+
+void write_chunk_raw(uint8_t *o, int cb, bool eof, int64_t chunk_size, const std::vector<DoneBlock> &blocks)
+{
+	o[0] = (uint8_t)cb;
+	o[1] = eof ? 1 : 0;
+	put_val(o, 2, chunk_size < kPage ? kPage : chunk_size, cb); // sinfo->size, src/stream.c:1150-1152, 1747
+	uint8_t *base = o + 2 + cb; // initial_pos: every offset in the headers is relative to it
 	int64_t cur_pos = 0, last_head[2];
 	for (int j = 0; j < 2; j++) { // src/stream.c:1755-1769
 		last_head[j] = cur_pos + 1 + cb * 2;
-		put_val(o, initial_pos + (size_t)cur_pos, CTYPE_NONE, 1);
-		put_val(o, initial_pos + (size_t)cur_pos + 1, 0, cb * 3);
+		base[cur_pos] = CTYPE_NONE;
+		put_val(base, (size_t)cur_pos + 1, 0, cb * 3);
 		cur_pos += 1 + cb * 3;
 	}
 	for (const DoneBlock &b : blocks) { // src/stream.c:1772-1821
-		put_val(o, initial_pos + (size_t)last_head[b.streamno], cur_pos, cb);
+		put_val(base, (size_t)last_head[b.streamno], cur_pos, cb);
 		last_head[b.streamno] = cur_pos + 1 + cb * 2;
-		put_val(o, initial_pos + (size_t)cur_pos, b.c_type, 1);
-		put_val(o, initial_pos + (size_t)cur_pos + 1, (int64_t)b.payload.size(), cb);
-		put_val(o, initial_pos + (size_t)cur_pos + 1 + cb, b.s_len, cb);
-		put_val(o, initial_pos + (size_t)cur_pos + 1 + 2 * cb, 0, cb);
+		base[cur_pos] = (uint8_t)b.c_type;
+		put_val(base, (size_t)cur_pos + 1, (int64_t)b.payload.size(), cb);
+		put_val(base, (size_t)cur_pos + 1 + cb, b.s_len, cb);
+		put_val(base, (size_t)cur_pos + 1 + 2 * cb, 0, cb);
 		cur_pos += 1 + cb * 3;
-		o.resize(initial_pos + (size_t)cur_pos);
-		o.insert(o.end(), b.payload.begin(), b.payload.end());
+		if (!b.payload.empty())
+			memcpy(base + cur_pos, b.payload.data(), b.payload.size());
 		cur_pos += (int64_t)b.payload.size();
 	}
+}
+
+void write_chunk(std::vector<uint8_t> *outp, int cb, bool eof, int64_t chunk_size, const std::vector<DoneBlock> &blocks)
+{
+	const size_t at = outp->size();
+	outp->resize(at + chunk_image_size(cb, blocks));
+	write_chunk_raw(outp->data() + at, cb, eof, chunk_size, blocks);
 }
 
 void write_magic(uint8_t magic[21], const Sizing &s, int64_t st_size)

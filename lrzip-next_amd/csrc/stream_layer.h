@@ -65,6 +65,10 @@ struct DoneBlock {
 void write_chunk(std::vector<uint8_t> *out, int chunk_bytes, bool eof, int64_t chunk_size,
 		 const std::vector<DoneBlock> &blocks);
 
+// The same into memory the caller provides (chunk_image_size() bytes).
+size_t chunk_image_size(int chunk_bytes, const std::vector<DoneBlock> &blocks);
+void write_chunk_raw(uint8_t *out, int chunk_bytes, bool eof, int64_t chunk_size, const std::vector<DoneBlock> &blocks);
+
 void write_magic(uint8_t magic[21], const Sizing &s, int64_t st_size); // src/lrzip.c:131-208
 
 } // namespace lrzgpu

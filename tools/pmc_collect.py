@@ -8,7 +8,7 @@ command, reduced to small summaries under gpurun_out/prof/ (copy what is to be j
 PMC passes are separate runs with no tracing besides --kernel-trace (MI355X_MICROARCH.md, HBM section);
 FETCH_SIZE on gfx950 counts 64 B per 128 B request of a wide streaming read, so the summary reports
 fetch x 2 + write for kernels marked streaming and raw fetch + write for the others, and says which."""
-import csv, glob, json, os, re, subprocess, sys, collections
+import csv, glob, json, os, re, shutil, subprocess, sys, collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -24,13 +24,18 @@ def short(name):
     return "rocprim_sort/scan/select" if n.startswith("rocprim") or "rocprim" in name[:40] else n
 
 
+RAW = "/tmp/lrzgpu_prof_raw"  # raw rocprofv3 output is hundreds of MiB: it never goes under gpurun_out/
+
+
 def run(args, tag):
-    d = os.path.join(OUT, tag)
+    d = os.path.join(RAW, tag)
+    shutil.rmtree(d, ignore_errors=True)
     os.makedirs(d, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     p = subprocess.run(["rocprofv3"] + args + ["-d", d, "-o", tag, "--output-format", "csv", "--"] + BENCH, cwd="/tmp", env=env,
                        capture_output=True, text=True)
     line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    print("rocprofv3", tag, "rc", p.returncode, "files", sum(len(f) for _, _, f in os.walk(d)), flush=True)
     if p.returncode != 0 or not line:
         sys.stderr.write(p.stdout[-2000:] + p.stderr[-4000:])
         raise SystemExit("rocprofv3 %s failed" % tag)
@@ -84,7 +89,8 @@ def main():
                        "streaming kernels (gfx950 counts 64 B per 128 B request), raw for the narrow random-access ones (uncalibrated: "
                        "true reads are between 1x and 2x the fetch part)"},
               open(os.path.join(OUT, "pmc_summary.json"), "w"), indent=1)
-    print("wrote", OUT)
+    shutil.rmtree(RAW, ignore_errors=True)
+    print("wrote", OUT, os.listdir(OUT))
 
 
 main()
