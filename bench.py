@@ -233,12 +233,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # LRZGPU_BENCH_BACKEND=gloo: the same N-rank code path on a box with fewer GPUs than ranks (ranks share
+    # devices, hand-off through host tensors) -- a functional check of the sharded step, not a measurement
+    backend = os.environ.get("LRZGPU_BENCH_BACKEND", "nccl")
+    local_dev = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_dev))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    comm_dev = dev if backend == "nccl" else torch.device("cpu")
 
     B = load_bindings()
     SH = load_module("lrzip_next_amd_sharded", "sharded.py")
@@ -278,7 +285,7 @@ def main():
     n_chunks = max(1, (n_bytes + chunk_size - 1) // chunk_size) if chunk_size else 1
 
     def fresh_ctl():
-        return B.make_control(device=local_rank, host_threads=host_threads, gpu_slots=args.gpu_slots,
+        return B.make_control(device=local_dev, host_threads=host_threads, gpu_slots=args.gpu_slots,
                               scan_slots=args.scan_slots, **ctl_kw)
 
     def step_single():
@@ -297,7 +304,7 @@ def main():
                 state["ctl"], state["md5"] = ctl, bytes(ctl.hash_resblock)
             return got
 
-        imgs, _ = SH.compress_sharded(compress_fn, n_chunks, rank, world, dist, torch, dev)
+        imgs, _ = SH.compress_sharded(compress_fn, n_chunks, rank, world, dist, torch, comm_dev)
         if rank != 0:
             return None, state["ctl"]
         return B.assemble_chunks(imgs, n_bytes, state["md5"], ctl=fresh_ctl())
@@ -325,7 +332,7 @@ def main():
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -403,7 +410,7 @@ def main():
                        "output_bytes": len(out), "host_threads": host_threads, "host_cpus_usable": round(usable, 1),
                        "host_cpu_seconds_rank0": round(cpu_s, 1),
                        "parallelism": ("%d chunks scanned concurrently on 1 GPU" % n_chunks) if world == 1 else
-                                      ("chunk k -> GPU k mod %d, chunk images handed to rank 0 over RCCL send/recv" % world)},
+                                      ("chunk k -> GPU k mod %d, chunk images handed to rank 0 over %s send/recv" % (world, "RCCL" if backend == "nccl" else backend))},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if verified is not None:

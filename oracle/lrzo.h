@@ -9,9 +9,11 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library.  The product (lrzip-next_amd/) must never call it.
  *
- * Pinning: see oracle/README.md -- pinned against recorded outputs of the
- * reference binary and against oracle/_ref/liblzma_ref.so
- * (the reference's own LZMA sources compiled unmodified).
+ * Pinning: see oracle/README.md -- the LZMA leg is pinned to oracle/_ref/liblzma_ref.so (the
+ * reference's own LZMA sources compiled unmodified by oracle/Makefile), the lz4 leg to the image's
+ * liblz4 1.9.3.  The rzip / stream / container leg is PARITY UNPINNED: rzip.c / stream.c cannot be
+ * built in this image without stand-in headers; it is anchored only to the two reference outputs
+ * recorded in SURVEY.md Appendix A (rzip level 7, one 64 MiB input).
  */
 #ifndef LRZO_H
 #define LRZO_H
