@@ -9,7 +9,7 @@ bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
 mib = int(sys.argv[1]) if len(sys.argv) > 1 else 5120
 window = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # -w (x100 MiB chunks), 0 = one chunk
 n = mib << 20
-buf = bench.make_workload(n, 3, torch.device("cuda:0"), "alnum")
+buf = bench.make_cfg2(n, 3, torch.device("cuda:0"), "alnum")
 want = hashlib.md5(buf[:n].cpu().numpy()).digest()
 cores = os.cpu_count(); phys = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
 ctl = B.make_control(level=7, threads=cores, processors=cores, ramsize=phys, window=window, host_threads=int(bench.usable_cpus() + 0.5), gpu_slots=8)

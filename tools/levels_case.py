@@ -8,7 +8,7 @@ spec = importlib.util.spec_from_file_location("lrz_bench", os.path.join(os.path.
 bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
 mib = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 n = mib << 20
-buf = bench.make_workload(n, 5, torch.device("cuda:0"), "alnum")
+buf = bench.make_cfg2(n, 5, torch.device("cuda:0"), "alnum")
 want = hashlib.md5(buf[:n].cpu().numpy()).digest()
 cores = os.cpu_count(); phys = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
 for level in (1, 4, 5, 9):
