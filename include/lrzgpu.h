@@ -73,7 +73,12 @@ void lrzgpu_control_init(lrzgpu_control *c); /* initialise_control() defaults, s
  * reference it does not write the 21-byte magic (compress_file does, src/lrzip.c:1464-1560). */
 int lrzgpu_rzip_fd(lrzgpu_control *control, int fd_in, int fd_out);
 
-/* compress_file() for plain files: magic placeholder, rzip_fd, write_magic -- src/lrzip.c:1464. */
+/* compress_file() for plain files: magic placeholder, rzip_fd, write_magic -- src/lrzip.c:1464.
+ * Both fd entry points read a regular fd_in chunk by chunk and write every chunk as soon as its blocks are done
+ * (host memory holds the blocks in flight, not the file).  A pipe as fd_in is spooled to memory first, as the
+ * reference does for STDIN (src/lrzip.c:627-922), and then compressed like a regular file of that size: the
+ * reference's STDIN mode sizes its chunks differently and leaves st_size out of the magic -- NOT reproduced
+ * (valid .lrz, not byte-identical to piped reference output).  A non-seekable fd_out gets the image at the end. */
 int lrzgpu_compress_file(lrzgpu_control *control, int fd_in, int fd_out);
 
 /* Same container, memory to memory. in: host buffer. *out is malloc'd (caller frees with free()). */
