@@ -118,16 +118,49 @@ constexpr int kMaxRec = 128; // u32 entries per position: 2 * (2 hash pairs + cu
 
 // One lane per hash bucket: replay the bucket's positions in order through the BT4 tree walk
 // (LzFindOpt.c GetMatchesSpecN_2 semantics), then the LZ-thread merge (MixMatches3).
+//
+// Tree storage.  The reference keeps son[2 * cyclic position]; a tree only ever links positions of ONE bucket, but
+// those are a dictionary apart in position order, so indexing by position makes every node visit two random
+// sectors (the son pair, and the bytes at that position to compare with) -- ~20 visits per position on text.
+// Here the nodes live in SORTED order: node s belongs to the s-th entry of the hash-sorted position list, so a
+// bucket's nodes are contiguous (most buckets fit a few cache lines, long ones stay L2-resident while their lane
+// walks them), links are sorted indices (+1, 0 = none), and each 32-byte node carries its position and the
+// first 20 bytes at that position: a visit is ONE aligned 32-byte load; the block itself is only read for the
+// current position and for agreements beyond 20 bytes.
+struct __attribute__((aligned(32))) BtNode {
+	uint32_t son0, son1; // the reference's pair[0] / pair[1], as sorted index + 1
+	uint32_t pos;        // 1-based position (pos of the reference)
+	uint32_t w[5];       // bytes 0..19 at the position, little endian
+};
+static_assert(sizeof(BtNode) == 32, "one sector per node");
 struct __attribute__((packed, aligned(1))) PackedU64 {
 	uint64_t v;
 };
+struct __attribute__((packed, aligned(1))) PackedU32 {
+	uint32_t v;
+};
 __device__ __forceinline__ uint64_t load_u64(const uint8_t *p) { return reinterpret_cast<const PackedU64 *>(p)->v; }
+__device__ __forceinline__ uint32_t load_u32(const uint8_t *p) { return reinterpret_cast<const PackedU32 *>(p)->v; }
+constexpr uint32_t kNodeBytes = 20;
+// first index in [0, 20) where two 20-byte prefixes differ (20 if none)
+__device__ __forceinline__ uint32_t prefix_mismatch(const uint32_t a[5], const uint32_t b[5])
+{
+	const uint64_t x0 = ((uint64_t)(a[1] ^ b[1]) << 32) | (a[0] ^ b[0]);
+	if (x0)
+		return (uint32_t)(__ffsll((long long)x0) - 1) >> 3;
+	const uint64_t x1 = ((uint64_t)(a[3] ^ b[3]) << 32) | (a[2] ^ b[2]);
+	if (x1)
+		return 8 + ((uint32_t)(__ffsll((long long)x1) - 1) >> 3);
+	const uint32_t x2 = a[4] ^ b[4];
+	return x2 ? 16 + ((uint32_t)(__ffs((int)x2) - 1) >> 3) : 20;
+}
+__device__ __forceinline__ uint32_t prefix_byte(const uint32_t a[5], uint32_t k) { return (a[k >> 2] >> (8 * (k & 3))) & 0xFF; }
 
 __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint32_t n,
 					   const uint32_t *__restrict__ spos,
 					   const uint32_t *__restrict__ seg_len_sorted, const uint32_t *__restrict__ seg_start_sorted,
 					   const uint32_t *__restrict__ nseg_p,
-					   uint32_t *__restrict__ son,
+					   BtNode *__restrict__ node,
 					   const uint32_t *__restrict__ prev2, const uint32_t *__restrict__ prev3,
 					   uint32_t dict, uint32_t fb, uint32_t cut,
 					   uint8_t *__restrict__ counts, uint64_t *__restrict__ tmp_start,
@@ -150,7 +183,8 @@ __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint
 	uint32_t loc_free = 0;
 
 	for (uint32_t j = 0; j < L; j++) {
-		const uint32_t i = spos[k0 + j];
+		const uint32_t self = k0 + j; // sorted index of this position = its node
+		const uint32_t i = spos[self];
 		const uint32_t pos = i + 1;
 		const uint8_t *cur = src + i;
 		const uint32_t avail = n - i;
@@ -159,49 +193,77 @@ __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint
 		uint32_t rec[kMaxRec];
 		uint32_t nrec = 0;
 		uint32_t delta = pos - prev; // prev == 0 -> delta == pos >= cbs -> empty
+		// the node of this position: its first 20 bytes (zero beyond the end of the block: never compared)
+		BtNode me;
+		me.pos = pos;
+		if (avail >= kNodeBytes) {
+			const uint64_t q0 = load_u64(cur), q1 = load_u64(cur + 8);
+			me.w[0] = (uint32_t)q0;
+			me.w[1] = (uint32_t)(q0 >> 32);
+			me.w[2] = (uint32_t)q1;
+			me.w[3] = (uint32_t)(q1 >> 32);
+			me.w[4] = load_u32(cur + 16);
+		} else {
+#pragma unroll
+			for (int k = 0; k < 5; k++)
+				me.w[k] = 0;
+			for (uint32_t k = 0; k < avail; k++)
+				me.w[k >> 2] |= (uint32_t)cur[k] << (8 * (k & 3));
+		}
+		me.son0 = me.son1 = 0;
 
 		if (delta >= cbs) {
-			son[2 * (size_t)pos] = 0;
-			son[2 * (size_t)pos + 1] = 0;
+			node[self] = me;
 			run_ok = false;
 		} else if (run_ok && delta == 1 && len_limit == fb && cur[fb - 1] == cur[fb - 2]) {
-			son[2 * (size_t)pos] = run_s0;
-			son[2 * (size_t)pos + 1] = run_s1;
+			me.son0 = run_s0;
+			me.son1 = run_s1;
+			node[self] = me;
 			rec[0] = fb;
 			rec[1] = 0;
 			nrec = 2;
 		} else {
 			run_ok = false;
-			uint32_t *ptr0 = son + 2 * (size_t)pos + 1, *ptr1 = son + 2 * (size_t)pos;
+			node[self] = me;
+			// ptr0 / ptr1 of the reference: where the next "greater" / "smaller" subtree root goes.  They
+			// start at this position's own pair, then move into visited nodes.
+			uint32_t *ptr0 = &node[self].son1, *ptr1 = &node[self].son0;
 			uint32_t len0 = 0, len1 = 0, max_len = 3, cv = cut;
+			uint32_t cur_ref = self; // sorted index + 1 of the predecessor in the bucket (j > 0 here)
 			for (;;) {
-				const uint32_t cur_match = pos - delta;
-				uint32_t *pair = son + 2 * (size_t)cur_match;
+				BtNode *np = node + (cur_ref - 1);
+				const BtNode N = *np;
+				delta = pos - N.pos;
+				if (delta >= cbs) {
+					*ptr0 = *ptr1 = 0;
+					break;
+				}
 				const uint8_t *pb = cur - delta;
 				uint32_t len = len0 < len1 ? len0 : len1;
-				const uint32_t pair0 = pair[0], pair1 = pair[1];
-				if (pb[len] == cur[len]) {
-					// eight bytes per step (unaligned loads stay inside [0, len_limit) <= avail)
-					++len;
-					if (len + 8 <= len_limit) {
-						const uint64_t x = load_u64(pb + len) ^ load_u64(cur + len);
-						if (x) {
-							len += (uint32_t)(__ffsll((long long)x) - 1) >> 3;
-							goto cmp_done;
-						}
-						len += 8;
-					}
-					while (len + 32 <= len_limit) { // long agreement: four words per round trip
+				bool full = false;
+				uint32_t b_node, b_cur; // the bytes that decide the branch
+				if (len < kNodeBytes) {
+					const uint32_t m = prefix_mismatch(N.w, me.w);
+					const uint32_t lim = len_limit < kNodeBytes ? len_limit : kNodeBytes;
+					len = m < lim ? m : lim;
+				}
+				if (len >= kNodeBytes && len < len_limit) {
+					// agreement beyond the cached prefix: the block itself (unaligned loads stay inside
+					// [0, len_limit) <= avail)
+					while (len + 32 <= len_limit) {
 						uint64_t x[4];
 #pragma unroll
 						for (int w = 0; w < 4; w++)
 							x[w] = load_u64(pb + len + 8 * w) ^ load_u64(cur + len + 8 * w);
+						bool hit = false;
 #pragma unroll
 						for (int w = 0; w < 4; w++)
-							if (x[w]) {
+							if (!hit && x[w]) {
 								len += 8 * w + ((uint32_t)(__ffsll((long long)x[w]) - 1) >> 3);
-								goto cmp_done;
+								hit = true;
 							}
+						if (hit)
+							goto cmp_done;
 						len += 32;
 					}
 					while (len + 8 <= len_limit) {
@@ -214,45 +276,55 @@ __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint
 					}
 					while (len != len_limit && pb[len] == cur[len])
 						++len;
-				cmp_done:
-					if (max_len < len) {
-						max_len = len;
-						rec[nrec++] = len;
-						rec[nrec++] = delta - 1;
-						if (len == len_limit) {
-							*ptr1 = pair0;
-							*ptr0 = pair1;
-							if (delta == 1 && nrec == 2 && len_limit == fb && pos == prev + 1) {
-								run_ok = true; // first step, full length, distance 1
-								run_s0 = pair0;
-								run_s1 = pair1;
-							}
-							break;
+				}
+			cmp_done:
+				full = len == len_limit;
+				if (max_len < len) {
+					max_len = len;
+					rec[nrec++] = len;
+					rec[nrec++] = delta - 1;
+					if (full) {
+						*ptr1 = N.son0;
+						*ptr0 = N.son1;
+						if (delta == 1 && nrec == 2 && len_limit == fb && pos == prev + 1) {
+							run_ok = true; // first step, full length, distance 1
+							run_s0 = N.son0;
+							run_s1 = N.son1;
 						}
+						break;
 					}
 				}
-				uint32_t next;
-				if (pb[len] < cur[len]) {
-					*ptr1 = cur_match;
-					ptr1 = pair + 1;
-					len1 = len;
-					next = pair1;
+				// (len < len_limit here: a full-length agreement that is not a new maximum cannot happen --
+				// max_len < len_limit until the first one, which breaks)
+				if (len < kNodeBytes) {
+					b_node = prefix_byte(N.w, len);
+					b_cur = prefix_byte(me.w, len);
 				} else {
-					*ptr0 = cur_match;
-					ptr0 = pair;
-					len0 = len;
-					next = pair0;
+					b_node = pb[len];
+					b_cur = cur[len];
 				}
-				if (next >= cur_match) { // corrupt tree (cannot happen): stop like the reference
+				uint32_t next;
+				if (b_node < b_cur) {
+					*ptr1 = cur_ref;
+					ptr1 = &np->son1;
+					len1 = len;
+					next = N.son1;
+				} else {
+					*ptr0 = cur_ref;
+					ptr0 = &np->son0;
+					len0 = len;
+					next = N.son0;
+				}
+				if (next >= cur_ref) { // corrupt tree (cannot happen): stop like the reference
 					*err = 2;
 					*ptr0 = *ptr1 = 0;
 					break;
 				}
-				delta = pos - next;
-				if (--cv == 0 || delta >= cbs) {
+				if (--cv == 0 || next == 0) {
 					*ptr0 = *ptr1 = 0;
 					break;
 				}
+				cur_ref = next;
 			}
 		}
 		prev = pos;
@@ -332,8 +404,14 @@ __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint
 						ok++;
 				for (uint32_t q = 0; q < ok; q++) {
 					const uint32_t iq = i + t + 1 + q;
-					son[2 * (size_t)(iq + 1)] = run_s0;
-					son[2 * (size_t)(iq + 1) + 1] = run_s1;
+					BtNode rn;
+					rn.son0 = run_s0;
+					rn.son1 = run_s1;
+					rn.pos = iq + 1;
+#pragma unroll
+					for (int k = 0; k < 5; k++)
+						rn.w[k] = b * 0x01010101u; // fb >= 20 bytes of the run lie ahead of every one of them
+					node[k0 + j + 1 + t + q] = rn;
 					counts[iq] = 2;
 					if (loc_free < 2) {
 						uint32_t take = (L - j) < 256 ? (L - j) * 4 : 1024;
@@ -544,7 +622,7 @@ int mf_workspace_create(MfWorkspace **out, size_t max_n, double pool_per_pos)
 	HIPCHK(hipMalloc(&w->seg_start_s, n * 4));
 	HIPCHK(hipMalloc(&w->seg_len_s, n * 4));
 	HIPCHK(hipMalloc(&w->flags, n));
-	HIPCHK(hipMalloc(&w->son, (n + 1) * 8));
+	HIPCHK(hipMalloc(&w->son, (n + 2) * 32)); // BtNode per sorted index (k_bt); u32 per position for k_hc5
 	HIPCHK(hipMalloc(&w->counts, n));
 	HIPCHK(hipMalloc(&w->tmp_start, n * 8));
 	HIPCHK(hipMalloc(&w->offsets, n * 8));
@@ -677,7 +755,7 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 								    w->seg_start_s, (int)nseg, 0, 32, s));
 		t_bt = new EventTimer(s);
 		hipLaunchKernelGGL(k_bt, dim3((nseg + 63) / 64), dim3(64), 0, s, d_src, (uint32_t)n, w->spos, w->seg_len_s,
-				   w->seg_start_s, d_nseg, w->son, w->prev2, w->prev3, dict, fb, cut, w->counts, w->tmp_start,
+				   w->seg_start_s, d_nseg, (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, w->counts, w->tmp_start,
 				   w->pool_tmp, d_cursor, w->pool_cap, d_err);
 		t_bt->stop();
 	}

@@ -15,6 +15,14 @@ FULL = os.environ.get("LRZGPU_FULL_CONFIGS") == "1"
 RAM = 80 * 100 << 20
 
 
+def _note(line):
+    """timings of the full-size runs for profiles/ (LRZGPU_TIMES_FILE)"""
+    f = os.environ.get("LRZGPU_TIMES_FILE")
+    if f:
+        with open(f, "a") as o:
+            o.write(line + "\n")
+
+
 def test_cfg1_text_rzip_only_whole_file(B, O):
     """cfg 1: 256 MiB of text, -n (rzip only, blocks stored), -w 3 -p1: one chunk, the whole-file path."""
     data = datagen.text_alnum(256 << 20, seed=11)
@@ -67,9 +75,14 @@ def test_cfg5_full_32gib_random(B):
     buf[n:] = 0
     torch.cuda.synchronize()
     ram = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    import time
+    t0 = time.time()
     out, ctl = B.compress_device(buf.data_ptr(), n, level=7, threads=os.cpu_count(), processors=os.cpu_count(), ramsize=ram, window=328,
                                  copy=False)
-    info = B.file_info_ptr(out) if hasattr(B, "file_info_ptr") else None
+    dt = time.time() - t0
+    _note("cfg5: 32 GiB random (torch.randint on the GPU, seed 5), -L7 -w 328, one chunk, input in HBM: %.1f s = %.1f MB/s, image %d bytes "
+          "(every literal block stored through the lz4 gate), cold pools" % (dt, (n >> 20) / dt, len(out)))
+    assert len(out) > n  # incompressible: stored blocks + headers
     back = B.decompress_buffer(out)
     assert hashlib.md5(back).digest() == bytes(ctl.hash_resblock)
     assert len(back) == n and torch.equal(torch.frombuffer(bytearray(back[:1 << 28]), dtype=torch.uint8), buf[:1 << 28].cpu())
@@ -79,7 +92,12 @@ def test_cfg5_full_32gib_random(B):
 def test_cfg4_full_10gib_zstd_round_trip(B):
     data = datagen.source_tree_tar(40, 256 << 20, seed=7)  # ~10 GiB
     ram = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    import time
+    t0 = time.time()
     got, ctl = B.compress_buffer(data, level=7, threads=os.cpu_count(), processors=os.cpu_count(), ramsize=ram, window=26, zstd=True, zstd_level=15)
+    dt = time.time() - t0
+    _note("cfg4: %d MiB tar of 40 copies of a 256 MiB synthetic source tree, --zstd --zstd-level 15 -w 26 (rzip level 6), host input: "
+          "%.1f s = %.1f MB/s, image %d bytes, cold pools" % (len(data) >> 20, dt, (len(data) >> 20) / dt, len(got)))
     info = B.file_info(got)
     assert info.chunks == -(-len(data) // (26 * 104857600))
     assert B.decompress_buffer(got) == data
