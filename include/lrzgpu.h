@@ -206,6 +206,20 @@ int64_t lrzgpu_lzma_match_lists(const uint8_t *src, size_t n, uint32_t dictSize,
 int64_t lrzgpu_lzma_match_lists_hc5(const uint8_t *src, size_t n, uint32_t dictSize, unsigned fb, unsigned cutValue,
 				    uint8_t *counts, uint32_t *pairs, size_t pairs_cap, int device);
 
+/* The same finder as a stream of blocks in the BT thread's format -- what BtGetMatches() hands to the LZ thread
+ * (src/lzma/C/LzFindMt.c:39-42, 571-729; consumer MatchFinderMt_GetNextBlock_Bt 946-981): d[0] = u32 words used
+ * in the block including these two, d[1] = bytes available at the block's first position, then per position a
+ * record [num, (len, dist-1) x num/2] of the binary-tree matches (length >= 4; the h2/h3 candidates are the LZ
+ * thread's own business, MixMatches3), num = 0 for none, [2, len, dist-1] inside long runs.  A block is filled
+ * while fewer than 65536 - 2 * fb words are used, like the reference's; where exactly the reference cuts its
+ * blocks also depends on its hash-thread phases, which the consumer does not see.  open() runs the finder for the
+ * whole block of data at once (lists are independent of the parser's decisions); next_block() returns the number
+ * of positions it put into btBuf (capacity >= 65536 words), 0 after the last one, < 0 on error. */
+typedef struct lrzgpu_mf lrzgpu_mf;
+int lrzgpu_lzma_mf_open(lrzgpu_mf **mf, const uint8_t *src, size_t n, uint32_t dictSize, unsigned fb, unsigned cutValue, int device);
+int lrzgpu_lzma_mf_next_block(lrzgpu_mf *mf, uint32_t *btBuf, size_t cap_u32);
+void lrzgpu_lzma_mf_close(lrzgpu_mf *mf);
+
 /* The host half alone: parser + range coder fed with match lists (any producer). */
 int lrzgpu_lzma_encode_with_lists(unsigned char *dest, size_t *destLen, const unsigned char *src, size_t srcLen,
 				  const uint8_t *counts, const uint32_t *pairs, int level, unsigned dictSize,

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -48,12 +49,25 @@ int select_device(int device)
 struct ThreadBuffers {
 	DevBuf small, block;
 	int device = -1;
+	hipStream_t s = nullptr; // own non-blocking stream: a null-stream call would wait for every blocking stream of the process
+	~ThreadBuffers()
+	{
+		if (s)
+			(void)hipStreamDestroy(s);
+	}
 	bool ensure(int dev, size_t block_bytes)
 	{
 		if (device != dev) {
 			small.release();
 			block.release();
+			if (s)
+				(void)hipStreamDestroy(s);
+			s = nullptr;
 			device = dev;
+		}
+		if (!s && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+			s = nullptr;
+			return false;
 		}
 		if (!small.p && !small.alloc(256, dev))
 			return false;
@@ -77,8 +91,8 @@ static int lz4_size_dev(const uint8_t *d_src, int src_size, int dst_capacity, in
 		return LRZGPU_E_NOMEM;
 	Lz4Job job{d_src, src_size, dst_capacity, stop_below}, *d_job = (Lz4Job *)tb.small.p;
 	int *d_res = (int *)(tb.small.p + 64), res = -1;
-	if (hipMemcpy(d_job, &job, sizeof(job), hipMemcpyHostToDevice) != hipSuccess || lz4_sizes_device(d_job, 1, d_res, 0) != 0 ||
-	    hipMemcpy(&res, d_res, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+	if (hipMemcpyAsync(d_job, &job, sizeof(job), hipMemcpyHostToDevice, tb.s) != hipSuccess || lz4_sizes_device(d_job, 1, d_res, tb.s) != 0 ||
+	    hipMemcpyAsync(&res, d_res, sizeof(int), hipMemcpyDeviceToHost, tb.s) != hipSuccess || stream_wait(tb.s) != hipSuccess)
 		return LRZGPU_E_HIP;
 	return res;
 }
@@ -112,7 +126,7 @@ extern "C" int lrzgpu_lz4_compresses(const uint8_t *s_buf, int64_t s_len, int th
 	ThreadBuffers &tb = thread_buffers();
 	if (!tb.ensure(device, (size_t)s_len + 16))
 		return LRZGPU_E_NOMEM;
-	if (s_len && hipMemcpy(tb.block.p, s_buf, (size_t)s_len, hipMemcpyHostToDevice) != hipSuccess)
+	if (s_len && (hipMemcpyAsync(tb.block.p, s_buf, (size_t)s_len, hipMemcpyHostToDevice, tb.s) != hipSuccess || stream_wait(tb.s) != hipSuccess))
 		return LRZGPU_E_HIP;
 	return lrzgpu_lz4_compresses_dev(tb.block.p, s_len, threshold, device);
 }
@@ -139,7 +153,7 @@ static int lz4_size_host(const uint8_t *src, int src_size, int dst_capacity, int
 	ThreadBuffers &tb = thread_buffers();
 	if (!tb.ensure(device, (size_t)src_size + 16))
 		return LRZGPU_E_NOMEM;
-	if (src_size && hipMemcpy(tb.block.p, src, (size_t)src_size, hipMemcpyHostToDevice) != hipSuccess)
+	if (src_size && (hipMemcpyAsync(tb.block.p, src, (size_t)src_size, hipMemcpyHostToDevice, tb.s) != hipSuccess || stream_wait(tb.s) != hipSuccess))
 		return LRZGPU_E_HIP;
 	return lz4_size_dev(tb.block.p, src_size, dst_capacity, stop_below);
 }
@@ -190,6 +204,78 @@ extern "C" int64_t lrzgpu_lzma_match_lists_hc5(const uint8_t *src, size_t n, uin
 {
 	return match_lists_impl(src, n, dictSize, fb, cutValue, counts, pairs, pairs_cap, device, true);
 }
+
+// ---- streaming finder in the BT thread's block format (LzFindMt.c:39-42, 571-729) ------------------------------
+struct lrzgpu_mf {
+	std::vector<uint8_t> counts;
+	std::vector<uint32_t> pairs;
+	size_t n = 0, pos = 0, off = 0;
+	unsigned fb = 0;
+};
+
+extern "C" int lrzgpu_lzma_mf_open(lrzgpu_mf **mf, const uint8_t *src, size_t n, uint32_t dictSize, unsigned fb, unsigned cutValue, int device)
+{
+	if (!mf || (!src && n) || fb < 5 || fb > 273)
+		return LRZGPU_E_PARAM;
+	try {
+		std::unique_ptr<lrzgpu_mf> m(new lrzgpu_mf());
+		m->n = n;
+		m->fb = fb;
+		m->counts.resize(n ? n : 1);
+		size_t cap = n * 16 + 4096;
+		for (int attempt = 0;; attempt++) {
+			m->pairs.resize(cap);
+			const int64_t total = match_lists_impl(src, n, dictSize, fb, cutValue, m->counts.data(), m->pairs.data(), cap, device, false);
+			if (total == LRZGPU_E_NOMEM && attempt < 3) {
+				cap *= 4;
+				continue;
+			}
+			if (total < 0)
+				return (int)total;
+			m->pairs.resize((size_t)total);
+			break;
+		}
+		*mf = m.release();
+		return 0;
+	} catch (...) {
+		return LRZGPU_E_NOMEM;
+	}
+}
+
+extern "C" int lrzgpu_lzma_mf_next_block(lrzgpu_mf *m, uint32_t *d, size_t cap_u32)
+{
+	constexpr uint32_t kBlock = 1u << 16; // kMtBtBlockSize
+	if (!m || !d || cap_u32 < kBlock)
+		return LRZGPU_E_PARAM;
+	if (m->pos >= m->n) {
+		d[0] = 2;
+		d[1] = 0;
+		return 0;
+	}
+	const uint32_t limit = kBlock - m->fb * 2; // a record may run past it by one list: that is what the slack is for
+	uint32_t cur = 2;
+	const size_t first = m->pos;
+	const size_t left = m->n - m->pos;
+	d[1] = left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left; // bytes available at the block's first position
+	while (cur < limit && m->pos < m->n) {
+		const unsigned c = m->counts[m->pos];
+		const uint32_t *p = m->pairs.data() + m->off;
+		// the LZ thread's h2/h3 candidates (lengths 2 and 3, MixMatches3) come first in the merged list; the BT
+		// thread's own records start at length 4 (maxLen starts at numHashBytes - 1)
+		unsigned k = 0;
+		while (k < c && p[k] < 4)
+			k += 2;
+		d[cur++] = c - k;
+		for (; k < c; k++)
+			d[cur++] = p[k];
+		m->off += c;
+		m->pos++;
+	}
+	d[0] = cur;
+	return (int)(m->pos - first);
+}
+
+extern "C" void lrzgpu_lzma_mf_close(lrzgpu_mf *m) { delete m; }
 
 extern "C" int lrzgpu_lzma_encode_with_lists_fmt(unsigned char *dest, size_t *destLen, const unsigned char *src, size_t srcLen,
 						 const uint8_t *counts, const uint32_t *pairs, int list_format, int level, unsigned dictSize,

@@ -710,7 +710,7 @@ struct Feeder {
 			if (q != hipSuccess)
 				return LRZGPU_E_HIP;
 			std::vector<int> res(b.jobs.size());
-			if (hipMemcpy(res.data(), b.d_res, res.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+			if (hipMemcpyAsync(res.data(), b.d_res, res.size() * sizeof(int), hipMemcpyDeviceToHost, ms) != hipSuccess || stream_wait(ms) != hipSuccess)
 				return LRZGPU_E_HIP;
 			{
 				ProfileStore &ps = ProfileStore::get();
@@ -1012,9 +1012,33 @@ struct Run {
 		explicit Scanner(Pipeline &p) : F(p) {}
 	};
 
+	// Resolvers of different chunks must not share a CU: each is ONE latency-bound wavefront, and the dispatcher
+	// happily packs eight single-wave workgroups onto the same SIMDs (measured: the first scan segment takes
+	// 653 ms with eight resolvers side by side against 413 ms alone, with nothing else on the GPU).  Scanner k gets
+	// the CUs k, k + 8, k + 16, ... for its scan stream: disjoint sets whatever the mask-bit-to-XCD mapping is (one
+	// XCD each if the bits go round the XCDs), 32 CUs wide so that the K1 kernels on the same stream keep their
+	// bandwidth.  Such streams are blocking streams: nothing in the pipeline uses the null stream.
+	std::atomic<int> scanner_ids{0};
+	hipError_t make_scan_stream(hipStream_t *s)
+	{
+		static const bool off = getenv("LRZGPU_NO_SCAN_CU_MASK") != nullptr;
+		hipDeviceProp_t prop;
+		if (scan_slots > 1 && !off && hipGetDeviceProperties(&prop, P.device) == hipSuccess && prop.multiProcessorCount >= 64) {
+			const int ncu = prop.multiProcessorCount > 256 ? 256 : prop.multiProcessorCount;
+			const int k = scanner_ids.fetch_add(1) % 8;
+			uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+			for (int c = k; c < ncu; c += 8)
+				mask[c >> 5] |= 1u << (c & 31);
+			if (hipExtStreamCreateWithCUMask(s, (uint32_t)((ncu + 31) / 32), mask) == hipSuccess)
+				return hipSuccess;
+			(void)hipGetLastError();
+		}
+		return make_stream(s, true);
+	}
+
 	int scanner_open(Scanner &S)
 	{
-		if (hipSetDevice(P.device) != hipSuccess || make_stream(&S.F.ms, true) != hipSuccess)
+		if (hipSetDevice(P.device) != hipSuccess || make_scan_stream(&S.F.ms) != hipSuccess)
 			return LRZGPU_E_HIP;
 		const int ngate = scan_slots > 1 ? 2 : 6;
 		for (int k = 0; k < ngate; k++) {

@@ -9,8 +9,9 @@
 //     chain of the reference is "previous position with the same hash value".  So the block is
 //     partitioned by hash value with a stable radix sort (key = hash, value = position) and every
 //     hash bucket becomes an independent serial chain -> one GPU lane per bucket, buckets
-//     scheduled longest-first.  son[] is indexed by absolute position (8 B per input byte in HBM)
-//     instead of the reference's cyclic buffer; the `delta >= cyclicBufferSize` cut-off is kept.
+//     scheduled longest-first.  Tree nodes live in SORTED order (a bucket's nodes are contiguous), 32 bytes
+//     each: two links, the position and the first 20 bytes at it -- one aligned load per visit (see BtNode)
+//     -- instead of the reference's cyclic son[] pairs; the `delta >= cyclicBufferSize` cut-off is kept.
 //   * the h2/h3 "most recent position with the same 2/3-byte hash" tables of the LZ thread are
 //     pure functions of the data (updated at every position), obtained with two more sorts.
 //   * records are written into a bump-allocated pool and then gathered into position order so the
@@ -21,8 +22,8 @@
 // Levels 1-4 (algo 0) use hash chains instead (HC5, LzFind.c:880-958, 1431-1502): every chain link
 // is "previous position with the same 5-byte hash" and no position changes what a later one sees,
 // so k_hc5 is one thread per position (see the comment above it).
-// Roofline: HBM-latency/throughput bound pointer chasing, no MFMA.  Algorithmic bytes/position:
-// 1 B read + 4 B head r/w + 8 B son pair + <=48 node visits (8 B pair + compares) -- see DESIGN.md.
+// Roofline: latency bound pointer chasing (the longest bucket's serial walk sets the launch time), no MFMA.
+// Algorithmic bytes/position: 1 B read + 4 B head r/w + 8 B son pair (+ <=48 node visits) -- see DESIGN.md.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 

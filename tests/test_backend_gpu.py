@@ -149,3 +149,41 @@ def test_lz4_early_verdict_equals_oracle(B, O):
                 want = LO.lrzo_lz4_size_stop_below(data, n, n + 1, bound, C.byref(flag))
                 got = LG.lrzgpu_lz4_size_stop_below(data, n, n + 1, bound, 0)
                 assert got == want, (kind, n, bound, got, want, flag.value)
+
+
+def test_mf_stream_in_btbuf_format(B, O):
+    """lrzgpu_lzma_mf_open / next_block / close: the BT thread's block format (LzFindMt.c:571-729).  Re-reading the
+    blocks must give, position by position, the oracle's lists without their h2/h3 front (lengths 2 and 3 belong to
+    the LZ thread), with consistent block headers."""
+    import ctypes as C
+    import numpy as np
+    L = B.lib()
+    L.lrzgpu_lzma_mf_open.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint, C.c_uint, C.c_int]
+    L.lrzgpu_lzma_mf_next_block.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.lrzgpu_lzma_mf_close.argtypes = [C.c_void_p]
+    for data, fb in ((datagen.text_like(700000, seed=61), 64), (datagen.long_range(900000, seed=62, base_frac=0.3), 32), (bytes(200000), 64), (b"abc", 64)):
+        offs, pairs = O.mf_bt4(data, dict_size=1 << 25, fb=fb, cut=16 + fb // 2)
+        h = C.c_void_p()
+        assert L.lrzgpu_lzma_mf_open(C.byref(h), data, len(data), 1 << 25, fb, 16 + fb // 2, 0) == 0
+        buf = np.zeros(1 << 16, dtype=np.uint32)
+        pos = 0
+        while True:
+            got = L.lrzgpu_lzma_mf_next_block(h, buf.ctypes.data, len(buf))
+            assert got >= 0
+            if got == 0:
+                break
+            assert buf[1] == len(data) - pos and 2 < buf[0] <= len(buf)
+            cur = 2
+            for _ in range(got):
+                want = pairs[int(offs[pos]):int(offs[pos + 1])]
+                k = 0
+                while k < len(want) and want[k] < 4:
+                    k += 2
+                want = want[k:]
+                num = int(buf[cur])
+                assert num == len(want) and (buf[cur + 1:cur + 1 + num] == want).all(), pos
+                cur += 1 + num
+                pos += 1
+            assert cur == buf[0] and (cur >= (1 << 16) - 2 * fb or pos == len(data))
+        assert pos == len(data)
+        L.lrzgpu_lzma_mf_close(h)

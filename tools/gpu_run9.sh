@@ -1,0 +1,13 @@
+#!/bin/bash
+mkdir -p gpurun_out/r2i
+exec > gpurun_out/r2i/log.txt 2>&1
+set -x
+( time timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 ) 2>&1
+cd /tmp && export TMPDIR=/tmp
+timeout 2400 python $GRAFT_REPO_ROOT/tools/pmc_collect.py r2 2>&1 | tail -6
+cd $GRAFT_REPO_ROOT
+LRZGPU_TRACE=1 timeout 1200 python bench.py --steps 3 --warmup 1 --verify 2> gpurun_out/r2i/bench16g.err > gpurun_out/r2i/bench16g.json
+cut -c1-200 gpurun_out/r2i/bench16g.json
+grep "lrzgpu driver" gpurun_out/r2i/bench16g.err | cut -c1-500
+bash tools/full_configs.sh
+tail -8 gpurun_out/full/log.txt
