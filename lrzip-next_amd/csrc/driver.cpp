@@ -33,6 +33,7 @@
 // Output bytes depend only on (input, control parameters), never on thread counts or timing here.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <pthread.h>
 #include <sched.h>
 
 #include <cerrno>
@@ -47,6 +48,7 @@
 #include <deque>
 #include <map>
 #include <memory>
+#include <string>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -160,6 +162,7 @@ struct ZstdLib {
 };
 
 struct Job;
+static std::vector<int> encoder_cpu_order();
 
 struct ChunkCtx {
 	int index = 0;
@@ -561,8 +564,19 @@ struct Pipeline {
 	{
 		for (int i = 0; i < n_gpu_workers; i++)
 			threads.emplace_back([this] { guarded([this] { gpu_worker_main(); }); });
-		for (int i = 0; i < n_encoders; i++)
+		std::vector<int> pin;
+		if (const char *e = getenv("LRZGPU_PIN_ENCODERS"))
+			if (*e == '1')
+				pin = encoder_cpu_order();
+		for (int i = 0; i < n_encoders; i++) {
 			threads.emplace_back([this] { guarded([this] { encoder_main(); }); });
+			if (!pin.empty()) {
+				cpu_set_t one;
+				CPU_ZERO(&one);
+				CPU_SET(pin[(size_t)i % pin.size()], &one);
+				(void)pthread_setaffinity_np(threads.back().native_handle(), sizeof(one), &one);
+			}
+		}
 	}
 	void stop()
 	{
@@ -761,6 +775,54 @@ struct Feeder {
 		arena.release();
 	}
 };
+
+// Where to run the k-th encoder thread (LRZGPU_PIN_ENCODERS=1): one core per L3 domain first (on a chiplet CPU an
+// encoder that has a last-level cache to itself keeps the hot part of its 67 MB block and its price tables in
+// it), then second cores of every domain, first SMT thread of a core only, inside the process's affinity mask.
+static std::vector<int> encoder_cpu_order()
+{
+	std::vector<int> order;
+	cpu_set_t allowed;
+	if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0)
+		return order;
+	const int ncpu = (int)sysconf(_SC_NPROCESSORS_CONF);
+	std::map<std::string, std::vector<int>> domains; // L3 shared_cpu_list -> first SMT threads of its cores
+	for (int c = 0; c < ncpu && c < CPU_SETSIZE; c++) {
+		if (!CPU_ISSET(c, &allowed))
+			continue;
+		char path[160], buf[256];
+		snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+		FILE *f = fopen(path, "r");
+		if (!f)
+			continue;
+		int first = -1;
+		if (fscanf(f, "%d", &first) != 1)
+			first = -1;
+		fclose(f);
+		if (first != c)
+			continue; // not the first hardware thread of its core
+		snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", c);
+		f = fopen(path, "r");
+		std::string key = "none";
+		if (f) {
+			if (fgets(buf, sizeof(buf), f))
+				key = buf;
+			fclose(f);
+		}
+		domains[key].push_back(c);
+	}
+	for (size_t r = 0;; r++) {
+		bool any = false;
+		for (auto &d : domains)
+			if (r < d.second.size()) {
+				order.push_back(d.second[r]);
+				any = true;
+			}
+		if (!any)
+			break;
+	}
+	return order;
+}
 
 // CPUs this process may burn: the affinity mask, capped by a cgroup CPU quota (v2 cpu.max, v1 cfs_quota_us)
 static int usable_cpus()

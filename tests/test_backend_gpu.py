@@ -107,12 +107,18 @@ def test_lzma_output_eof(B, O):
     assert rc_g == 7
 
 
+def test_system_liblz4_is_there():
+    """The lz4 leg of the oracle is pinned to the image's liblz4 (the reference links the system library): if it is
+    missing the comparison below would quietly shrink to product-vs-restatement -- say so loudly instead."""
+    C.CDLL("liblz4.so.1")
+
+
 def test_lz4_size_equals_liblz4_and_oracle(B, O):
     try:
         lz4 = C.CDLL("liblz4.so.1")
         lz4.LZ4_compress_default.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int]
     except OSError:
-        lz4 = None
+        lz4 = None  # test_system_liblz4_is_there fails in that case
     for kind in ["text", "random", "few", "phrases", "sparse", "zeros"]:
         for n in SIZES_SMALL + [2000001]:
             data = datagen.KINDS[kind](n, seed=n % 31 + 2)

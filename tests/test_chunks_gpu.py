@@ -24,7 +24,7 @@ def _bench():
 
 def _profile(B, bench):
     p = bench.Profile()
-    B.lib().lrzgpu_profile_get.argtypes = [C.POINTER(bench.Profile)]
+    B.lib().lrzgpu_profile_get.argtypes = None  # other test modules load their own copy of bench.Profile
     B.lib().lrzgpu_profile_get(C.byref(p))
     return p
 

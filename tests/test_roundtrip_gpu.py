@@ -40,7 +40,7 @@ def test_roundtrip_full_size_headline_workload(B):
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     n = 4096 << 20
-    buf = bench.make_workload(n, 1, torch.device("cuda:0"), "alnum")
+    buf = bench.make_cfg2(n, 1, torch.device("cuda:0"), "alnum")
     torch.cuda.synchronize()
     cores = os.cpu_count() or 1
     phys = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
@@ -57,5 +57,32 @@ def test_roundtrip_full_size_headline_workload(B):
     assert out.shape[0] == n
     del out
     back = B.decompress_buffer(img, host_threads=usable)  # library decoder: same checks, own LZMA decoder
+    assert len(back) == n and hashlib.md5(back).digest() == want_md5
+    img.free()
+
+
+def test_roundtrip_full_size_cfg3_headline(B):
+    """BASELINE.json configs[2], the configuration the metric is quoted on: 16 GiB, -L7 -w 21, 8 chunks scanned
+    side by side, input in HBM; chunk layout, per-chunk CRCs and the MD5 checked by the library's decoder."""
+    import torch
+    spec = importlib.util.spec_from_file_location("lrz_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n = 16384 << 20
+    buf = bench.make_cfg3(n, 1 << 30, 1, torch.device("cuda:0"), "alnum")
+    torch.cuda.synchronize()
+    cores = os.cpu_count() or 1
+    phys = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    usable = max(1, int(bench.usable_cpus() + 0.5))
+    ctl = B.make_control(level=7, threads=cores, processors=cores, ramsize=phys, window=21, host_threads=usable, gpu_slots=8)
+    img, ctl = B.compress_device(buf.data_ptr(), n, ctl=ctl, copy=False)
+    want_md5 = hashlib.md5(buf[:n].cpu().numpy()).digest()
+    del buf
+    torch.cuda.empty_cache()
+    assert bytes(ctl.hash_resblock) == want_md5
+    hdr, chunks = lrz_decode.parse(img.view())
+    assert hdr["st_size"] == n and len(chunks) == 8 and [c["eof"] for c in chunks] == [0] * 7 + [1]
+    assert [c["size"] for c in chunks] == [2202009600] * 7 + [1765801984]
+    back = B.decompress_buffer(img, host_threads=usable)  # chunk CRCs + MD5 verified inside
     assert len(back) == n and hashlib.md5(back).digest() == want_md5
     img.free()

@@ -94,6 +94,6 @@ def test_headline_shape(B, O, mib):
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     n = mib << 20
-    data = bench.make_workload(n, 1, torch.device("cuda:0"), "alnum")[:n].cpu().numpy().tobytes()
+    data = bench.make_cfg2(n, 1, torch.device("cuda:0"), "alnum")[:n].cpu().numpy().tobytes()
     st = _check(B, O, data, level=7)
     assert st.match_bytes > (n // 2) - (8 << 20) and st.minimum_tag_mask >= 0x3f
