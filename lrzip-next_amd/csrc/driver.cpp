@@ -46,6 +46,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -218,7 +219,8 @@ struct Pipeline {
 	Sizing sz;
 	int device = 0;
 	int n_gpu_workers = 2, n_encoders = 1;
-	int err = 0;
+	std::atomic<int> err{0};          // first failure; read by every thread of the run
+	std::function<void()> on_fail;    // wakes the run's own waiters (reader, scanners, committer)
 
 	std::mutex mu;
 	std::condition_variable cv_jobs, cv_enc, cv_done;
@@ -238,18 +240,18 @@ struct Pipeline {
 
 	void fail(int e)
 	{
-		std::lock_guard<std::mutex> lk(mu);
-		if (!err)
-			err = e;
-		cv_jobs.notify_all();
-		cv_enc.notify_all();
-		cv_done.notify_all();
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			int none = 0;
+			err.compare_exchange_strong(none, e);
+			cv_jobs.notify_all();
+			cv_enc.notify_all();
+			cv_done.notify_all();
+		}
+		if (on_fail)
+			on_fail();
 	}
-	int error()
-	{
-		std::lock_guard<std::mutex> lk(mu);
-		return err;
-	}
+	int error() const { return err.load(); }
 
 	void mark_finished(Job *j, bool held_lists)
 	{
@@ -906,12 +908,7 @@ struct Run {
 
 	Run(lrzgpu_control *c, const CompressSource &i, CompressSink &o, const ChunkSelect *s) : ctl(c), in(i), out(o), sel(s) {}
 
-	void fail(int e)
-	{
-		P.fail(e);
-		std::lock_guard<std::mutex> lk(mu);
-		cv.notify_all();
-	}
+	void fail(int e) { P.fail(e); } // (P.on_fail wakes this run's waiters)
 
 	// ---- reader: chunk bytes into HBM, in file order ----------------------------------------------
 	void reader_main()
@@ -1430,6 +1427,10 @@ int Run::run()
 
 	t0 = now_s();
 	g_trace_t0 = t0;
+	P.on_fail = [this] {
+		std::lock_guard<std::mutex> lk(mu);
+		cv.notify_all();
+	};
 	P.start();
 	std::vector<std::thread> side;
 	const bool want_md5 = !sel || sel->with_md5;

@@ -119,3 +119,51 @@ int main(void) {
                     B.Control.zstd_level.offset, bench.Profile.resolve_dbg.offset]
     offs = [int(x) for x in lines[2].split()]
     assert offs == [bench.Profile.spec_cancelled_blocks.offset, B.Info.stream_u_len.offset]
+
+
+@pytest.mark.parametrize("level,kind", [(7, "text"), (7, "longrange"), (5, "phrases"), (9, "text"), (7, "zeros"), (6, "sparse")])
+def test_parser_list_formats(B, O, level, kind):
+    """The host parser reads the finder's three list formats (plain couples, tail flag in bit 31, one packed word
+    per pair): each must write the reference LzmaCompress bytes.  Lists and tail flags come from the oracle finder / numpy here (no GPU)."""
+    import numpy as np
+    n = 400000 if kind != "zeros" else 90000
+    data = datagen.KINDS[kind](n, seed=17)
+    fb = 32 if level < 7 else 64
+    dict_size = {5: 1 << 24, 6: 1 << 25, 7: 1 << 25, 9: 1 << 27}[level]
+    offs, pairs = O.mf_bt4(data, dict_size=dict_size, fb=fb, cut=16 + fb // 2)
+    counts = np.diff(offs).astype(np.uint8)
+    rc, want, _ = O.lzma_compress_ref(data, level=level, dict_size=dict_size)
+    assert rc == 0
+    for fmt in (0, 1, 2):
+        if fmt == 2 and dict_size > (1 << 25):
+            continue
+        lists = B.format_lists(data, counts, pairs, fmt)
+        rc, got = B.lzma_encode_with_lists(data, counts, lists, level=level, dict_size=dict_size, fb=fb, list_format=fmt)
+        assert rc == 0 and got == want, fmt  # (the AVX2 build on an AVX-512 host: the fresh-process test below)
+
+
+def test_parser_avx2_build_in_a_fresh_process(B, O):
+    """LRZGPU_NO_AVX512=1 selects the AVX2 build of the parser at first use: run it in its own interpreter."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, os
+sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np
+import datagen, oracle_lib as O
+from conftest import load_bindings
+B = load_bindings()
+data = datagen.text_like(300000, seed=23) + datagen.long_range(200000, seed=24)
+offs, pairs = O.mf_bt4(data, dict_size=1 << 25, fb=64, cut=48)
+counts = np.diff(offs).astype(np.uint8)
+rc, want, _ = O.lzma_compress_ref(data, level=7, dict_size=1 << 25)
+for fmt in (0, 1, 2):
+    rc, got = B.lzma_encode_with_lists(data, counts, B.format_lists(data, counts, pairs, fmt), level=7, dict_size=1 << 25, fb=64, list_format=fmt)
+    assert rc == 0 and got == want, fmt
+print("ok")
+''' % root
+    env = dict(os.environ, LRZGPU_NO_AVX512="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
