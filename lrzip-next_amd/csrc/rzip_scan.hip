@@ -700,8 +700,11 @@ struct LaneSim {
 	i64 w_off[4];
 	uint32_t lo, hi; // inclusive slot interval read
 	// twin successor: simulated on top of the insert its predecessor (same tag, previous lane) is
-	// expected to make: (tag, predecessor position) written to tw_slot, replacing a cleanable entry if tw_dec
-	bool twin, tw_dec;
+	// expected to make: (tag, predecessor position) written to tw_slot, whose occupant was of kind tw_kind
+	// (0 empty, 1 due for cleaning, 2 of lesser bitness: displaced by the predecessor)
+	bool twin;
+	int tw_kind;
+	int k0; // kind of the first stop of this lane's own insert (-1 none, 3 round-robin eviction)
 	uint32_t tw_slot;
 };
 
@@ -743,7 +746,93 @@ fwd_done:
 	return true;
 }
 
-__global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf, Slot *__restrict__ tbl, ScanState *__restrict__ st,
+// ---- look-ahead wave of the resolver ----------------------------------------------------------
+// The automaton's time goes into dependent misses on 64 MiB of randomly addressed table state.  The
+// second wavefront of the workgroup owns no state: it runs ahead of the resolver over the packed
+// candidate list and touches what each candidate is going to need -- the rank / fingerprint lines of
+// its bucket, the slots whose fingerprint agrees, the bytes at the candidate and at those slots'
+// offsets (quick_reject) -- so that the resolver's loads hit the XCD's L2 (~200 cycles) instead of
+// HBM / Infinity Cache (~900).  It reads a table that is some hundred inserts stale and never
+// writes: a pure hint, the result cannot depend on it.
+struct LookAhead {
+	uint32_t cpos; // packed-list position the resolver has consumed up to
+	uint32_t done;
+	u64 min_mask;
+	i64 p_skip;
+};
+constexpr uint32_t LA_MAX = 1536; // candidates ahead of the resolver's queue (~5 lines each: < 1 MiB of L2)
+
+__device__ void resolve_look_ahead(const uint8_t *__restrict__ buf, const Slot *__restrict__ tbl, const uint8_t *__restrict__ rk,
+				   const uint8_t *__restrict__ fpa, u64 hmask, i64 seg_lo, i64 end, const uint32_t *__restrict__ comp_rel,
+				   const u64 *__restrict__ comp_tag, uint32_t ctotal, LookAhead *sh, ScanState *st)
+{
+	const int lane = threadIdx.x & 63;
+	uint32_t hpos = 0;
+	u64 acc = 0;
+	for (;;) {
+		if (__hip_atomic_load(&sh->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+			break;
+		const uint32_t mainpos = __hip_atomic_load(&sh->cpos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		if (hpos < mainpos)
+			hpos = mainpos;
+		if (hpos >= ctotal)
+			break;
+		if (hpos >= mainpos + LA_MAX) {
+			__builtin_amdgcn_s_sleep(64);
+			continue;
+		}
+		const u64 mm = __hip_atomic_load(&sh->min_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		const i64 skip = __hip_atomic_load(&sh->p_skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		u64 T = 0;
+		i64 P = -1;
+		if (hpos + lane < ctotal) {
+			T = comp_tag[hpos + lane];
+			P = seg_lo + (i64)comp_rel[hpos + lane];
+		}
+		hpos += 64;
+		if (P > skip && (T & mm) == mm) {
+			const i64 idx = (i64)(T & hmask);
+			U128u r4[4], f4[4];
+#pragma unroll
+			for (int c = 0; c < 4; c++) {
+				r4[c] = *reinterpret_cast<const U128u *>(rk + idx + 16 * c);
+				f4[c] = *reinterpret_cast<const U128u *>(fpa + idx + 16 * c);
+			}
+			if (P <= end)
+				acc ^= reinterpret_cast<const U64u *>(buf + P)->v;
+			if (P >= 8)
+				acc ^= reinterpret_cast<const U64u *>(buf + P - 8)->v;
+			const u64 fp8 = (u64)fp_byte(T) * B01;
+			u64 E = 0, Q = 0;
+#pragma unroll
+			for (int c = 0; c < 4; c++) {
+				E |= (u64)((flags_to_bits(bytes_lt(r4[c].b, B01)) << 8) | flags_to_bits(bytes_lt(r4[c].a, B01))) << (16 * c);
+				Q |= (u64)((flags_to_bits(bytes_eq(f4[c].b, fp8)) << 8) | flags_to_bits(bytes_eq(f4[c].a, fp8))) << (16 * c);
+			}
+			const int fe = E ? __ffsll((long long)E) - 1 : 63;
+			// the slot line the insert is going to land in (and whose occupant it may displace)
+			acc ^= tbl[idx + fe].t;
+			u64 hm = Q & low_mask(fe);
+			for (int n = 0; hm && n < 4; n++) {
+				const int q = __ffsll((long long)hm) - 1;
+				hm &= hm - 1;
+				const Slot sl = tbl[idx + q];
+				if (sl.t == T && sl.offset < P && sl.offset >= 8) {
+					acc ^= reinterpret_cast<const U64u *>(buf + sl.offset)->v;
+					acc ^= reinterpret_cast<const U64u *>(buf + sl.offset - 8)->v;
+				}
+			}
+		}
+	}
+	// keep the loads observable
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1)
+		acc ^= bcast64(acc, lane ^ d);
+	if (lane == 0 && acc == 0x9E3779B97F4A7C15ull)
+		st->sink = acc;
+}
+
+__global__ void __launch_bounds__(128) k_resolve(const uint8_t *__restrict__ buf, Slot *__restrict__ tbl, ScanState *__restrict__ st,
 						i64 seg_lo, int ntiles, const uint32_t *__restrict__ cand_rel,
 						const u64 *__restrict__ cand_tag, const uint32_t *__restrict__ tile_count,
 						MatchRec *__restrict__ records, int batch_mode, const uint32_t *__restrict__ tile_base,
@@ -759,6 +848,22 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 	__shared__ i64 hit_lds[MAX_HITS * 64];
 	__shared__ uint32_t eqs_lds[MAX_EQS * 64]; // per window ticket: slots of the first equal tags of the insert walk
 	__shared__ uint32_t cf_bits[CF_WORDS]; // all zero between rounds
+	__shared__ LookAhead la;
+
+	if (threadIdx.x == 0) {
+		la.cpos = 0;
+		la.done = 0;
+		la.min_mask = st->min_mask;
+		la.p_skip = st->p_skip;
+	}
+	__syncthreads();
+	if (threadIdx.x >= 64) { // second wavefront: look-ahead only (packed candidate list)
+		const uint32_t total = tile_base[ntiles];
+		if ((batch_mode & 4) && total <= comp_cap)
+			resolve_look_ahead(buf, tbl, rank_bytes, fp_bytes, ((u64)1 << st->hash_bits) - 1, seg_lo, st->end, comp_rel, comp_tag, total,
+					   &la, st);
+		return;
+	}
 
 	Resolver R;
 	R.buf = buf;
@@ -912,6 +1017,11 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 				ring_cnt += __popcll(m);
 				cpos += 64;
 			}
+			if (lane == 0) {
+				__hip_atomic_store(&la.cpos, cpos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				__hip_atomic_store(&la.min_mask, R.min_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				__hip_atomic_store(&la.p_skip, p_skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 			return;
@@ -953,7 +1063,9 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 	int next_ticket = 0;
 	LaneSim L;
 	L.complex_ = L.match = L.ins = L.victim = false;
-	L.twin = L.tw_dec = false;
+	L.twin = false;
+	L.tw_kind = 0;
+	L.k0 = -1;
 	L.tw_slot = 0;
 	L.dec = L.misses = L.nw = 0;
 	L.lo = L.hi = 0;
@@ -975,7 +1087,8 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		L.match = __shfl((int)L.match, src) != 0;
 		L.ins = __shfl((int)L.ins, src) != 0;
 		L.twin = __shfl((int)L.twin, src) != 0;
-		L.tw_dec = __shfl((int)L.tw_dec, src) != 0;
+		L.tw_kind = __shfl(L.tw_kind, src);
+		L.k0 = __shfl(L.k0, src);
 		L.tw_slot = __shfl(L.tw_slot, src);
 		L.dec = __shfl(L.dec, src);
 		L.misses = __shfl(L.misses, src);
@@ -1166,19 +1279,18 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 									if (!seek_pred) {
 										kind = k1;
 										sidx = idx + s1; // a lesser-bitness occupant (kind 2) is fetched after the walk
-										if (tw && k1 == 2)
-											L.complex_ = true;
-										break;
+										break; // (a twin that displaces in its turn: A3 checks its walks against tw_slot)
 									}
 									seek_pred = false;
-									if (k1 == 2 || (k1 == 1 && ((Q >> s1) & 1))) {
-										tw = false; // the predecessor displaces or replaces its own tag: conflict path
+									if (k1 == 1 && ((Q >> s1) & 1)) {
+										tw = false; // the predecessor may replace its own tag: conflict path
 										kind = k1;
 										sidx = idx + s1;
 										break;
 									}
 									L.tw_slot = (uint32_t)(idx + s1);
-									L.tw_dec = k1 == 1;
+									L.tw_kind = k1; // 2: the predecessor takes the slot of a lesser-bitness occupant, which it
+											// re-inserts elsewhere -- a foreign write like any other for phase C
 									tw_hit = true;
 									if (k1 == 0)
 										Em &= ~(1ull << s1); // the twin fills the first empty slot: my lookup walks on
@@ -1215,8 +1327,11 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 				}
 			}
 
-			if (need_sim && kind == 2 && !L.complex_)
-				occ = tbl[sidx]; // just read by the walk: an L2 hit, and only displacing inserts pay for it
+			if (need_sim) {
+				L.k0 = kind;
+				if (kind == 2 && !L.complex_)
+					occ = tbl[sidx]; // just read by the walk: an L2 hit, and only displacing inserts pay for it
+			}
 			lap(9);
 			// ---- A2: are the tag hits real matches (>= MINIMUM_MATCH)? ----
 			{
@@ -1268,6 +1383,7 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 					bool walk = false;
 					i64 j = 0;
 					int r2 = 0;
+					i64 home2 = 0;
 					if (chain) {
 						if (L.nw == 4) {
 							L.complex_ = true;
@@ -1299,6 +1415,7 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 								cur_off = occ.offset;
 								r2 = bitness_rank(cur_t);
 								j = (i64)(cur_t & R.hmask);
+								home2 = j;
 								if ((uint32_t)j < L.lo)
 									L.lo = (uint32_t)j;
 								kind = -1;
@@ -1351,6 +1468,12 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 									if (kind == 2)
 										occ = tbl[sidx];
 									walk = false;
+									// a twin's re-insert walk ran over the table WITHOUT its predecessor's insert:
+									// exact only if it never met that slot
+									if (tw && tw_hit && (i64)L.tw_slot >= home2 && (i64)L.tw_slot <= sidx) {
+										L.complex_ = true;
+										chain = false;
+									}
 								}
 							}
 							j += 64;
@@ -1414,6 +1537,7 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		}
 		lap(10);
 		uint32_t my_vict = 0xFFFFFFFFu;
+		int sub = 0; // diagnostics: what kind of conflict (counted in dbg[8..15] when the cycle laps are off)
 		int why = 0; // 3 complex, 4 match, 5 conflict, 6 no victim, 7 swept range
 		bool stop = false;
 		if (live && L.complex_) {
@@ -1448,11 +1572,12 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		const bool tw_live = live && L.twin && !L.complex_ && !L.match;
 		if (__ballot(tw_live)) {
 			const uint32_t p_slot = __shfl_up(L.w_slot[0], 1);
-			const int p_nw = __shfl_up(L.nw, 1), p_dec = __shfl_up(L.dec, 1);
+			const int p_nw = __shfl_up(L.nw, 1), p_k0 = __shfl_up(L.k0, 1);
 			const int p_ok = __shfl_up((int)(live && L.ins && !L.complex_ && !L.match && !L.victim && !stop), 1);
-			if (tw_live && !stop && !(lane > 0 && p_ok && p_nw == 1 && p_slot == L.tw_slot && (p_dec != 0) == L.tw_dec)) {
+			if (tw_live && !stop && !(lane > 0 && p_ok && p_nw >= 1 && p_slot == L.tw_slot && p_k0 == L.tw_kind)) {
 				stop = true;
 				why = 5; // re-simulated as the first lane of the next round
+				sub = lane == 0 ? 1 : !p_ok ? 2 : p_slot != L.tw_slot ? 3 : 4;
 			}
 		}
 		// conflicts: the EARLIEST lane whose write (insert, displacement or clean) lies inside my
@@ -1553,6 +1678,20 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		const int why_f = f < 64 ? __shfl(why, f) : 0;
 		if (f < wcount && why_f >= 3 && why_f <= 7)
 			dbg[why_f]++;
+		if (!prof && f < wcount && why_f == 5) {
+			// 8: twin arrived as lane 0, 9: twin's predecessor not committable, 10: predecessor wrote elsewhere,
+			// 11: other kind of stop than predicted, 12: write of the SAME tag by the lane before (unpredicted twin),
+			// 13: write of the same tag further back, 14: unrelated write in the interval, 15: suspects over budget
+			const int sub_f = __shfl(sub, f);
+			const int fc = __shfl(first_conf, f);
+			int code = 7 + sub_f;
+			if (sub_f == 0) {
+				const u64 tf = bcast64(w_tag, f);
+				const u64 tc = bcast64(w_tag, fc < 64 ? fc : 0);
+				code = fc >= 64 ? 15 : tf != tc ? 14 : fc == f - 1 ? 12 : 13;
+			}
+			dbg[code]++;
+		}
 		const bool committed = lane < f && live;
 		if (f < 4 && f < wcount) {
 			if (++poor_rounds >= 8) {
@@ -1618,6 +1757,8 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		}
 	}
 
+	if (lane == 0)
+		__hip_atomic_store(&la.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
 	for (int d = 32; d >= 1; d >>= 1)
 		miss_acc += (i64)bcast64((u64)miss_acc, lane ^ d);
@@ -1936,6 +2077,9 @@ int scan_workspace_create(ScanWorkspace **out, int rzip_level, int64_t max_chunk
 		const char *pr = getenv("LRZGPU_RESOLVE_PROF"); // bit 1: per-phase cycle counters in the profile
 		if (pr && *pr == '1')
 			w->batch_mode |= 2;
+		const char *la = getenv("LRZGPU_NO_LOOKAHEAD"); // bit 2: the look-ahead wavefront (a pure cache hint)
+		if (!(la && *la == '1'))
+			w->batch_mode |= 4;
 	}
 	w->seg_cap = (size_t)1 << 28; // up to 256 Mi positions per segment
 	if ((int64_t)w->seg_cap > max_chunk + TILE)
@@ -2031,7 +2175,7 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 				   (u64 *)w->comp_tag);
 		t1.stop();
 		EventTimer t2(s);
-		hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), 0, s, d_chunk, (Slot *)w->table, w->state, (i64)seg_lo, ntiles,
+		hipLaunchKernelGGL(k_resolve, dim3(1), dim3(128), 0, s, d_chunk, (Slot *)w->table, w->state, (i64)seg_lo, ntiles,
 				   (const uint32_t *)w->cand_rel, (const u64 *)w->cand_tag, (const uint32_t *)w->tile_count, w->records,
 				   w->batch_mode, (const uint32_t *)w->tile_base, (const uint32_t *)w->comp_rel, (const u64 *)w->comp_tag,
 				   (uint32_t)w->comp_cap, w->rank_bytes, w->fp_bytes);

@@ -43,5 +43,6 @@ int main(int argc, char **argv)
 	return 0;
 }
 CPP
-g++ -O3 -march=x86-64-v3 -std=c++17 ${PROF:+-DLZMA_PARSER_PROF} -Ilrzip-next_amd/csrc -o /tmp/prof/prof /tmp/prof/main.cpp lrzip-next_amd/csrc/lzma_parser.cpp
+g++ -O3 -march=x86-64-v4 -std=c++17 ${PROF:+-DLZMA_PARSER_PROF} -Ilrzip-next_amd/csrc -c -o /tmp/prof/p4.o lrzip-next_amd/csrc/lzma_parser.cpp
+g++ -O3 -march=x86-64-v3 -std=c++17 ${PROF:+-DLZMA_PARSER_PROF} -Ilrzip-next_amd/csrc -o /tmp/prof/prof /tmp/prof/main.cpp lrzip-next_amd/csrc/lzma_parser.cpp /tmp/prof/p4.o
 for f in ${FORMATS:-0 2}; do /tmp/prof/prof $f; done

@@ -1,0 +1,34 @@
+"""Scan-only timing of the resolver with per-phase shader-clock counters (LRZGPU_RESOLVE_PROF=1).
+usage: python tools/resolve_prof.py [MiB]   -- the bench text, one chunk, rzip level 7"""
+import ctypes as C
+import os
+import sys
+import time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("LRZGPU_RESOLVE_PROF", "1")
+import torch
+import bench
+
+mib = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+B = bench.load_bindings()
+L = B.lib()
+data = bench.text_like_torch(mib << 20, 12345, "cuda:0").cpu().numpy().tobytes()
+L.lrzgpu_profile_reset()
+t0 = time.time()
+s0, s1, st, crc, vr = B.hash_search(data, level=7)
+dt = time.time() - t0
+p = bench.Profile()
+L.lrzgpu_profile_get(C.byref(p))
+d = [int(v) for v in p.resolve_dbg]
+print("scan %d MiB: wall %.3f s, k_resolve %.1f ms in %d launches, lookups %d inserts %d" % (mib, dt, p.resolve_ms, p.resolve_launches, p.resolve_lookups, p.resolve_inserts))
+names = ("batches", "committed", "serial_steps", "stop_complex", "stop_match", "stop_conflict", "stop_novictim", "stop_sweptrange")
+print(dict(zip(names, d[:8])))
+if os.environ.get("LRZGPU_RESOLVE_PROF") != "1":
+    print("conflict kinds:", dict(zip(("twin@lane0", "pred not committable", "pred wrote elsewhere", "pred other kind", "same tag lane-1", "same tag earlier", "unrelated write", "over budget/first_conf=0"), d[8:])))
+    sys.exit(0)
+cyc = d[8:]
+tot = sum(cyc) or 1
+lab = ("8 prefetch-sweep", "9 simulate(A1)+commit-prep", "10 victims", "11 conflicts", "12 apply", "13 tail/shift/serial", "14 A2 verify", "15 A3 displacement")
+for n, c in zip(lab, cyc):
+    print("  %-28s %12d ticks  %5.1f %%  %8.1f per batch" % (n, c, 100.0 * c / tot, c / max(d[0], 1)))
