@@ -703,6 +703,7 @@ struct LaneSim {
 	// expected to make: (tag, predecessor position) written to tw_slot, whose occupant was of kind tw_kind
 	// (0 empty, 1 due for cleaning, 2 of lesser bitness: displaced by the predecessor)
 	bool twin;
+	bool tw_over; // the twin's own tag is due for cleaning (before the first clean of a chunk): it overwrites tw_slot
 	int tw_kind;
 	int k0; // kind of the first stop of this lane's own insert (-1 none, 3 round-robin eviction)
 	uint32_t tw_slot;
@@ -746,93 +747,7 @@ fwd_done:
 	return true;
 }
 
-// ---- look-ahead wave of the resolver ----------------------------------------------------------
-// The automaton's time goes into dependent misses on 64 MiB of randomly addressed table state.  The
-// second wavefront of the workgroup owns no state: it runs ahead of the resolver over the packed
-// candidate list and touches what each candidate is going to need -- the rank / fingerprint lines of
-// its bucket, the slots whose fingerprint agrees, the bytes at the candidate and at those slots'
-// offsets (quick_reject) -- so that the resolver's loads hit the XCD's L2 (~200 cycles) instead of
-// HBM / Infinity Cache (~900).  It reads a table that is some hundred inserts stale and never
-// writes: a pure hint, the result cannot depend on it.
-struct LookAhead {
-	uint32_t cpos; // packed-list position the resolver has consumed up to
-	uint32_t done;
-	u64 min_mask;
-	i64 p_skip;
-};
-constexpr uint32_t LA_MAX = 1536; // candidates ahead of the resolver's queue (~5 lines each: < 1 MiB of L2)
-
-__device__ void resolve_look_ahead(const uint8_t *__restrict__ buf, const Slot *__restrict__ tbl, const uint8_t *__restrict__ rk,
-				   const uint8_t *__restrict__ fpa, u64 hmask, i64 seg_lo, i64 end, const uint32_t *__restrict__ comp_rel,
-				   const u64 *__restrict__ comp_tag, uint32_t ctotal, LookAhead *sh, ScanState *st)
-{
-	const int lane = threadIdx.x & 63;
-	uint32_t hpos = 0;
-	u64 acc = 0;
-	for (;;) {
-		if (__hip_atomic_load(&sh->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
-			break;
-		const uint32_t mainpos = __hip_atomic_load(&sh->cpos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		if (hpos < mainpos)
-			hpos = mainpos;
-		if (hpos >= ctotal)
-			break;
-		if (hpos >= mainpos + LA_MAX) {
-			__builtin_amdgcn_s_sleep(64);
-			continue;
-		}
-		const u64 mm = __hip_atomic_load(&sh->min_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		const i64 skip = __hip_atomic_load(&sh->p_skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		u64 T = 0;
-		i64 P = -1;
-		if (hpos + lane < ctotal) {
-			T = comp_tag[hpos + lane];
-			P = seg_lo + (i64)comp_rel[hpos + lane];
-		}
-		hpos += 64;
-		if (P > skip && (T & mm) == mm) {
-			const i64 idx = (i64)(T & hmask);
-			U128u r4[4], f4[4];
-#pragma unroll
-			for (int c = 0; c < 4; c++) {
-				r4[c] = *reinterpret_cast<const U128u *>(rk + idx + 16 * c);
-				f4[c] = *reinterpret_cast<const U128u *>(fpa + idx + 16 * c);
-			}
-			if (P <= end)
-				acc ^= reinterpret_cast<const U64u *>(buf + P)->v;
-			if (P >= 8)
-				acc ^= reinterpret_cast<const U64u *>(buf + P - 8)->v;
-			const u64 fp8 = (u64)fp_byte(T) * B01;
-			u64 E = 0, Q = 0;
-#pragma unroll
-			for (int c = 0; c < 4; c++) {
-				E |= (u64)((flags_to_bits(bytes_lt(r4[c].b, B01)) << 8) | flags_to_bits(bytes_lt(r4[c].a, B01))) << (16 * c);
-				Q |= (u64)((flags_to_bits(bytes_eq(f4[c].b, fp8)) << 8) | flags_to_bits(bytes_eq(f4[c].a, fp8))) << (16 * c);
-			}
-			const int fe = E ? __ffsll((long long)E) - 1 : 63;
-			// the slot line the insert is going to land in (and whose occupant it may displace)
-			acc ^= tbl[idx + fe].t;
-			u64 hm = Q & low_mask(fe);
-			for (int n = 0; hm && n < 4; n++) {
-				const int q = __ffsll((long long)hm) - 1;
-				hm &= hm - 1;
-				const Slot sl = tbl[idx + q];
-				if (sl.t == T && sl.offset < P && sl.offset >= 8) {
-					acc ^= reinterpret_cast<const U64u *>(buf + sl.offset)->v;
-					acc ^= reinterpret_cast<const U64u *>(buf + sl.offset - 8)->v;
-				}
-			}
-		}
-	}
-	// keep the loads observable
-#pragma unroll
-	for (int d = 32; d >= 1; d >>= 1)
-		acc ^= bcast64(acc, lane ^ d);
-	if (lane == 0 && acc == 0x9E3779B97F4A7C15ull)
-		st->sink = acc;
-}
-
-__global__ void __launch_bounds__(128) k_resolve(const uint8_t *__restrict__ buf, Slot *__restrict__ tbl, ScanState *__restrict__ st,
+__global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf, Slot *__restrict__ tbl, ScanState *__restrict__ st,
 						i64 seg_lo, int ntiles, const uint32_t *__restrict__ cand_rel,
 						const u64 *__restrict__ cand_tag, const uint32_t *__restrict__ tile_count,
 						MatchRec *__restrict__ records, int batch_mode, const uint32_t *__restrict__ tile_base,
@@ -848,22 +763,6 @@ __global__ void __launch_bounds__(128) k_resolve(const uint8_t *__restrict__ buf
 	__shared__ i64 hit_lds[MAX_HITS * 64];
 	__shared__ uint32_t eqs_lds[MAX_EQS * 64]; // per window ticket: slots of the first equal tags of the insert walk
 	__shared__ uint32_t cf_bits[CF_WORDS]; // all zero between rounds
-	__shared__ LookAhead la;
-
-	if (threadIdx.x == 0) {
-		la.cpos = 0;
-		la.done = 0;
-		la.min_mask = st->min_mask;
-		la.p_skip = st->p_skip;
-	}
-	__syncthreads();
-	if (threadIdx.x >= 64) { // second wavefront: look-ahead only (packed candidate list)
-		const uint32_t total = tile_base[ntiles];
-		if ((batch_mode & 4) && total <= comp_cap)
-			resolve_look_ahead(buf, tbl, rank_bytes, fp_bytes, ((u64)1 << st->hash_bits) - 1, seg_lo, st->end, comp_rel, comp_tag, total,
-					   &la, st);
-		return;
-	}
 
 	Resolver R;
 	R.buf = buf;
@@ -1017,11 +916,6 @@ __global__ void __launch_bounds__(128) k_resolve(const uint8_t *__restrict__ buf
 				ring_cnt += __popcll(m);
 				cpos += 64;
 			}
-			if (lane == 0) {
-				__hip_atomic_store(&la.cpos, cpos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				__hip_atomic_store(&la.min_mask, R.min_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				__hip_atomic_store(&la.p_skip, p_skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			}
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 			return;
@@ -1063,7 +957,7 @@ __global__ void __launch_bounds__(128) k_resolve(const uint8_t *__restrict__ buf
 	int next_ticket = 0;
 	LaneSim L;
 	L.complex_ = L.match = L.ins = L.victim = false;
-	L.twin = false;
+	L.twin = L.tw_over = false;
 	L.tw_kind = 0;
 	L.k0 = -1;
 	L.tw_slot = 0;
@@ -1087,6 +981,7 @@ __global__ void __launch_bounds__(128) k_resolve(const uint8_t *__restrict__ buf
 		L.match = __shfl((int)L.match, src) != 0;
 		L.ins = __shfl((int)L.ins, src) != 0;
 		L.twin = __shfl((int)L.twin, src) != 0;
+		L.tw_over = __shfl((int)L.tw_over, src) != 0;
 		L.tw_kind = __shfl(L.tw_kind, src);
 		L.k0 = __shfl(L.k0, src);
 		L.tw_slot = __shfl(L.tw_slot, src);
@@ -1212,9 +1107,8 @@ __global__ void __launch_bounds__(128) k_resolve(const uint8_t *__restrict__ buf
 					L.hi = (uint32_t)idx;
 					if (L.complex_)
 						fin = true;
-					// (a tag that is itself due for cleaning -- only before the first clean of a chunk --
-					// would make the successor overwrite the twin's slot: left to the conflict path)
-					tw = tw && L.ins && !L.complex_ && (T & better) == better;
+					L.tw_over = false;
+					tw = tw && L.ins && !L.complex_;
 					seek_pred = tw;
 				}
 				const u64 thr8 = (u64)thr * B01, fp8 = (u64)fp_byte(T) * B01;
@@ -1294,6 +1188,14 @@ __global__ void __launch_bounds__(128) k_resolve(const uint8_t *__restrict__ buf
 									tw_hit = true;
 									if (k1 == 0)
 										Em &= ~(1ull << s1); // the twin fills the first empty slot: my lookup walks on
+									if ((T & better) != better) {
+										// before the first clean of a chunk a tag may itself be due for cleaning: the
+										// predecessor's entry is then the stop of my own insert, which replaces it
+										kind = 1;
+										sidx = idx + s1;
+										L.tw_over = true;
+										break;
+									}
 									if (neq < MAX_EQS)
 										eqs_lds[neq * 64 + w_ticket] = (uint32_t)(idx + s1);
 									if (++neq >= R.max_chain) {
@@ -1702,9 +1604,11 @@ __global__ void __launch_bounds__(128) k_resolve(const uint8_t *__restrict__ buf
 			poor_rounds = 0;
 
 		// Phase D: apply the committed prefix
+		// (a twin that replaces its predecessor's entry: two lanes, one slot -- the later store is the only one made)
+		const bool nxt_over = __shfl_down((int)(lane < f && live && L.twin && L.tw_over), 1) != 0 && lane < 63;
 		if (committed) {
 			for (int k = 0; k < 4; k++)
-				if (k < L.nw)
+				if (k < L.nw && !(k == 0 && nxt_over))
 					R.store_slot(L.w_slot[k], L.w_t[k], L.w_off[k]);
 			if (cleans)
 				R.store_slot(my_vict, 0, 0);
@@ -1757,8 +1661,6 @@ __global__ void __launch_bounds__(128) k_resolve(const uint8_t *__restrict__ buf
 		}
 	}
 
-	if (lane == 0)
-		__hip_atomic_store(&la.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
 	for (int d = 32; d >= 1; d >>= 1)
 		miss_acc += (i64)bcast64((u64)miss_acc, lane ^ d);
@@ -2077,9 +1979,6 @@ int scan_workspace_create(ScanWorkspace **out, int rzip_level, int64_t max_chunk
 		const char *pr = getenv("LRZGPU_RESOLVE_PROF"); // bit 1: per-phase cycle counters in the profile
 		if (pr && *pr == '1')
 			w->batch_mode |= 2;
-		const char *la = getenv("LRZGPU_NO_LOOKAHEAD"); // bit 2: the look-ahead wavefront (a pure cache hint)
-		if (!(la && *la == '1'))
-			w->batch_mode |= 4;
 	}
 	w->seg_cap = (size_t)1 << 28; // up to 256 Mi positions per segment
 	if ((int64_t)w->seg_cap > max_chunk + TILE)
@@ -2175,7 +2074,7 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 				   (u64 *)w->comp_tag);
 		t1.stop();
 		EventTimer t2(s);
-		hipLaunchKernelGGL(k_resolve, dim3(1), dim3(128), 0, s, d_chunk, (Slot *)w->table, w->state, (i64)seg_lo, ntiles,
+		hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), 0, s, d_chunk, (Slot *)w->table, w->state, (i64)seg_lo, ntiles,
 				   (const uint32_t *)w->cand_rel, (const u64 *)w->cand_tag, (const uint32_t *)w->tile_count, w->records,
 				   w->batch_mode, (const uint32_t *)w->tile_base, (const uint32_t *)w->comp_rel, (const u64 *)w->comp_tag,
 				   (uint32_t)w->comp_cap, w->rank_bytes, w->fp_bytes);
