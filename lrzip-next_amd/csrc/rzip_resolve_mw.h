@@ -1,0 +1,793 @@
+// rzip_resolve_mw.h -- K2 on NW wavefronts (included by rzip_scan.hip, inside namespace lrzgpu).
+//
+// k_resolve is bound by the instruction issue of ONE wavefront: a round costs ~5000 instructions
+// whatever the number of lanes it commits.  Here the same round runs on NW wavefronts of one
+// workgroup (their own SIMDs) over a window of 64 * NW candidates, lane gi = 64 * wave + lane in
+// candidate order:
+//   * phase A (simulations) and phase D (table writes) are per lane: nothing changes;
+//   * phase C's in-order quantities (hash_count prefix, the k-th clean victim, the round-robin
+//     eviction index, the first lane that cannot be committed) are prefix counts over ballots: every
+//     wave publishes its ballots in LDS and adds the popcounts of the waves before it;
+//   * the conflict filter is one LDS table for the workgroup; the exact test of a flagged lane runs
+//     over a compacted list of suspects that every wave checks against its own lanes' writes;
+//   * the automaton itself (masks, hash_count, sweep pointer, lazy match, records) lives in wave 0,
+//     which publishes what the others need at the start of a round and makes every exact serial step;
+//   * the window only moves through LDS when a round stops early; a full commit empties it.
+// Bit-exact by the same argument as k_resolve: a prefix of the window is committed only if every lane
+// in it was simulated against a table that no earlier lane of the round writes into its read interval.
+// Twins are predicted inside a wave (a pair across two waves takes the conflict path).
+#pragma once
+
+constexpr int MW_NONE = 0x7FFFFFFF;
+
+struct MwUniform { // published by wave 0 before the first barrier of a round
+	u64 min_mask, tag_mask;
+	i64 last_match, p_skip, hash_count, clean_ptr, victim_round;
+	int wcount_old, topup, ring_head, mode; // mode: 0 batch round, 1 serial steps (shift), 2 exit
+	uint32_t abs0;                          // absolute queue index of the first entry taken this round
+	int shift;                              // mode 1: lanes consumed by wave 0
+	int nv;
+	i64 scan_end;
+};
+
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restrict__ buf, Slot *__restrict__ tbl, ScanState *__restrict__ st, i64 seg_lo,
+							int ntiles, const uint32_t *__restrict__ cand_rel, const u64 *__restrict__ cand_tag,
+							const uint32_t *__restrict__ tile_count, MatchRec *__restrict__ records, int batch_mode,
+							const uint32_t *__restrict__ tile_base, const uint32_t *__restrict__ comp_rel,
+							const u64 *__restrict__ comp_tag, uint32_t comp_cap, uint8_t *__restrict__ rank_bytes,
+							uint8_t *__restrict__ fp_bytes)
+{
+	constexpr int W = 64 * NW;
+	constexpr int RINGN = 4 * W;
+	constexpr int BUDGET = 16 * NW;
+	__shared__ i64 ring_pos[RINGN];
+	__shared__ u64 ring_tag[RINGN];
+	__shared__ u64 stk_t[64];
+	__shared__ i64 stk_off[64];
+	__shared__ i64 stk_h[64];
+	// phase A scratch of each wave (tag hits of the lookup walk); between rounds the staging area of the window
+	__shared__ __attribute__((aligned(16))) i64 hit_all[NW][MAX_HITS * 64];
+	__shared__ uint32_t eqs_lds[MAX_EQS * W];
+	__shared__ uint32_t cf_bits[CF_WORDS];
+	__shared__ uint32_t vict[W];
+	__shared__ MwUniform U;
+	__shared__ u64 xm_x[NW], xm_ev[NW], xm_clean[NW], xm_flag[NW], xm_bad[NW], xm_twl[NW];
+	__shared__ int x_why[NW];
+	__shared__ i64 x_P[NW];
+	__shared__ u64 x_T[NW];
+	__shared__ int x_cnt[NW][4];
+	__shared__ uint32_t x_lastvict[NW];
+	__shared__ uint32_t fl_k[BUDGET], fl_lo[BUDGET], fl_hi[BUDGET];
+	__shared__ int fl_res[NW][BUDGET];
+	__shared__ i64 x_miss;
+	static_assert(sizeof(i64) * MAX_HITS * 64 * NW >= (size_t)W * 128, "staging area");
+
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, gi = threadIdx.x;
+	const bool master = wave == 0;
+	const u64 lane_bit = 1ull << lane;
+	const u64 lanes_below = lane_bit - 1;
+	i64 *hit_lds = hit_all[wave];
+
+	Resolver R; // wave 0: the automaton; the others: the read-only part their simulations need
+	R.buf = buf;
+	R.tbl = tbl;
+	R.rk = rank_bytes;
+	R.fpa = fp_bytes;
+	R.lane = lane;
+	R.hmask = ((u64)1 << st->hash_bits) - 1;
+	R.end = st->end;
+	R.last_match = st->last_match;
+	R.tag_mask = st->tag_mask;
+	R.min_mask = st->min_mask;
+	R.hash_count = st->hash_count;
+	R.hash_limit = st->hash_limit;
+	R.clean_ptr = st->clean_ptr;
+	R.victim_round = st->victim_round;
+	R.max_chain = st->max_chain_len;
+	R.tag_hits = st->tag_hits;
+	R.tag_misses = st->tag_misses;
+	R.stk_t = stk_t;
+	R.stk_off = stk_off;
+	R.stk_h = stk_h;
+	R.hint_p = st->hint_p;
+	R.hint_op = st->hint_op;
+	R.hint_len = st->hint_len;
+	R.allow_abort = true;
+	R.aborted = false;
+	R.ext_p = R.ext_op = R.ext_done = 0;
+	for (int k = threadIdx.x; k < CF_WORDS; k += W)
+		cf_bits[k] = 0;
+	if (threadIdx.x == 0)
+		x_miss = 0;
+
+	// ---- wave 0 only ----
+	i64 p_skip = st->p_skip;
+	i64 cur_p = st->cur_p, cur_ofs = st->cur_ofs, cur_len = st->cur_len;
+	i64 n_rec = st->n_records;
+	const i64 rec_cap = st->rec_cap;
+	i64 inserts = st->inserts, lookups = st->lookups;
+	int error = st->error;
+	i64 dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	i64 miss_acc = 0; // per lane, every wave
+	const i64 tbl_size = (i64)R.hmask + 1;
+
+	// One exact automaton step at candidate (P, T): see k_resolve.
+	auto serial_step = [&](i64 P, u64 T) {
+		dbg[2]++;
+		bool again;
+		R.allow_abort = true;
+		do {
+			again = false;
+			i64 offset = 0, reverse = 0;
+			lookups++;
+			const i64 hits0 = R.tag_hits, misses0 = R.tag_misses;
+			i64 mlen = R.lookup(T, P, &offset, &reverse);
+			if (R.aborted) {
+				lookups--;
+				dbg[2]--;
+				R.tag_hits = hits0;
+				R.tag_misses = misses0;
+				if (P - 1 > p_skip)
+					p_skip = P - 1;
+				error = 3;
+				return;
+			}
+			R.allow_abort = false;
+			if ((T & R.tag_mask) == R.tag_mask) {
+				inserts++;
+				R.hash_count++;
+				R.insert(T, P);
+				if (R.hash_count > R.hash_limit)
+					R.tag_mask = R.clean_one();
+			}
+			if (mlen > cur_len) {
+				cur_p = P - reverse;
+				cur_len = mlen;
+				cur_ofs = offset;
+			}
+			if ((cur_len >= GREAT_MATCH || P >= cur_p + MINIMUM_MATCH) && cur_len >= MINIMUM_MATCH) {
+				if (n_rec >= rec_cap) {
+					error = 1;
+					return;
+				}
+				if (lane == 0) {
+					MatchRec r;
+					r.p = cur_p;
+					r.ofs = cur_ofs;
+					r.len = cur_len;
+					records[n_rec] = r;
+				}
+				n_rec++;
+				R.last_match = cur_p + cur_len;
+				p_skip = R.last_match;
+				cur_p = R.last_match;
+				cur_len = 0;
+				again = P > p_skip && P <= R.end && (T & R.min_mask) == R.min_mask;
+			}
+		} while (again);
+	};
+
+	// ---- candidate queue (LDS), filled by wave 0 from the K1 lists ----
+	int tile = 0;
+	uint32_t tb0 = 0;
+	int ring_head = 0, ring_cnt = 0;
+	uint32_t popped_abs = 0;
+	const uint32_t ctotal = tile_base[ntiles];
+	const bool packed = ctotal <= comp_cap;
+	uint32_t cpos = 0;
+	i64 skip_seen = p_skip;
+	auto push = [&](bool ok, i64 pos, u64 tag) {
+		const u64 m = __ballot(ok);
+		if (ok) {
+			const int slot = (ring_head + ring_cnt + __popcll(m & lanes_below)) & (RINGN - 1);
+			ring_pos[slot] = pos;
+			ring_tag[slot] = tag;
+		}
+		ring_cnt += __popcll(m);
+	};
+	auto refill_ring = [&]() {
+		if (packed) {
+			if (p_skip != skip_seen) { // a match was emitted: jump over the candidates inside it
+				skip_seen = p_skip;
+				if (p_skip >= seg_lo) {
+					const i64 t = (p_skip + 1 - seg_lo) / TILE;
+					const uint32_t c0 = t < ntiles ? tile_base[t] : ctotal;
+					if (c0 > cpos)
+						cpos = c0;
+				}
+			}
+			// four independent loads per trip: one memory latency for up to 256 candidates
+			while (ring_cnt <= RINGN - 256 && cpos < ctotal) {
+				i64 pos[4];
+				u64 tag[4];
+#pragma unroll
+				for (int j = 0; j < 4; j++) {
+					pos[j] = -1;
+					tag[j] = 0;
+					if (cpos + 64 * j + lane < ctotal) {
+						pos[j] = seg_lo + (i64)comp_rel[cpos + 64 * j + lane];
+						tag[j] = comp_tag[cpos + 64 * j + lane];
+					}
+				}
+#pragma unroll
+				for (int j = 0; j < 4; j++)
+					push(pos[j] > p_skip && (tag[j] & R.min_mask) == R.min_mask, pos[j], tag[j]);
+				cpos += 256;
+			}
+			return;
+		}
+		while (ring_cnt <= RINGN - 64 && tile < ntiles) {
+			const uint32_t cnt = tile_count[tile];
+			if (tb0 >= cnt || seg_lo + (i64)(tile + 1) * TILE - 1 <= p_skip) { // exhausted / inside a match
+				tile++;
+				tb0 = 0;
+				continue;
+			}
+			const size_t base = (size_t)tile * TILE;
+			i64 pos = -1;
+			u64 tag = 0;
+			if (tb0 + lane < cnt) {
+				pos = seg_lo + (i64)cand_rel[base + tb0 + lane];
+				tag = cand_tag[base + tb0 + lane];
+			}
+			push(pos > p_skip && (tag & R.min_mask) == R.min_mask, pos, tag);
+			tb0 += 64;
+		}
+	};
+
+	// ---- the window: one candidate per lane of the workgroup, gi order = candidate order ----
+	int wcount = 0;
+	i64 w_pos = -1;
+	u64 w_tag = 0;
+	bool w_simd = false;
+	int w_ticket = 0; // index into eqs_lds, stable while the entry is in the window
+	LaneSim L;
+	memset(&L, 0, sizeof(L));
+	L.k0 = -1;
+
+	// staging layout (SoA over gi, in the hit scratch)
+	uint8_t *stage = reinterpret_cast<uint8_t *>(&hit_all[0][0]);
+	i64 *sg_pos = reinterpret_cast<i64 *>(stage);
+	u64 *sg_tag = reinterpret_cast<u64 *>(stage + (size_t)W * 8);
+	u64 *sg_wt = reinterpret_cast<u64 *>(stage + (size_t)W * 16);   // [4][W]
+	i64 *sg_woff = reinterpret_cast<i64 *>(stage + (size_t)W * 48); // [4][W]
+	uint32_t *sg_u32 = reinterpret_cast<uint32_t *>(stage + (size_t)W * 80); // [10][W]: flags, packed, lo, hi, tw_slot, ticket, w_slot[4]
+	// drops the first c entries of the window (c and wcount are the same in every wave)
+	auto shift_window = [&](int c) {
+		if (c <= 0)
+			return;
+		if (c >= wcount) {
+			wcount = 0;
+			w_simd = false;
+			return;
+		}
+		if (gi >= c && gi < wcount) {
+			sg_pos[gi] = w_pos;
+			sg_tag[gi] = w_tag;
+			sg_u32[0 * W + gi] = (uint32_t)w_simd | (uint32_t)L.complex_ << 1 | (uint32_t)L.match << 2 | (uint32_t)L.ins << 3 |
+					     (uint32_t)L.victim << 4 | (uint32_t)L.twin << 5 | (uint32_t)L.tw_over << 6 | (uint32_t)(L.dec != 0) << 7;
+			sg_u32[1 * W + gi] = (uint32_t)(L.tw_kind & 3) | (uint32_t)((L.k0 + 1) & 7) << 2 | (uint32_t)(L.nw & 7) << 5 | (uint32_t)(L.misses & 0xFFFF) << 8;
+			sg_u32[2 * W + gi] = L.lo;
+			sg_u32[3 * W + gi] = L.hi;
+			sg_u32[4 * W + gi] = L.tw_slot;
+			sg_u32[5 * W + gi] = (uint32_t)w_ticket;
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				sg_u32[(6 + k) * W + gi] = L.w_slot[k];
+				sg_wt[k * W + gi] = L.w_t[k];
+				sg_woff[k * W + gi] = L.w_off[k];
+			}
+		}
+		__syncthreads();
+		const int src = gi + c;
+		if (src < wcount) {
+			w_pos = sg_pos[src];
+			w_tag = sg_tag[src];
+			const uint32_t fl = sg_u32[0 * W + src], pk = sg_u32[1 * W + src];
+			w_simd = (fl & 1) != 0;
+			L.complex_ = (fl & 2) != 0;
+			L.match = (fl & 4) != 0;
+			L.ins = (fl & 8) != 0;
+			L.victim = (fl & 16) != 0;
+			L.twin = (fl & 32) != 0;
+			L.tw_over = (fl & 64) != 0;
+			L.dec = (fl >> 7) & 1;
+			L.tw_kind = (int)(pk & 3);
+			L.k0 = (int)((pk >> 2) & 7) - 1;
+			L.nw = (int)((pk >> 5) & 7);
+			L.misses = (int)(pk >> 8);
+			L.lo = sg_u32[2 * W + src];
+			L.hi = sg_u32[3 * W + src];
+			L.tw_slot = sg_u32[4 * W + src];
+			w_ticket = (int)sg_u32[5 * W + src];
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				L.w_slot[k] = sg_u32[(6 + k) * W + src];
+				L.w_t[k] = sg_wt[k * W + src];
+				L.w_off[k] = sg_woff[k * W + src];
+			}
+		}
+		wcount -= c;
+		if (gi >= wcount)
+			w_simd = false;
+		// (the staging area is the hit scratch of phase A: the first barrier of the next round lies in between)
+	};
+
+	int poor_rounds = 0, serial_left = 0;
+	__syncthreads();
+	for (;;) {
+		// ---- wave 0: queue, top-up size, state for the others ----
+		if (master) {
+			int mode = 0, k = 0;
+			if (error)
+				mode = 2;
+			else {
+				refill_ring();
+				k = W - wcount;
+				if (k > ring_cnt)
+					k = ring_cnt;
+				if (wcount + k == 0)
+					mode = 2;
+				else if (!(batch_mode & 1) || cur_len > 0 || serial_left > 0)
+					mode = 1;
+			}
+			if (lane == 0) {
+				U.min_mask = R.min_mask;
+				U.tag_mask = R.tag_mask;
+				U.last_match = R.last_match;
+				U.p_skip = p_skip;
+				U.hash_count = R.hash_count;
+				U.clean_ptr = R.clean_ptr;
+				U.victim_round = R.victim_round;
+				U.wcount_old = wcount;
+				U.topup = k;
+				U.ring_head = ring_head;
+				U.abs0 = popped_abs;
+				U.mode = mode;
+			}
+			ring_head = (ring_head + k) & (RINGN - 1);
+			ring_cnt -= k;
+			popped_abs += (uint32_t)k;
+		}
+		__syncthreads(); // #1
+		const int mode = U.mode;
+		if (mode == 2)
+			break;
+		if (!master) {
+			R.min_mask = U.min_mask;
+			R.tag_mask = U.tag_mask;
+			R.last_match = U.last_match;
+			p_skip = U.p_skip;
+			R.hash_count = U.hash_count;
+			R.clean_ptr = U.clean_ptr;
+			R.victim_round = U.victim_round;
+		}
+		{
+			const int k = U.topup, rh = U.ring_head;
+			if (gi >= wcount && gi < wcount + k) {
+				const int slot = (rh + gi - wcount) & (RINGN - 1);
+				w_pos = ring_pos[slot];
+				w_tag = ring_tag[slot];
+				w_simd = false;
+				w_ticket = (int)((U.abs0 + (uint32_t)(gi - wcount)) & (W - 1));
+			}
+			wcount += k;
+		}
+		const bool has = gi < wcount;
+		const bool alive = has && w_pos > p_skip && (w_tag & R.min_mask) == R.min_mask;
+
+		// ---- serial path: pending lazy match, batching disabled, or batching not paying off ----
+		if (mode == 1) {
+			if (master) {
+				const int lim = wcount < 64 ? wcount : 64;
+				int c = 0;
+				while (c < lim && !error && (c == 0 || !(batch_mode & 1) || cur_len > 0 || serial_left > 0)) {
+					if (serial_left > 0)
+						serial_left--;
+					const i64 P = (i64)bcast64((u64)w_pos, c);
+					const u64 T = bcast64(w_tag, c);
+					if (P > p_skip && (T & R.min_mask) == R.min_mask)
+						serial_step(P, T);
+					c++;
+				}
+				if (lane == 0)
+					U.shift = c;
+			}
+			__syncthreads();
+			w_simd = false; // the table changed in ways the simulations did not see
+			shift_window(U.shift);
+			continue;
+		}
+
+		const u64 better = mask_up(R.min_mask);
+		const i64 hc0 = R.hash_count, cp0 = R.clean_ptr, vr0 = R.victim_round;
+		const u64 tm0 = R.tag_mask;
+
+		// ---- phase A/B: simulations, every wave for its own lanes ----
+		{
+			const bool need_sim = alive && !w_simd;
+			if (__ballot(need_sim)) {
+				simulate_lanes(R, tbl, buf, tbl_size, better, lane, alive, need_sim, w_tag, w_pos, w_ticket, hit_lds, eqs_lds, W, L, [](int) {});
+				if (need_sim)
+					w_simd = true;
+			}
+		}
+
+		// ---- phase C: the longest conflict-free prefix of the window ----
+		const bool live = alive;
+		const int x = (live && L.ins && !L.dec && !L.complex_ && !L.match) ? 1 : 0;
+		const bool evicts = live && L.victim && !L.complex_ && !L.match;
+		{
+			const u64 bx = __ballot(x != 0), be = __ballot(evicts);
+			if (lane == 0) {
+				xm_x[wave] = bx;
+				xm_ev[wave] = be;
+			}
+		}
+		__syncthreads(); // #2
+		int x_before = 0, ev_before = 0;
+		u64 evict_all = 0;
+#pragma unroll
+		for (int w2 = 0; w2 < NW; w2++) {
+			if (w2 < wave) {
+				x_before += __popcll(xm_x[w2]);
+				ev_before += __popcll(xm_ev[w2]);
+			}
+			evict_all |= xm_ev[w2];
+		}
+		const int px = x + x_before + __popcll(xm_x[wave] & lanes_below); // inclusive prefix count
+		const i64 hc_before = hc0 + (px - x) < R.hash_limit ? hc0 + (px - x) : R.hash_limit;
+		const bool cleans = x && hc_before + 1 > R.hash_limit;
+		if (evicts) {
+			const uint32_t r = (uint32_t)((vr0 + ev_before + __popcll(xm_ev[wave] & lanes_below)) % (i64)R.max_chain);
+			L.w_slot[0] = eqs_lds[r * W + w_ticket];
+		}
+		(void)evict_all;
+		{
+			const u64 bc = __ballot(cleans);
+			if (lane == 0)
+				xm_clean[wave] = bc;
+		}
+		__syncthreads(); // #3
+		int kth = __popcll(xm_clean[wave] & lanes_below), want = 0, first_clean_gi = MW_NONE;
+#pragma unroll
+		for (int w2 = 0; w2 < NW; w2++) {
+			const u64 m = xm_clean[w2];
+			if (w2 < wave)
+				kth += __popcll(m);
+			want += __popcll(m);
+			if (m && first_clean_gi == MW_NONE)
+				first_clean_gi = 64 * w2 + __ffsll((long long)m) - 1;
+		}
+		// victim list: the next `want` entries the sweep would delete, in sweep order (wave 0)
+		const int vic_nb1 = __popcll(better) + 1;
+		int nv = 0;
+		i64 scan_end = cp0;
+		if (want) {
+			if (master) {
+				i64 ptr = cp0;
+				int rounds = 0;
+				int n = 0;
+				while (n < want && ptr < tbl_size && rounds < 512 * NW) {
+					// two 64-slot pieces per trip: independent loads
+					const i64 q = ptr + lane, q2 = q + 64;
+					uint32_t rv = 0, rv2 = 0;
+					if (q < tbl_size)
+						rv = R.rk[q];
+					if (q2 < tbl_size)
+						rv2 = R.rk[q2];
+					const bool cand = rv != 0 && rv < (uint32_t)vic_nb1; // occupied and due for cleaning
+					const u64 m = __ballot(cand);
+					const int r = n + __popcll(m & lanes_below);
+					if (cand && r < W)
+						vict[r] = (uint32_t)q;
+					n += __popcll(m);
+					ptr += 64;
+					rounds++;
+					if (n < want && ptr < tbl_size) {
+						const bool cand2 = rv2 != 0 && rv2 < (uint32_t)vic_nb1;
+						const u64 m2 = __ballot(cand2);
+						const int r2 = n + __popcll(m2 & lanes_below);
+						if (cand2 && r2 < W)
+							vict[r2] = (uint32_t)q2;
+						n += __popcll(m2);
+						ptr += 64;
+						rounds++;
+					}
+				}
+				if (lane == 0) {
+					U.nv = n > W ? W : n;
+					U.scan_end = ptr < tbl_size ? ptr : tbl_size;
+				}
+			}
+			__syncthreads(); // #4 (want is the same in every wave)
+			nv = U.nv;
+			scan_end = U.scan_end;
+		}
+		uint32_t my_vict = 0xFFFFFFFFu;
+		int why = 0; // 3 complex, 4 match, 5 conflict, 6 no victim, 7 swept range
+		bool stop = false;
+		if (live && L.complex_) {
+			stop = true;
+			why = 3;
+		} else if (live && L.match) {
+			stop = true;
+			why = 4;
+		}
+		if (cleans) {
+			if (kth < nv)
+				my_vict = vict[kth];
+			else if (!stop) {
+				stop = true; // sweep wrap / no victim in reach: serial path
+				why = 6;
+			}
+		}
+		// the first clean of a chunk switches tag_mask from the initial mask to `better`
+		if (tm0 != better && first_clean_gi != MW_NONE && live && !stop && gi > first_clean_gi) {
+			stop = true;
+			why = 3;
+		}
+		// an insert landing inside the swept range could change what the sweep meets
+		if (live && want && !stop)
+			for (int k = 0; k < 4; k++)
+				if (k < L.nw && (i64)L.w_slot[k] >= cp0 && (i64)L.w_slot[k] < scan_end) {
+					stop = true;
+					why = 7;
+				}
+		// twin successors: did the predecessor's simulation make exactly the predicted insert?
+		const bool tw_live = live && L.twin && !L.complex_ && !L.match;
+		if (__ballot(tw_live)) {
+			const uint32_t p_slot = __shfl_up(L.w_slot[0], 1);
+			const int p_nw = __shfl_up(L.nw, 1), p_k0 = __shfl_up(L.k0, 1);
+			const int p_ok = __shfl_up((int)(live && L.ins && !L.complex_ && !L.match && !L.victim && !stop), 1);
+			if (tw_live && !stop && !(lane > 0 && p_ok && p_nw >= 1 && p_slot == L.tw_slot && p_k0 == L.tw_kind)) {
+				stop = true;
+				why = 5;
+			}
+		}
+		// conflicts: the EARLIEST lane whose write lies inside my read interval (see k_resolve)
+		int gsh = __popcll(R.min_mask) - 2;
+		gsh = gsh < 3 ? 3 : gsh > 16 ? 16 : gsh;
+		uint32_t wr[5], wh[5];
+#pragma unroll
+		for (int k = 0; k < 5; k++) {
+			wr[k] = 0xFFFFFFFFu;
+			if (live) {
+				if (k < 4) {
+					if (k < L.nw)
+						wr[k] = L.w_slot[k];
+				} else
+					wr[k] = my_vict;
+			}
+			wh[k] = wr[k] != 0xFFFFFFFFu ? ((wr[k] >> gsh) * 2654435761u) >> (32 - CF_BITS) : 0xFFFFFFFFu;
+		}
+#pragma unroll
+		for (int k = 0; k < 5; k++)
+			if (wh[k] != 0xFFFFFFFFu)
+				__hip_atomic_fetch_add(&cf_bits[wh[k] >> 1], 1u << (16 * (wh[k] & 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		__syncthreads(); // #5
+		const bool reads = live && !L.complex_ && !L.match;
+		const uint32_t r_lo = L.lo & ~7u, r_hi = L.hi | 7u;
+		const uint32_t tw_h = tw_live && !stop ? ((L.tw_slot >> gsh) * 2654435761u) >> (32 - CF_BITS) : 0xFFFFFFFFu;
+		bool flagged = false;
+		if (reads) {
+			const uint32_t g1 = L.hi >> gsh;
+			uint32_t expect = tw_h != 0xFFFFFFFFu ? 1u : 0u;
+			for (uint32_t g = L.lo >> gsh; g <= g1; g++) {
+				const uint32_t hb = (g * 2654435761u) >> (32 - CF_BITS);
+				uint32_t cnt = (cf_bits[hb >> 1] >> (16 * (hb & 1))) & 0xFFFFu;
+#pragma unroll
+				for (int q = 0; q < 5; q++)
+					cnt -= wh[q] == hb;
+				if (expect && hb == tw_h && cnt) {
+					cnt--;
+					expect = 0;
+				}
+				if (cnt)
+					flagged = true;
+			}
+		}
+		{
+			const u64 bf = __ballot(flagged), bt = __ballot(tw_live);
+			if (lane == 0) {
+				xm_flag[wave] = bf;
+				xm_twl[wave] = bt;
+			}
+		}
+		__syncthreads(); // #6
+		int first_conf = MW_NONE; // window index of the earliest conflicting writer
+		int fidx = __popcll(xm_flag[wave] & lanes_below), nflag = 0;
+#pragma unroll
+		for (int w2 = 0; w2 < NW; w2++) {
+			const int c = __popcll(xm_flag[w2]);
+			if (w2 < wave)
+				fidx += c;
+			nflag += c;
+		}
+		if (nflag) { // (the same in every wave)
+			if (flagged) {
+				if (fidx < BUDGET) {
+					fl_k[fidx] = (uint32_t)gi;
+					fl_lo[fidx] = r_lo;
+					fl_hi[fidx] = r_hi;
+				} else
+					first_conf = 0; // too many suspects: call the rest conflicting (they re-simulate)
+			}
+			__syncthreads(); // #7
+			const int ne = nflag < BUDGET ? nflag : BUDGET;
+			for (int e = 0; e < ne; e++) {
+				const int k = (int)fl_k[e];
+				const uint32_t klo = fl_lo[e], khi = fl_hi[e];
+				const bool k_twin = (xm_twl[k >> 6] >> (k & 63)) & 1; // its predecessor's insert is part of its simulation
+				bool hit = false;
+#pragma unroll
+				for (int q = 0; q < 5; q++)
+					hit |= wr[q] != 0xFFFFFFFFu && wr[q] >= klo && wr[q] <= khi && !(q == 0 && k_twin && gi == k - 1);
+				const u64 hm = __ballot(hit && gi < k);
+				if (lane == 0)
+					fl_res[wave][e] = hm ? 64 * wave + __ffsll((long long)hm) - 1 : MW_NONE;
+			}
+			__syncthreads(); // #8
+			if (flagged && fidx < BUDGET) {
+#pragma unroll
+				for (int w2 = 0; w2 < NW; w2++) {
+					const int r = fl_res[w2][fidx];
+					if (r < first_conf)
+						first_conf = r;
+				}
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < 5; k++)
+			if (wh[k] != 0xFFFFFFFFu)
+				cf_bits[wh[k] >> 1] = 0;
+		const bool conflict = first_conf != MW_NONE;
+		if (!stop && conflict)
+			why = 5;
+		{
+			const u64 bb = __ballot(live && (stop || conflict));
+			if (lane == 0)
+				xm_bad[wave] = bb;
+			if (bb && lane == __ffsll((long long)bb) - 1) {
+				x_why[wave] = why;
+				x_P[wave] = w_pos;
+				x_T[wave] = w_tag;
+			}
+		}
+		__syncthreads(); // #9
+		int f = wcount, why_f = 0;
+		i64 P_f = 0;
+		u64 T_f = 0;
+#pragma unroll
+		for (int w2 = NW - 1; w2 >= 0; w2--) {
+			const u64 m = xm_bad[w2];
+			if (m) {
+				f = 64 * w2 + __ffsll((long long)m) - 1;
+				why_f = x_why[w2];
+				P_f = x_P[w2];
+				T_f = x_T[w2];
+			}
+		}
+		if (f > wcount)
+			f = wcount;
+		const bool committed = gi < f && live;
+
+		// ---- phase D: apply the committed prefix ----
+		const bool nxt_over = __shfl_down((int)(gi < f && live && L.twin && L.tw_over), 1) != 0 && lane < 63;
+		if (committed) {
+			for (int k = 0; k < 4; k++)
+				if (k < L.nw && !(k == 0 && nxt_over))
+					R.store_slot(L.w_slot[k], L.w_t[k], L.w_off[k]);
+			if (cleans)
+				R.store_slot(my_vict, 0, 0);
+			miss_acc += L.misses;
+		}
+		{
+			const u64 cm = __ballot(committed);
+			const int n_ins = __popcll(__ballot(committed && L.ins));
+			const int n_x = __popcll(__ballot(committed && x));
+			const int n_ev = __popcll(__ballot(committed && evicts));
+			const u64 cc = __ballot(committed && cleans);
+			const uint32_t lastv = cc ? (uint32_t)__shfl((int)my_vict, 63 - __clzll((long long)cc)) : 0xFFFFFFFFu;
+			if (lane == 0) {
+				x_cnt[wave][0] = __popcll(cm);
+				x_cnt[wave][1] = n_ins;
+				x_cnt[wave][2] = n_x;
+				x_cnt[wave][3] = n_ev;
+				x_lastvict[wave] = lastv;
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__syncthreads(); // #10: every table write of the round is visible to every wave
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		uint32_t last_clean = 0xFFFFFFFFu;
+#pragma unroll
+		for (int w2 = 0; w2 < NW; w2++)
+			if (x_lastvict[w2] != 0xFFFFFFFFu)
+				last_clean = x_lastvict[w2];
+		const bool first_clean = last_clean != 0xFFFFFFFFu && tm0 != better;
+		if (master) {
+			int n_commit = 0, n_ins = 0, n_x = 0, n_ev = 0;
+#pragma unroll
+			for (int w2 = 0; w2 < NW; w2++) {
+				n_commit += x_cnt[w2][0];
+				n_ins += x_cnt[w2][1];
+				n_x += x_cnt[w2][2];
+				n_ev += x_cnt[w2][3];
+			}
+			lookups += n_commit;
+			dbg[0]++;
+			dbg[1] += n_commit;
+			if (f < wcount && why_f >= 3 && why_f <= 7)
+				dbg[why_f]++;
+			inserts += n_ins;
+			const i64 hc = R.hash_count + n_x;
+			R.hash_count = hc < R.hash_limit ? hc : R.hash_limit;
+			R.victim_round = (R.victim_round + n_ev) % (i64)R.max_chain;
+			if (last_clean != 0xFFFFFFFFu) {
+				R.clean_ptr = (i64)last_clean;
+				R.tag_mask = better; // clean_one_from_hash() returns better_than_min
+			}
+			if (f < 4 && f < wcount) {
+				if (++poor_rounds >= 8) {
+					poor_rounds = 0;
+					serial_left = 256;
+				}
+			} else
+				poor_rounds = 0;
+		}
+		if (first_clean)
+			w_simd = false; // the insert mask changed: every kept simulation is stale
+		// simulations that read something a committed lane has just written are stale
+		if (first_conf < f)
+			w_simd = false;
+		if (f < wcount) {
+			if (why_f == 5) {
+				// conflict only: lane f re-simulates against the updated table next round
+				if (gi == f)
+					w_simd = false;
+				shift_window(f);
+			} else {
+				// complex / real match / sweep wrap / swept range: exact serial step (progress)
+				if (master)
+					serial_step(P_f, T_f);
+				w_simd = false;
+				shift_window(f + 1);
+			}
+		} else {
+			shift_window(f);
+		}
+	}
+
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1)
+		miss_acc += (i64)bcast64((u64)miss_acc, lane ^ d);
+	if (lane == 0)
+		atomicAdd((unsigned long long *)&x_miss, (unsigned long long)miss_acc);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		R.tag_misses += x_miss;
+		st->p_skip = p_skip;
+		st->last_match = R.last_match;
+		st->cur_p = cur_p;
+		st->cur_ofs = cur_ofs;
+		st->cur_len = cur_len;
+		st->tag_mask = R.tag_mask;
+		st->min_mask = R.min_mask;
+		st->hash_count = R.hash_count;
+		st->clean_ptr = R.clean_ptr;
+		st->victim_round = R.victim_round;
+		st->n_records = n_rec;
+		st->error = error;
+		st->ext_p = R.ext_p;
+		st->ext_op = R.ext_op;
+		st->ext_done = R.ext_done;
+		st->inserts = inserts;
+		st->lookups = lookups;
+		st->tag_hits = R.tag_hits;
+		st->tag_misses = R.tag_misses;
+		for (int k = 0; k < 8; k++)
+			st->dbg[k] += dbg[k];
+	}
+}

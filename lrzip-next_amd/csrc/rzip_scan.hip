@@ -747,6 +747,338 @@ fwd_done:
 	return true;
 }
 
+// Phase A/B of a resolver round, for the lanes with need_sim: one automaton step each, simulated
+// against the table as it stands.  Wave-convergent, so that every dependent HBM round trip is shared
+// by all simulating lanes: (A1) lookup walk in 64-slot steps over the side arrays, (A2) verification of
+// tag hits, (A3) the displacement chain of the insert, one level at a time.  Called by the resolver
+// wave for its window and by the pre-simulation waves for the candidates still in the queue; R is
+// only read (masks, table pointers, last_match); hit_lds / eqs_lds are the caller's own LDS scratch.
+template <class LapF>
+__device__ __forceinline__ void simulate_lanes(const Resolver &R, const Slot *__restrict__ tbl, const uint8_t *__restrict__ buf, const i64 tbl_size,
+					       const u64 better, const int lane, const bool alive, const bool need_sim, const u64 w_tag,
+					       const i64 w_pos, const int w_ticket, i64 *hit_lds, uint32_t *eqs_lds, const int eqs_stride, LaneSim &L, LapF lap)
+{
+		const u64 T = w_tag;
+		const i64 P = w_pos;
+		const int my_rank = bitness_rank(T);
+		const int nb1 = __popcll(better) + 1; // rank bytes below this are due for cleaning
+		int kind = -1; // insert stop: 0 empty, 1 due for cleaning, 2 lesser bitness
+		i64 sidx = 0;
+		Slot occ;
+		occ.offset = 0;
+		occ.t = 0;
+		int nhit = 0; // tag hits met by the lookup walk, offsets parked in LDS (hit_lds)
+		// Twins: consecutive candidates with the SAME tag (the byte leaving the 31-byte window
+		// equals the byte entering it) share a bucket, so the second always conflicts with the
+		// first one's insert.  The second of such a pair is simulated on top of the insert it can
+		// predict for the first from its own walk (same tag, same table); phase C checks the prediction.
+		// (cross-lane reads are made by all lanes: no short-circuit evaluation around them)
+		const int prev_alive = __shfl_up((int)alive, 1);
+		const u64 prev_tag = bcast64(w_tag, (lane + 63) & 63);
+		const i64 P_prev = (i64)bcast64((u64)w_pos, (lane + 63) & 63);
+		const bool tw_cand = lane > 0 && alive && prev_alive != 0 && prev_tag == w_tag;
+		const int prev_cand = __shfl_up((int)tw_cand, 1);
+		bool tw = tw_cand && prev_cand == 0; // a third twin in a row takes the conflict path
+		bool seek_pred = false, tw_hit = false;
+		// ---- A1: lookup walk to the first empty slot, 16 slots per step, branch-free masks ----
+		{
+			i64 idx = (i64)(T & R.hmask);
+			uint32_t neq = 0;
+			int steps = 0;
+			bool fin = !need_sim;
+			const int thr = my_rank > nb1 ? my_rank : nb1; // ranks below this stop my insert
+			if (need_sim) {
+				L.complex_ = nb1 >= 63 || my_rank >= 63; // rank bytes saturate at 63
+				L.match = false;
+				L.victim = false;
+				L.dec = 0;
+				L.misses = 0;
+				L.nw = 0;
+				L.ins = (T & R.tag_mask) == R.tag_mask;
+				L.lo = (uint32_t)idx;
+				L.hi = (uint32_t)idx;
+				if (L.complex_)
+					fin = true;
+				L.tw_over = false;
+				tw = tw && L.ins && !L.complex_;
+				seek_pred = tw;
+			}
+			const u64 thr8 = (u64)thr * B01, fp8 = (u64)fp_byte(T) * B01;
+			while (__ballot(!fin)) {
+				if (!fin) {
+					// 64 slots per step: their rank and fingerprint bytes (the arrays are padded)
+					U128u r4[4], f4[4];
+#pragma unroll
+					for (int c = 0; c < 4; c++) {
+						r4[c] = *reinterpret_cast<const U128u *>(R.rk + idx + 16 * c);
+						f4[c] = *reinterpret_cast<const U128u *>(R.fpa + idx + 16 * c);
+					}
+					u64 E = 0, S = 0, Q = 0; // bit q: slot idx + q is empty / stops my insert / may hold my tag
+#pragma unroll
+					for (int c = 0; c < 4; c++) {
+						E |= (u64)((flags_to_bits(bytes_lt(r4[c].b, B01)) << 8) | flags_to_bits(bytes_lt(r4[c].a, B01))) << (16 * c);
+						S |= (u64)((flags_to_bits(bytes_lt(r4[c].b, thr8)) << 8) | flags_to_bits(bytes_lt(r4[c].a, thr8))) << (16 * c);
+						Q |= (u64)((flags_to_bits(bytes_eq(f4[c].b, fp8)) << 8) | flags_to_bits(bytes_eq(f4[c].a, fp8))) << (16 * c);
+						// loose masks mean short clusters: stop evaluating once every walking lane has met
+						// its first empty slot (two for a twin, whose lookup may walk on past the first)
+						if (c < 3 && !__ballot(tw ? __popcll(E) < 2 : E == 0))
+							break;
+					}
+					steps += 64;
+					if (idx + 64 > tbl_size || steps > A1_MAX_STEPS) {
+						L.complex_ = true;
+						L.hi = (uint32_t)(idx + 63 < tbl_size - 1 ? idx + 63 : tbl_size - 1);
+						fin = true;
+					} else {
+						u64 Em = E;
+						if (kind < 0 && L.ins) {
+							int from = 0;
+							for (int pass = 0; pass < 2; pass++) {
+								const u64 Sm = S & ~low_mask(from);
+								const int s1 = Sm ? __ffsll((long long)Sm) - 1 : 64;
+								u64 eqb = Q & low_mask(s1) & ~low_mask(from);
+								while (eqb) {
+									const int q = __ffsll((long long)eqb) - 1;
+									eqb &= eqb - 1;
+									if (tbl[idx + q].t != T)
+										continue; // fingerprint false positive
+									if (neq < MAX_EQS)
+										eqs_lds[neq * eqs_stride + w_ticket] = (uint32_t)(idx + q);
+									if (++neq >= R.max_chain) {
+										if (R.max_chain <= MAX_EQS && !tw)
+											kind = 3; // round-robin eviction among these equal tags
+										else if (seek_pred) {
+											tw = seek_pred = false;
+											if (R.max_chain <= MAX_EQS)
+												kind = 3;
+											else
+												L.complex_ = true;
+										} else
+											L.complex_ = true;
+										eqb = 0;
+									}
+								}
+								if (kind >= 0 || L.complex_ || s1 >= 64)
+									break;
+								const int rv = R.rk[idx + s1]; // just loaded: which kind of stop is it?
+								const int k1 = rv == 0 ? 0 : rv < nb1 ? 1 : 2;
+								if (!seek_pred) {
+									kind = k1;
+									sidx = idx + s1; // a lesser-bitness occupant (kind 2) is fetched after the walk
+									break; // (a twin that displaces in its turn: A3 checks its walks against tw_slot)
+								}
+								seek_pred = false;
+								if (k1 == 1 && ((Q >> s1) & 1)) {
+									tw = false; // the predecessor may replace its own tag: conflict path
+									kind = k1;
+									sidx = idx + s1;
+									break;
+								}
+								L.tw_slot = (uint32_t)(idx + s1);
+								L.tw_kind = k1; // 2: the predecessor takes the slot of a lesser-bitness occupant, which it
+										// re-inserts elsewhere -- a foreign write like any other for phase C
+								tw_hit = true;
+								if (k1 == 0)
+									Em &= ~(1ull << s1); // the twin fills the first empty slot: my lookup walks on
+								if ((T & better) != better) {
+									// before the first clean of a chunk a tag may itself be due for cleaning: the
+									// predecessor's entry is then the stop of my own insert, which replaces it
+									kind = 1;
+									sidx = idx + s1;
+									L.tw_over = true;
+									break;
+								}
+								if (neq < MAX_EQS)
+									eqs_lds[neq * eqs_stride + w_ticket] = (uint32_t)(idx + s1);
+								if (++neq >= R.max_chain) {
+									L.complex_ = true;
+									break;
+								}
+								from = s1 + 1;
+							}
+						}
+						const int fe = Em ? __ffsll((long long)Em) - 1 : 64; // first empty slot of the step
+						u64 hm = Q & low_mask(fe);
+						while (hm) {
+							const int q = __ffsll((long long)hm) - 1;
+							hm &= hm - 1;
+							const Slot sl = tbl[idx + q];
+							if (sl.t != T)
+								continue; // fingerprint false positive
+							if (nhit < MAX_HITS)
+								hit_lds[nhit * 64 + lane] = sl.offset;
+							else
+								L.complex_ = true;
+							nhit++;
+						}
+						if (fe < 64) {
+							L.hi = (uint32_t)(idx + fe);
+							fin = true;
+						}
+					}
+					idx += 64;
+				}
+			}
+		}
+
+		if (need_sim) {
+			L.k0 = kind;
+			if (kind == 2 && !L.complex_)
+				occ = tbl[sidx]; // just read by the walk: an L2 hit, and only displacing inserts pay for it
+		}
+		lap(9);
+		// ---- A2: are the tag hits real matches (>= MINIMUM_MATCH)? ----
+		{
+			// all hits are pre-tested with independent loads (one round trip), the rare
+			// undecided ones get the exact compare
+			uint32_t und = 0; // bit k: hit k needs the exact compare
+			if (need_sim && !L.complex_) {
+				for (int k = 0; k < nhit && k < MAX_HITS; k++)
+					if (!quick_reject(buf, P, hit_lds[k * 64 + lane], R.end, R.last_match))
+						und |= 1u << k;
+				L.misses = (nhit < MAX_HITS ? nhit : MAX_HITS) - __popc(und);
+			}
+			while (__ballot(und != 0)) {
+				if (und) {
+					const int k = __ffs((int)und) - 1;
+					und &= und - 1;
+					if (!L.match) {
+						if (lane_verify(buf, P, hit_lds[k * 64 + lane], R.end, R.last_match))
+							L.match = true;
+						else
+							L.misses++;
+					}
+				}
+			}
+		}
+		// the twin's entry is one more tag hit for its successor: a real match (a run of one byte
+		// value) goes to the serial path
+		if (__ballot(need_sim && tw && tw_hit && !L.complex_)) {
+			if (need_sim && tw && tw_hit && !L.complex_) {
+				// (independent 8-byte looks first: text twins differ right there)
+				if (!quick_reject(buf, P, P_prev, R.end, R.last_match) && lane_verify(buf, P, P_prev, R.end, R.last_match))
+					L.complex_ = true;
+				else
+					L.misses++;
+			}
+		}
+		if (need_sim)
+			L.twin = tw && tw_hit && !L.complex_;
+		lap(14);
+		// ---- A3: displacement chain of the insert, level by level ----
+		{
+			u64 cur_t = T;
+			i64 cur_off = P;
+			bool chain = need_sim && L.ins && !L.complex_ && !L.match;
+#pragma unroll 1
+			for (int level = 0; level < 5; level++) {
+				if (!__ballot(chain))
+					break;
+				bool walk = false;
+				i64 j = 0;
+				int r2 = 0;
+				i64 home2 = 0;
+				if (chain) {
+					if (L.nw == 4) {
+						L.complex_ = true;
+						chain = false;
+					} else {
+#pragma unroll
+						for (int k = 0; k < 4; k++)
+							if (k == L.nw) {
+								L.w_slot[k] = (uint32_t)sidx;
+								L.w_t[k] = cur_t;
+								L.w_off[k] = cur_off;
+							}
+						L.nw++;
+						if ((uint32_t)sidx > L.hi)
+							L.hi = (uint32_t)sidx;
+						if (kind == 0) {
+							chain = false;
+						} else if (kind == 1) {
+							L.dec = 1;
+							chain = false;
+						} else if (kind == 3) {
+							// victim slot depends on victim_round at commit time (set in phase C)
+							L.victim = true;
+							L.dec = 1;
+							chain = false;
+						} else {
+							// lesser-bitness occupant: it is re-inserted from its own bucket
+							cur_t = occ.t;
+							cur_off = occ.offset;
+							r2 = bitness_rank(cur_t);
+							j = (i64)(cur_t & R.hmask);
+							home2 = j;
+							if ((uint32_t)j < L.lo)
+								L.lo = (uint32_t)j;
+							kind = -1;
+							walk = true;
+						}
+					}
+				}
+				uint32_t neq2 = 0;
+				int st2 = 0;
+				const int thr2 = r2 > nb1 ? r2 : nb1;
+				const u64 thr2_8 = (u64)thr2 * B01, fp2_8 = (u64)fp_byte(cur_t) * B01;
+				while (__ballot(walk)) {
+					if (walk) {
+						U128u r4[4], f4[4];
+#pragma unroll
+						for (int c = 0; c < 4; c++) {
+							r4[c] = *reinterpret_cast<const U128u *>(R.rk + j + 16 * c);
+							f4[c] = *reinterpret_cast<const U128u *>(R.fpa + j + 16 * c);
+						}
+						u64 S2 = 0, Q2 = 0;
+#pragma unroll
+						for (int c = 0; c < 4; c++) {
+							S2 |= (u64)((flags_to_bits(bytes_lt(r4[c].b, thr2_8)) << 8) | flags_to_bits(bytes_lt(r4[c].a, thr2_8))) << (16 * c);
+							Q2 |= (u64)((flags_to_bits(bytes_eq(f4[c].b, fp2_8)) << 8) | flags_to_bits(bytes_eq(f4[c].a, fp2_8))) << (16 * c);
+							if (c < 3 && !__ballot(S2 == 0))
+								break; // every walking lane has its stop
+						}
+						st2 += 64;
+						if (j + 64 > tbl_size || st2 > A1_MAX_STEPS || r2 >= 63) {
+							L.complex_ = true;
+							chain = false;
+							walk = false;
+						} else {
+							const int s2 = S2 ? __ffsll((long long)S2) - 1 : 64;
+							u64 eq2 = Q2 & low_mask(s2);
+							while (eq2) {
+								const int q = __ffsll((long long)eq2) - 1;
+								eq2 &= eq2 - 1;
+								if (tbl[j + q].t == cur_t && ++neq2 >= R.max_chain) {
+									L.complex_ = true;
+									chain = false;
+									walk = false;
+									eq2 = 0;
+								}
+							}
+							if (walk && s2 < 64) {
+								sidx = j + s2;
+								const int rv = R.rk[sidx];
+								kind = rv == 0 ? 0 : rv < nb1 ? 1 : 2;
+								if (kind == 2)
+									occ = tbl[sidx];
+								walk = false;
+								// a twin's re-insert walk ran over the table WITHOUT its predecessor's insert:
+								// exact only if it never met that slot
+								if (tw && tw_hit && (i64)L.tw_slot >= home2 && (i64)L.tw_slot <= sidx) {
+									L.complex_ = true;
+									chain = false;
+								}
+							}
+						}
+						j += 64;
+					}
+				}
+			}
+			if (chain)
+				L.complex_ = true; // deeper than the write list allows
+		}
+}
+
 __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf, Slot *__restrict__ tbl, ScanState *__restrict__ st,
 						i64 seg_lo, int ntiles, const uint32_t *__restrict__ cand_rel,
 						const u64 *__restrict__ cand_tag, const uint32_t *__restrict__ tile_count,
@@ -1066,325 +1398,7 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		// tag hits, (A3) the displacement chain of the insert, one level at a time.
 		const bool need_sim = alive && !w_simd;
 		if (__ballot(need_sim)) {
-			const u64 T = w_tag;
-			const i64 P = w_pos;
-			const int my_rank = bitness_rank(T);
-			const int nb1 = __popcll(better) + 1; // rank bytes below this are due for cleaning
-			int kind = -1; // insert stop: 0 empty, 1 due for cleaning, 2 lesser bitness
-			i64 sidx = 0;
-			Slot occ;
-			occ.offset = 0;
-			occ.t = 0;
-			int nhit = 0; // tag hits met by the lookup walk, offsets parked in LDS (hit_lds)
-			// Twins: consecutive candidates with the SAME tag (the byte leaving the 31-byte window
-			// equals the byte entering it) share a bucket, so the second always conflicts with the
-			// first one's insert.  The second of such a pair is simulated on top of the insert it can
-			// predict for the first from its own walk (same tag, same table); phase C checks the prediction.
-			// (cross-lane reads are made by all lanes: no short-circuit evaluation around them)
-			const int prev_alive = __shfl_up((int)alive, 1);
-			const u64 prev_tag = bcast64(w_tag, (lane + 63) & 63);
-			const i64 P_prev = (i64)bcast64((u64)w_pos, (lane + 63) & 63);
-			const bool tw_cand = lane > 0 && alive && prev_alive != 0 && prev_tag == w_tag;
-			const int prev_cand = __shfl_up((int)tw_cand, 1);
-			bool tw = tw_cand && prev_cand == 0; // a third twin in a row takes the conflict path
-			bool seek_pred = false, tw_hit = false;
-			// ---- A1: lookup walk to the first empty slot, 16 slots per step, branch-free masks ----
-			{
-				i64 idx = (i64)(T & R.hmask);
-				uint32_t neq = 0;
-				int steps = 0;
-				bool fin = !need_sim;
-				const int thr = my_rank > nb1 ? my_rank : nb1; // ranks below this stop my insert
-				if (need_sim) {
-					L.complex_ = nb1 >= 63 || my_rank >= 63; // rank bytes saturate at 63
-					L.match = false;
-					L.victim = false;
-					L.dec = 0;
-					L.misses = 0;
-					L.nw = 0;
-					L.ins = (T & R.tag_mask) == R.tag_mask;
-					L.lo = (uint32_t)idx;
-					L.hi = (uint32_t)idx;
-					if (L.complex_)
-						fin = true;
-					L.tw_over = false;
-					tw = tw && L.ins && !L.complex_;
-					seek_pred = tw;
-				}
-				const u64 thr8 = (u64)thr * B01, fp8 = (u64)fp_byte(T) * B01;
-				while (__ballot(!fin)) {
-					if (!fin) {
-						// 64 slots per step: their rank and fingerprint bytes (the arrays are padded)
-						U128u r4[4], f4[4];
-#pragma unroll
-						for (int c = 0; c < 4; c++) {
-							r4[c] = *reinterpret_cast<const U128u *>(R.rk + idx + 16 * c);
-							f4[c] = *reinterpret_cast<const U128u *>(R.fpa + idx + 16 * c);
-						}
-						u64 E = 0, S = 0, Q = 0; // bit q: slot idx + q is empty / stops my insert / may hold my tag
-#pragma unroll
-						for (int c = 0; c < 4; c++) {
-							E |= (u64)((flags_to_bits(bytes_lt(r4[c].b, B01)) << 8) | flags_to_bits(bytes_lt(r4[c].a, B01))) << (16 * c);
-							S |= (u64)((flags_to_bits(bytes_lt(r4[c].b, thr8)) << 8) | flags_to_bits(bytes_lt(r4[c].a, thr8))) << (16 * c);
-							Q |= (u64)((flags_to_bits(bytes_eq(f4[c].b, fp8)) << 8) | flags_to_bits(bytes_eq(f4[c].a, fp8))) << (16 * c);
-							// loose masks mean short clusters: stop evaluating once every walking lane has met
-							// its first empty slot (two for a twin, whose lookup may walk on past the first)
-							if (c < 3 && !__ballot(tw ? __popcll(E) < 2 : E == 0))
-								break;
-						}
-						steps += 64;
-						if (idx + 64 > tbl_size || steps > A1_MAX_STEPS) {
-							L.complex_ = true;
-							L.hi = (uint32_t)(idx + 63 < tbl_size - 1 ? idx + 63 : tbl_size - 1);
-							fin = true;
-						} else {
-							u64 Em = E;
-							if (kind < 0 && L.ins) {
-								int from = 0;
-								for (int pass = 0; pass < 2; pass++) {
-									const u64 Sm = S & ~low_mask(from);
-									const int s1 = Sm ? __ffsll((long long)Sm) - 1 : 64;
-									u64 eqb = Q & low_mask(s1) & ~low_mask(from);
-									while (eqb) {
-										const int q = __ffsll((long long)eqb) - 1;
-										eqb &= eqb - 1;
-										if (tbl[idx + q].t != T)
-											continue; // fingerprint false positive
-										if (neq < MAX_EQS)
-											eqs_lds[neq * 64 + w_ticket] = (uint32_t)(idx + q);
-										if (++neq >= R.max_chain) {
-											if (R.max_chain <= MAX_EQS && !tw)
-												kind = 3; // round-robin eviction among these equal tags
-											else if (seek_pred) {
-												tw = seek_pred = false;
-												if (R.max_chain <= MAX_EQS)
-													kind = 3;
-												else
-													L.complex_ = true;
-											} else
-												L.complex_ = true;
-											eqb = 0;
-										}
-									}
-									if (kind >= 0 || L.complex_ || s1 >= 64)
-										break;
-									const int rv = R.rk[idx + s1]; // just loaded: which kind of stop is it?
-									const int k1 = rv == 0 ? 0 : rv < nb1 ? 1 : 2;
-									if (!seek_pred) {
-										kind = k1;
-										sidx = idx + s1; // a lesser-bitness occupant (kind 2) is fetched after the walk
-										break; // (a twin that displaces in its turn: A3 checks its walks against tw_slot)
-									}
-									seek_pred = false;
-									if (k1 == 1 && ((Q >> s1) & 1)) {
-										tw = false; // the predecessor may replace its own tag: conflict path
-										kind = k1;
-										sidx = idx + s1;
-										break;
-									}
-									L.tw_slot = (uint32_t)(idx + s1);
-									L.tw_kind = k1; // 2: the predecessor takes the slot of a lesser-bitness occupant, which it
-											// re-inserts elsewhere -- a foreign write like any other for phase C
-									tw_hit = true;
-									if (k1 == 0)
-										Em &= ~(1ull << s1); // the twin fills the first empty slot: my lookup walks on
-									if ((T & better) != better) {
-										// before the first clean of a chunk a tag may itself be due for cleaning: the
-										// predecessor's entry is then the stop of my own insert, which replaces it
-										kind = 1;
-										sidx = idx + s1;
-										L.tw_over = true;
-										break;
-									}
-									if (neq < MAX_EQS)
-										eqs_lds[neq * 64 + w_ticket] = (uint32_t)(idx + s1);
-									if (++neq >= R.max_chain) {
-										L.complex_ = true;
-										break;
-									}
-									from = s1 + 1;
-								}
-							}
-							const int fe = Em ? __ffsll((long long)Em) - 1 : 64; // first empty slot of the step
-							u64 hm = Q & low_mask(fe);
-							while (hm) {
-								const int q = __ffsll((long long)hm) - 1;
-								hm &= hm - 1;
-								const Slot sl = tbl[idx + q];
-								if (sl.t != T)
-									continue; // fingerprint false positive
-								if (nhit < MAX_HITS)
-									hit_lds[nhit * 64 + lane] = sl.offset;
-								else
-									L.complex_ = true;
-								nhit++;
-							}
-							if (fe < 64) {
-								L.hi = (uint32_t)(idx + fe);
-								fin = true;
-							}
-						}
-						idx += 64;
-					}
-				}
-			}
-
-			if (need_sim) {
-				L.k0 = kind;
-				if (kind == 2 && !L.complex_)
-					occ = tbl[sidx]; // just read by the walk: an L2 hit, and only displacing inserts pay for it
-			}
-			lap(9);
-			// ---- A2: are the tag hits real matches (>= MINIMUM_MATCH)? ----
-			{
-				// all hits are pre-tested with independent loads (one round trip), the rare
-				// undecided ones get the exact compare
-				uint32_t und = 0; // bit k: hit k needs the exact compare
-				if (need_sim && !L.complex_) {
-					for (int k = 0; k < nhit && k < MAX_HITS; k++)
-						if (!quick_reject(buf, P, hit_lds[k * 64 + lane], R.end, R.last_match))
-							und |= 1u << k;
-					L.misses = (nhit < MAX_HITS ? nhit : MAX_HITS) - __popc(und);
-				}
-				while (__ballot(und != 0)) {
-					if (und) {
-						const int k = __ffs((int)und) - 1;
-						und &= und - 1;
-						if (!L.match) {
-							if (lane_verify(buf, P, hit_lds[k * 64 + lane], R.end, R.last_match))
-								L.match = true;
-							else
-								L.misses++;
-						}
-					}
-				}
-			}
-			// the twin's entry is one more tag hit for its successor: a real match (a run of one byte
-			// value) goes to the serial path
-			if (__ballot(need_sim && tw && tw_hit && !L.complex_)) {
-				if (need_sim && tw && tw_hit && !L.complex_) {
-					// (independent 8-byte looks first: text twins differ right there)
-					if (!quick_reject(buf, P, P_prev, R.end, R.last_match) && lane_verify(buf, P, P_prev, R.end, R.last_match))
-						L.complex_ = true;
-					else
-						L.misses++;
-				}
-			}
-			if (need_sim)
-				L.twin = tw && tw_hit && !L.complex_;
-			lap(14);
-			// ---- A3: displacement chain of the insert, level by level ----
-			{
-				u64 cur_t = T;
-				i64 cur_off = P;
-				bool chain = need_sim && L.ins && !L.complex_ && !L.match;
-#pragma unroll 1
-				for (int level = 0; level < 5; level++) {
-					if (!__ballot(chain))
-						break;
-					bool walk = false;
-					i64 j = 0;
-					int r2 = 0;
-					i64 home2 = 0;
-					if (chain) {
-						if (L.nw == 4) {
-							L.complex_ = true;
-							chain = false;
-						} else {
-#pragma unroll
-							for (int k = 0; k < 4; k++)
-								if (k == L.nw) {
-									L.w_slot[k] = (uint32_t)sidx;
-									L.w_t[k] = cur_t;
-									L.w_off[k] = cur_off;
-								}
-							L.nw++;
-							if ((uint32_t)sidx > L.hi)
-								L.hi = (uint32_t)sidx;
-							if (kind == 0) {
-								chain = false;
-							} else if (kind == 1) {
-								L.dec = 1;
-								chain = false;
-							} else if (kind == 3) {
-								// victim slot depends on victim_round at commit time (set in phase C)
-								L.victim = true;
-								L.dec = 1;
-								chain = false;
-							} else {
-								// lesser-bitness occupant: it is re-inserted from its own bucket
-								cur_t = occ.t;
-								cur_off = occ.offset;
-								r2 = bitness_rank(cur_t);
-								j = (i64)(cur_t & R.hmask);
-								home2 = j;
-								if ((uint32_t)j < L.lo)
-									L.lo = (uint32_t)j;
-								kind = -1;
-								walk = true;
-							}
-						}
-					}
-					uint32_t neq2 = 0;
-					int st2 = 0;
-					const int thr2 = r2 > nb1 ? r2 : nb1;
-					const u64 thr2_8 = (u64)thr2 * B01, fp2_8 = (u64)fp_byte(cur_t) * B01;
-					while (__ballot(walk)) {
-						if (walk) {
-							U128u r4[4], f4[4];
-#pragma unroll
-							for (int c = 0; c < 4; c++) {
-								r4[c] = *reinterpret_cast<const U128u *>(R.rk + j + 16 * c);
-								f4[c] = *reinterpret_cast<const U128u *>(R.fpa + j + 16 * c);
-							}
-							u64 S2 = 0, Q2 = 0;
-#pragma unroll
-							for (int c = 0; c < 4; c++) {
-								S2 |= (u64)((flags_to_bits(bytes_lt(r4[c].b, thr2_8)) << 8) | flags_to_bits(bytes_lt(r4[c].a, thr2_8))) << (16 * c);
-								Q2 |= (u64)((flags_to_bits(bytes_eq(f4[c].b, fp2_8)) << 8) | flags_to_bits(bytes_eq(f4[c].a, fp2_8))) << (16 * c);
-								if (c < 3 && !__ballot(S2 == 0))
-									break; // every walking lane has its stop
-							}
-							st2 += 64;
-							if (j + 64 > tbl_size || st2 > A1_MAX_STEPS || r2 >= 63) {
-								L.complex_ = true;
-								chain = false;
-								walk = false;
-							} else {
-								const int s2 = S2 ? __ffsll((long long)S2) - 1 : 64;
-								u64 eq2 = Q2 & low_mask(s2);
-								while (eq2) {
-									const int q = __ffsll((long long)eq2) - 1;
-									eq2 &= eq2 - 1;
-									if (tbl[j + q].t == cur_t && ++neq2 >= R.max_chain) {
-										L.complex_ = true;
-										chain = false;
-										walk = false;
-										eq2 = 0;
-									}
-								}
-								if (walk && s2 < 64) {
-									sidx = j + s2;
-									const int rv = R.rk[sidx];
-									kind = rv == 0 ? 0 : rv < nb1 ? 1 : 2;
-									if (kind == 2)
-										occ = tbl[sidx];
-									walk = false;
-									// a twin's re-insert walk ran over the table WITHOUT its predecessor's insert:
-									// exact only if it never met that slot
-									if (tw && tw_hit && (i64)L.tw_slot >= home2 && (i64)L.tw_slot <= sidx) {
-										L.complex_ = true;
-										chain = false;
-									}
-								}
-							}
-							j += 64;
-						}
-					}
-				}
-				if (chain)
-					L.complex_ = true; // deeper than the write list allows
-			}
+			simulate_lanes(R, tbl, buf, tbl_size, better, lane, alive, need_sim, w_tag, w_pos, w_ticket, hit_lds, eqs_lds, 64, L, lap);
 			if (need_sim)
 				w_simd = true;
 			lap(15);
@@ -1697,6 +1711,8 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		st->sink = any;
 }
 
+#include "rzip_resolve_mw.h"
+
 // ---------------------------------------------------------------------------------------------
 // K3: grid-wide forward extent of one long match
 // ---------------------------------------------------------------------------------------------
@@ -1979,6 +1995,13 @@ int scan_workspace_create(ScanWorkspace **out, int rzip_level, int64_t max_chunk
 		const char *pr = getenv("LRZGPU_RESOLVE_PROF"); // bit 1: per-phase cycle counters in the profile
 		if (pr && *pr == '1')
 			w->batch_mode |= 2;
+		// bits 4..6: wavefronts of the resolver workgroup (1 = k_resolve, 2 / 4 = k_resolve_mw)
+		int nw = 4;
+		if (const char *e = getenv("LRZGPU_RESOLVE_WAVES"))
+			nw = atoi(e);
+		nw = nw >= 4 ? 4 : nw >= 2 ? 2 : 1;
+		if ((w->batch_mode & 3) == 1 && nw > 1)
+			w->batch_mode |= nw << 4;
 	}
 	w->seg_cap = (size_t)1 << 28; // up to 256 Mi positions per segment
 	if ((int64_t)w->seg_cap > max_chunk + TILE)
@@ -2074,10 +2097,14 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 				   (u64 *)w->comp_tag);
 		t1.stop();
 		EventTimer t2(s);
-		hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), 0, s, d_chunk, (Slot *)w->table, w->state, (i64)seg_lo, ntiles,
-				   (const uint32_t *)w->cand_rel, (const u64 *)w->cand_tag, (const uint32_t *)w->tile_count, w->records,
-				   w->batch_mode, (const uint32_t *)w->tile_base, (const uint32_t *)w->comp_rel, (const u64 *)w->comp_tag,
-				   (uint32_t)w->comp_cap, w->rank_bytes, w->fp_bytes);
+		{
+			const int nw = (w->batch_mode >> 4) & 7;
+			auto kern = nw == 4 ? k_resolve_mw<4> : nw == 2 ? k_resolve_mw<2> : k_resolve;
+			hipLaunchKernelGGL(kern, dim3(1), dim3(nw == 4 ? 256 : nw == 2 ? 128 : 64), 0, s, d_chunk, (Slot *)w->table, w->state, (i64)seg_lo,
+					   ntiles, (const uint32_t *)w->cand_rel, (const u64 *)w->cand_tag, (const uint32_t *)w->tile_count, w->records,
+					   w->batch_mode, (const uint32_t *)w->tile_base, (const uint32_t *)w->comp_rel, (const u64 *)w->comp_tag,
+					   (uint32_t)w->comp_cap, w->rank_bytes, w->fp_bytes);
+		}
 		t2.stop();
 		HIPCHK(hipMemcpyAsync(&h, w->state, sizeof(h), hipMemcpyDeviceToHost, s));
 		HIPCHK(stream_wait(s));
