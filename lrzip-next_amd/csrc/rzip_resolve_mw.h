@@ -40,7 +40,9 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 {
 	constexpr int W = 64 * NW;
 	constexpr int RINGN = 4 * W;
-	constexpr int BUDGET = 16 * NW;
+	constexpr int PWB = 16; // suspects per wave that get the exact test
+	constexpr int CFB = CF_BITS + (NW >= 4 ? 1 : 0); // four times the writes per round: twice the counters
+	constexpr int CFW = (1 << CFB) / 2;
 	__shared__ i64 ring_pos[RINGN];
 	__shared__ u64 ring_tag[RINGN];
 	__shared__ u64 stk_t[64];
@@ -49,17 +51,19 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 	// phase A scratch of each wave (tag hits of the lookup walk); between rounds the staging area of the window
 	__shared__ __attribute__((aligned(16))) i64 hit_all[NW][MAX_HITS * 64];
 	__shared__ uint32_t eqs_lds[MAX_EQS * W];
-	__shared__ uint32_t cf_bits[CF_WORDS];
+	__shared__ uint32_t cf_bits[CFW];
 	__shared__ uint32_t vict[W];
 	__shared__ MwUniform U;
-	__shared__ u64 xm_x[NW], xm_ev[NW], xm_clean[NW], xm_flag[NW], xm_bad[NW], xm_twl[NW];
+	__shared__ u64 xm_x[NW], xm_ev[NW], xm_clean[NW], xm_bad[NW];
+	__shared__ int xm_nfl[NW];
 	__shared__ int x_why[NW];
 	__shared__ i64 x_P[NW];
 	__shared__ u64 x_T[NW];
 	__shared__ int x_cnt[NW][4];
 	__shared__ uint32_t x_lastvict[NW];
-	__shared__ uint32_t fl_k[BUDGET], fl_lo[BUDGET], fl_hi[BUDGET];
-	__shared__ int fl_res[NW][BUDGET];
+	// suspects of the conflict filter: one list per wave (lane order), checked by that wave and the waves before it
+	__shared__ uint32_t fl_k[NW][PWB], fl_lo[NW][PWB], fl_hi[NW][PWB];
+	__shared__ int fl_res[NW][NW][PWB];
 	__shared__ i64 x_miss;
 	static_assert(sizeof(i64) * MAX_HITS * 64 * NW >= (size_t)W * 128, "staging area");
 
@@ -96,7 +100,7 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 	R.allow_abort = true;
 	R.aborted = false;
 	R.ext_p = R.ext_op = R.ext_done = 0;
-	for (int k = threadIdx.x; k < CF_WORDS; k += W)
+	for (int k = threadIdx.x; k < CFW; k += W)
 		cf_bits[k] = 0;
 	if (threadIdx.x == 0)
 		x_miss = 0;
@@ -108,7 +112,16 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 	const i64 rec_cap = st->rec_cap;
 	i64 inserts = st->inserts, lookups = st->lookups;
 	int error = st->error;
-	i64 dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	i64 dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	u64 tclk = __builtin_amdgcn_s_memtime();
+	const bool prof = (batch_mode & 2) != 0 && master; // shader-clock laps of wave 0 between the barriers of a round
+	auto lap = [&](int slot) {
+		if (!prof)
+			return;
+		const u64 now = __builtin_amdgcn_s_memtime();
+		dbg[slot] += (i64)(now - tclk);
+		tclk = now;
+	};
 	i64 miss_acc = 0; // per lane, every wave
 	const i64 tbl_size = (i64)R.hmask + 1;
 
@@ -186,6 +199,20 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 		}
 		ring_cnt += __popcll(m);
 	};
+	i64 pre_pos[4] = {-1, -1, -1, -1};
+	u64 pre_tag[4] = {0, 0, 0, 0};
+	uint32_t pre_at = 0xFFFFFFFFu; // packed-list position pre_* were fetched for
+	auto fetch4 = [&](uint32_t at, i64(&pos)[4], u64(&tag)[4]) {
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			pos[j] = -1;
+			tag[j] = 0;
+			if (at + 64 * j + lane < ctotal) {
+				pos[j] = seg_lo + (i64)comp_rel[at + 64 * j + lane];
+				tag[j] = comp_tag[at + 64 * j + lane];
+			}
+		}
+	};
 	auto refill_ring = [&]() {
 		if (packed) {
 			if (p_skip != skip_seen) { // a match was emitted: jump over the candidates inside it
@@ -197,19 +224,20 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 						cpos = c0;
 				}
 			}
-			// four independent loads per trip: one memory latency for up to 256 candidates
+			// four independent loads per trip: one memory latency for up to 256 candidates (none when the
+			// trip's candidates were fetched during the previous round)
 			while (ring_cnt <= RINGN - 256 && cpos < ctotal) {
 				i64 pos[4];
 				u64 tag[4];
+				if (pre_at == cpos) {
 #pragma unroll
-				for (int j = 0; j < 4; j++) {
-					pos[j] = -1;
-					tag[j] = 0;
-					if (cpos + 64 * j + lane < ctotal) {
-						pos[j] = seg_lo + (i64)comp_rel[cpos + 64 * j + lane];
-						tag[j] = comp_tag[cpos + 64 * j + lane];
+					for (int j = 0; j < 4; j++) {
+						pos[j] = pre_pos[j];
+						tag[j] = pre_tag[j];
 					}
-				}
+				} else
+					fetch4(cpos, pos, tag);
+				pre_at = 0xFFFFFFFFu;
 #pragma unroll
 				for (int j = 0; j < 4; j++)
 					push(pos[j] > p_skip && (tag[j] & R.min_mask) == R.min_mask, pos[j], tag[j]);
@@ -350,6 +378,7 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 			ring_cnt -= k;
 			popped_abs += (uint32_t)k;
 		}
+		lap(8); // queue refill, publication
 		__syncthreads(); // #1
 		const int mode = U.mode;
 		if (mode == 2)
@@ -376,6 +405,16 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 		}
 		const bool has = gi < wcount;
 		const bool alive = has && w_pos > p_skip && (w_tag & R.min_mask) == R.min_mask;
+		// wave 0: what the next refill and this round's sweep will read first, fetched behind the simulations
+		u64 pre_rb = 0;
+		if (master && mode == 0) {
+			if (packed && pre_at != cpos && cpos < ctotal) {
+				fetch4(cpos, pre_pos, pre_tag);
+				pre_at = cpos;
+			}
+			if (R.hash_count + W > R.hash_limit && R.clean_ptr + 8 * lane < tbl_size)
+				pre_rb = reinterpret_cast<const U64u *>(R.rk + R.clean_ptr + 8 * lane)->v;
+		}
 
 		// ---- serial path: pending lazy match, batching disabled, or batching not paying off ----
 		if (mode == 1) {
@@ -426,6 +465,7 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 			}
 		}
 		__syncthreads(); // #2
+		lap(9); // top-up + simulations (the slowest wave)
 		int x_before = 0, ev_before = 0;
 		u64 evict_all = 0;
 #pragma unroll
@@ -466,35 +506,37 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 		i64 scan_end = cp0;
 		if (want) {
 			if (master) {
+				// 512 slots per trip: eight rank bytes per lane, in slot order (lane-major), one memory latency
 				i64 ptr = cp0;
-				int rounds = 0;
 				int n = 0;
-				while (n < want && ptr < tbl_size && rounds < 512 * NW) {
-					// two 64-slot pieces per trip: independent loads
-					const i64 q = ptr + lane, q2 = q + 64;
-					uint32_t rv = 0, rv2 = 0;
-					if (q < tbl_size)
-						rv = R.rk[q];
-					if (q2 < tbl_size)
-						rv2 = R.rk[q2];
-					const bool cand = rv != 0 && rv < (uint32_t)vic_nb1; // occupied and due for cleaning
-					const u64 m = __ballot(cand);
-					const int r = n + __popcll(m & lanes_below);
-					if (cand && r < W)
-						vict[r] = (uint32_t)q;
-					n += __popcll(m);
-					ptr += 64;
-					rounds++;
-					if (n < want && ptr < tbl_size) {
-						const bool cand2 = rv2 != 0 && rv2 < (uint32_t)vic_nb1;
-						const u64 m2 = __ballot(cand2);
-						const int r2 = n + __popcll(m2 & lanes_below);
-						if (cand2 && r2 < W)
-							vict[r2] = (uint32_t)q2;
-						n += __popcll(m2);
-						ptr += 64;
-						rounds++;
+				const u64 nb8 = (u64)vic_nb1 * B01;
+				while (n < want && ptr < tbl_size && ptr - cp0 < (i64)32768 * NW) {
+					const i64 q0 = ptr + 8 * lane;
+					u64 rb = 0;
+					if (ptr == cp0 && hc0 + W > R.hash_limit)
+						rb = pre_rb; // (nothing has written the table since)
+					else if (q0 < tbl_size)
+						rb = reinterpret_cast<const U64u *>(R.rk + q0)->v; // (the array is zero-padded past the table)
+					uint32_t m8 = flags_to_bits(bytes_lt(rb, nb8) & ~bytes_lt(rb, B01)); // occupied and due for cleaning
+					if (q0 + 8 > tbl_size)
+						m8 &= q0 < tbl_size ? (1u << (int)(tbl_size - q0)) - 1 : 0;
+					int before = 0, total = 0;
+#pragma unroll
+					for (int b = 0; b < 8; b++) {
+						const u64 bm = __ballot((m8 >> b) & 1);
+						before += __popcll(bm & lanes_below);
+						total += __popcll(bm);
 					}
+					int r = n + before;
+					while (m8) {
+						const int b = __ffs((int)m8) - 1;
+						m8 &= m8 - 1;
+						if (r < W)
+							vict[r] = (uint32_t)(q0 + b);
+						r++;
+					}
+					n += total;
+					ptr += 512;
 				}
 				if (lane == 0) {
 					U.nv = n > W ? W : n;
@@ -505,6 +547,7 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 			nv = U.nv;
 			scan_end = U.scan_end;
 		}
+		lap(10); // prefix counts, victim sweep
 		uint32_t my_vict = 0xFFFFFFFFu;
 		int why = 0; // 3 complex, 4 match, 5 conflict, 6 no victim, 7 swept range
 		bool stop = false;
@@ -560,26 +603,36 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 				} else
 					wr[k] = my_vict;
 			}
-			wh[k] = wr[k] != 0xFFFFFFFFu ? ((wr[k] >> gsh) * 2654435761u) >> (32 - CF_BITS) : 0xFFFFFFFFu;
+			wh[k] = wr[k] != 0xFFFFFFFFu ? ((wr[k] >> gsh) * 2654435761u) >> (32 - CFB) : 0xFFFFFFFFu;
 		}
 #pragma unroll
 		for (int k = 0; k < 5; k++)
 			if (wh[k] != 0xFFFFFFFFu)
 				__hip_atomic_fetch_add(&cf_bits[wh[k] >> 1], 1u << (16 * (wh[k] & 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		__syncthreads(); // #5
+		lap(14); // stops, twin check, filter writes
 		const bool reads = live && !L.complex_ && !L.match;
 		const uint32_t r_lo = L.lo & ~7u, r_hi = L.hi | 7u;
-		const uint32_t tw_h = tw_live && !stop ? ((L.tw_slot >> gsh) * 2654435761u) >> (32 - CF_BITS) : 0xFFFFFFFFu;
+		const uint32_t tw_h = tw_live && !stop ? ((L.tw_slot >> gsh) * 2654435761u) >> (32 - CFB) : 0xFFFFFFFFu;
 		bool flagged = false;
+		// the writes of the lane after me come after me whatever they are: not counted either (a twin's
+		// insert lands in its predecessor's granule, which made a suspect of every predecessor)
+		uint32_t nh[5];
+#pragma unroll
+		for (int q = 0; q < 5; q++) {
+			nh[q] = __shfl_down(wh[q], 1);
+			if (lane == 63)
+				nh[q] = 0xFFFFFFFFu;
+		}
 		if (reads) {
 			const uint32_t g1 = L.hi >> gsh;
 			uint32_t expect = tw_h != 0xFFFFFFFFu ? 1u : 0u;
 			for (uint32_t g = L.lo >> gsh; g <= g1; g++) {
-				const uint32_t hb = (g * 2654435761u) >> (32 - CF_BITS);
+				const uint32_t hb = (g * 2654435761u) >> (32 - CFB);
 				uint32_t cnt = (cf_bits[hb >> 1] >> (16 * (hb & 1))) & 0xFFFFu;
 #pragma unroll
 				for (int q = 0; q < 5; q++)
-					cnt -= wh[q] == hb;
+					cnt -= (uint32_t)(wh[q] == hb) + (uint32_t)(nh[q] == hb);
 				if (expect && hb == tw_h && cnt) {
 					cnt--;
 					expect = 0;
@@ -588,53 +641,65 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 					flagged = true;
 			}
 		}
-		{
-			const u64 bf = __ballot(flagged), bt = __ballot(tw_live);
-			if (lane == 0) {
-				xm_flag[wave] = bf;
-				xm_twl[wave] = bt;
-			}
-		}
-		__syncthreads(); // #6
+		lap(15); // filter reads
 		int first_conf = MW_NONE; // window index of the earliest conflicting writer
-		int fidx = __popcll(xm_flag[wave] & lanes_below), nflag = 0;
-#pragma unroll
-		for (int w2 = 0; w2 < NW; w2++) {
-			const int c = __popcll(xm_flag[w2]);
-			if (w2 < wave)
-				fidx += c;
-			nflag += c;
-		}
-		if (nflag) { // (the same in every wave)
+		int fidx;
+		{
+			const u64 bf = __ballot(flagged);
+			fidx = __popcll(bf & lanes_below);
 			if (flagged) {
-				if (fidx < BUDGET) {
-					fl_k[fidx] = (uint32_t)gi;
-					fl_lo[fidx] = r_lo;
-					fl_hi[fidx] = r_hi;
+				if (fidx < PWB) {
+					fl_k[wave][fidx] = (uint32_t)gi | (tw_live ? 0x80000000u : 0u); // (a twin's predecessor's insert is part of its simulation)
+					fl_lo[wave][fidx] = r_lo;
+					fl_hi[wave][fidx] = r_hi;
 				} else
 					first_conf = 0; // too many suspects: call the rest conflicting (they re-simulate)
 			}
-			__syncthreads(); // #7
-			const int ne = nflag < BUDGET ? nflag : BUDGET;
-			for (int e = 0; e < ne; e++) {
-				const int k = (int)fl_k[e];
-				const uint32_t klo = fl_lo[e], khi = fl_hi[e];
-				const bool k_twin = (xm_twl[k >> 6] >> (k & 63)) & 1; // its predecessor's insert is part of its simulation
-				bool hit = false;
+			if (lane == 0)
+				xm_nfl[wave] = __popcll(bf) < PWB ? __popcll(bf) : PWB;
+		}
+		__syncthreads(); // #6
+		lap(7);
+		{
+			int any = 0;
 #pragma unroll
-				for (int q = 0; q < 5; q++)
-					hit |= wr[q] != 0xFFFFFFFFu && wr[q] >= klo && wr[q] <= khi && !(q == 0 && k_twin && gi == k - 1);
-				const u64 hm = __ballot(hit && gi < k);
-				if (lane == 0)
-					fl_res[wave][e] = hm ? 64 * wave + __ffsll((long long)hm) - 1 : MW_NONE;
-			}
-			__syncthreads(); // #8
-			if (flagged && fidx < BUDGET) {
+			for (int w2 = 0; w2 < NW; w2++)
+				any += xm_nfl[w2];
+			if (any) { // (the same in every wave)
 #pragma unroll
 				for (int w2 = 0; w2 < NW; w2++) {
-					const int r = fl_res[w2][fidx];
-					if (r < first_conf)
-						first_conf = r;
+					const int n2 = xm_nfl[w2];
+					if (w2 < wave || n2 == 0) // writers of a later wave come after every suspect of this list
+						continue;
+					// the whole list in registers (lane e holds entry e), then one uniform pass per entry
+					const uint32_t mk = fl_k[w2][lane & (PWB - 1)], mlo = fl_lo[w2][lane & (PWB - 1)], mhi = fl_hi[w2][lane & (PWB - 1)];
+					int res = MW_NONE;
+					for (int e = 0; e < n2; e++) {
+						const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)mk, e);
+						const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)mlo, e), khi = (uint32_t)__builtin_amdgcn_readlane((int)mhi, e);
+						const int k = (int)(kk & 0x7FFFFFFFu);
+						const bool excl0 = (kk >> 31) != 0 && gi == k - 1; // the twin's predecessor: its insert is expected
+						const uint32_t span = khi - klo;                 // (an unused write slot, 0xFFFFFFFF, is never inside)
+						bool hit = wr[0] - klo <= span && !excl0;
+#pragma unroll
+						for (int q = 1; q < 5; q++)
+							hit |= wr[q] - klo <= span;
+						const u64 hm = __ballot(hit && gi < k);
+						if (lane == e && hm)
+							res = 64 * wave + __ffsll((long long)hm) - 1;
+					}
+					if (lane < n2)
+						fl_res[wave][w2][lane] = res;
+				}
+				__syncthreads(); // #8
+				if (flagged && fidx < PWB) {
+#pragma unroll
+					for (int w1 = 0; w1 < NW; w1++)
+						if (w1 <= wave) {
+							const int r = fl_res[w1][wave][fidx];
+							if (r < first_conf)
+								first_conf = r;
+						}
 				}
 			}
 		}
@@ -656,6 +721,7 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 			}
 		}
 		__syncthreads(); // #9
+		lap(11); // filter reads, suspects
 		int f = wcount, why_f = 0;
 		i64 P_f = 0;
 		u64 T_f = 0;
@@ -701,6 +767,7 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		__syncthreads(); // #10: every table write of the round is visible to every wave
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+		lap(12); // table writes
 		uint32_t last_clean = 0xFFFFFFFFu;
 #pragma unroll
 		for (int w2 = 0; w2 < NW; w2++)
@@ -758,6 +825,7 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 		} else {
 			shift_window(f);
 		}
+		lap(13); // bookkeeping, serial step, window shift
 	}
 
 #pragma unroll
@@ -787,7 +855,7 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 		st->lookups = lookups;
 		st->tag_hits = R.tag_hits;
 		st->tag_misses = R.tag_misses;
-		for (int k = 0; k < 8; k++)
+		for (int k = 0; k < 16; k++)
 			st->dbg[k] += dbg[k];
 	}
 }

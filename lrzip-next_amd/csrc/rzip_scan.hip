@@ -2000,7 +2000,7 @@ int scan_workspace_create(ScanWorkspace **out, int rzip_level, int64_t max_chunk
 		if (const char *e = getenv("LRZGPU_RESOLVE_WAVES"))
 			nw = atoi(e);
 		nw = nw >= 4 ? 4 : nw >= 2 ? 2 : 1;
-		if ((w->batch_mode & 3) == 1 && nw > 1)
+		if ((w->batch_mode & 1) && nw > 1)
 			w->batch_mode |= nw << 4;
 	}
 	w->seg_cap = (size_t)1 << 28; // up to 256 Mi positions per segment

@@ -29,6 +29,10 @@ if os.environ.get("LRZGPU_RESOLVE_PROF") != "1":
     sys.exit(0)
 cyc = d[8:]
 tot = sum(cyc) or 1
-lab = ("8 prefetch-sweep", "9 simulate(A1)+commit-prep", "10 victims", "11 conflicts", "12 apply", "13 tail/shift/serial", "14 A2 verify", "15 A3 displacement")
+if os.environ.get("LRZGPU_RESOLVE_WAVES", "4") != "1":
+    lab = ("8 refill+publish", "9 top-up+simulate", "10 prefix+sweep", "11 filter reads+suspects", "12 table writes", "13 bookkeeping+serial+shift", "14 stops+filter writes", "15 filter reads")
+else:
+  lab = ("8 prefetch-sweep", "9 simulate(A1)+commit-prep", "10 victims", "11 conflicts", "12 apply", "13 tail/shift/serial", "14 A2 verify", "15 A3 displacement")
+print("  (mw: lap 7 = suspects publish + barrier: %d ticks)" % d[7])
 for n, c in zip(lab, cyc):
     print("  %-28s %12d ticks  %5.1f %%  %8.1f per batch" % (n, c, 100.0 * c / tot, c / max(d[0], 1)))
