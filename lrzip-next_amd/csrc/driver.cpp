@@ -128,14 +128,22 @@ static bool tracing_events()
 
 static hipError_t make_stream(hipStream_t *s, bool high_priority = false)
 {
+	const int dev = current_device_or0(), kind = high_priority ? 1 : 0;
+	if ((*s = StreamPool::get().take(dev, kind)) != nullptr)
+		return hipSuccess;
+	hipError_t e = hipErrorUnknown;
 	if (high_priority) {
 		// a scan stream must never queue behind a multi-second gate/finder kernel: streams share a
 		// small pool of hardware queues (GPU_MAX_HW_QUEUES), priority streams get their own
 		int lo = 0, hi = 0;
 		if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
-			return hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi);
+			e = hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi);
 	}
-	return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+	if (e != hipSuccess)
+		e = hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+	if (e == hipSuccess)
+		StreamPool::get().created(*s, dev, kind);
+	return e;
 }
 
 // --zstd back end: the system libzstd, bound at run time like the reference links it
@@ -420,7 +428,7 @@ struct Pipeline {
 			for (int k = 0; k < 2; k++)
 				if (stage[k])
 					(void)hipHostFree(stage[k]);
-			(void)hipStreamDestroy(s);
+			StreamPool::get().give(s);
 		};
 		if (hipHostMalloc((void **)&stage[0], STAGE_BYTES, hipHostMallocDefault) != hipSuccess ||
 		    hipHostMalloc((void **)&stage[1], STAGE_BYTES, hipHostMallocDefault) != hipSuccess) {
@@ -769,9 +777,9 @@ struct Feeder {
 		}
 		batches.clear();
 		if (ms)
-			(void)hipStreamDestroy(ms);
+			StreamPool::get().give(ms);
 		for (hipStream_t gs : gate_streams)
-			(void)hipStreamDestroy(gs);
+			StreamPool::get().give(gs);
 		ms = nullptr;
 		gate_streams.clear();
 		arena.release();
@@ -924,7 +932,7 @@ struct Run {
 				if (stage[k])
 					(void)hipHostFree(stage[k]);
 			if (s)
-				(void)hipStreamDestroy(s);
+				StreamPool::get().give(s);
 		};
 		if (make_stream(&s) != hipSuccess) {
 			fail(LRZGPU_E_HIP);
@@ -1042,7 +1050,7 @@ struct Run {
 					if (stage[q])
 						(void)hipHostFree(stage[q]);
 				if (s)
-					(void)hipStreamDestroy(s);
+					StreamPool::get().give(s);
 			} else {
 				std::vector<uint8_t> buf(piece);
 				for (int64_t o = 0; o < in.n && !rc; o += (int64_t)piece) {
@@ -1085,11 +1093,15 @@ struct Run {
 		if (scan_slots > 1 && !off && hipGetDeviceProperties(&prop, P.device) == hipSuccess && prop.multiProcessorCount >= 64) {
 			const int ncu = prop.multiProcessorCount > 256 ? 256 : prop.multiProcessorCount;
 			const int k = scanner_ids.fetch_add(1) % 8;
+			if ((*s = StreamPool::get().take(P.device, 16 + k)) != nullptr)
+				return hipSuccess;
 			uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 			for (int c = k; c < ncu; c += 8)
 				mask[c >> 5] |= 1u << (c & 31);
-			if (hipExtStreamCreateWithCUMask(s, (uint32_t)((ncu + 31) / 32), mask) == hipSuccess)
+			if (hipExtStreamCreateWithCUMask(s, (uint32_t)((ncu + 31) / 32), mask) == hipSuccess) {
+				StreamPool::get().created(*s, P.device, 16 + k);
 				return hipSuccess;
+			}
 			(void)hipGetLastError();
 		}
 		return make_stream(s, true);

@@ -10,6 +10,7 @@
 #include <unistd.h>
 
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <new>
@@ -147,6 +148,111 @@ template <typename T> struct RawBuf { // uninitialised host buffer (std::vector 
 	const T *data() const { return p; }
 };
 
+// ---- device memory: never let the runtime run out ---------------------------------------------------
+// When an allocation fails, the HSA runtime of this ROCm build trims its own caches and crashes doing so
+// (rocr::AMD::GpuAgent::Trim -> AqlQueue::AsyncReclaimMainScratch through a queue that no longer exists:
+// seen as SIGSEGV inside hipMalloc in a process that had created and destroyed CU-masked streams).  So the pools
+// do not let it get there: every large allocation of the library is made under one mutex after asking the
+// driver how much is free, parked buffers are given back first when the device is short, and what is parked is
+// bounded.
+inline void pools_release_device(int device); // everything parked in DevicePool and WorkspacePool, defined below
+struct DeviceBudget {
+	static std::mutex &alloc_mu()
+	{
+		static std::mutex m;
+		return m;
+	}
+	static size_t margin() { return (size_t)6 << 30; }
+	static size_t free_now()
+	{
+		size_t fr = 0, tot = 0;
+		if (hipMemGetInfo(&fr, &tot) != hipSuccess) {
+			(void)hipGetLastError();
+			return ~(size_t)0;
+		}
+		return fr;
+	}
+	static size_t idle_limit() // parked device memory above this is freed when it is given back
+	{
+		static const size_t lim = [] {
+			size_t fr = 0, tot = 0;
+			if (hipMemGetInfo(&fr, &tot) != hipSuccess || tot == 0) {
+				(void)hipGetLastError();
+				return (size_t)128 << 30;
+			}
+			return tot / 10 * 7;
+		}();
+		return lim;
+	}
+	// call with alloc_mu held, before hipMalloc()ing `bytes`: false = not even after releasing what is parked
+	static bool make_room(size_t bytes, int device)
+	{
+		const size_t f0 = free_now();
+		if (f0 >= bytes + margin())
+			return true;
+		pools_release_device(device);
+		const size_t f1 = free_now();
+		if (getenv("LRZGPU_TRACE"))
+			fprintf(stderr, "lrzgpu pools: %zu MiB wanted, %zu MiB free: parked buffers released, now %zu MiB free\n", bytes >> 20, f0 >> 20, f1 >> 20);
+		return f1 >= bytes + ((size_t)1 << 30);
+	}
+};
+
+// ---- streams: created once, parked, never destroyed ---------------------------------------------------
+// (a destroyed stream's hardware queue is exactly what the runtime trips over later, see DeviceBudget; a
+// compressor that handles file after file needs the same handful of streams again anyway)
+struct StreamPool {
+	struct Entry {
+		hipStream_t s;
+		int device, kind; // kind: 0 plain non-blocking, 1 high priority, 16 + k the k-th CU-masked set
+	};
+	std::mutex mu;
+	std::vector<Entry> idle, known;
+	static StreamPool &get()
+	{
+		static StreamPool p;
+		return p;
+	}
+	hipStream_t take(int device, int kind)
+	{
+		std::lock_guard<std::mutex> lk(mu);
+		for (size_t i = 0; i < idle.size(); i++)
+			if (idle[i].device == device && idle[i].kind == kind) {
+				hipStream_t s = idle[i].s;
+				idle[i] = idle.back();
+				idle.pop_back();
+				return s;
+			}
+		return nullptr;
+	}
+	void created(hipStream_t s, int device, int kind)
+	{
+		std::lock_guard<std::mutex> lk(mu);
+		known.push_back(Entry{s, device, kind});
+	}
+	void give(hipStream_t s) // in place of hipStreamDestroy(): the stream must be idle
+	{
+		if (!s)
+			return;
+		std::lock_guard<std::mutex> lk(mu);
+		for (auto &e : known)
+			if (e.s == s) {
+				idle.push_back(e);
+				return;
+			}
+		// not one of ours: leave it alone (and alive)
+	}
+};
+inline int current_device_or0()
+{
+	int d = 0;
+	if (hipGetDevice(&d) != hipSuccess) {
+		(void)hipGetLastError();
+		d = 0;
+	}
+	return d;
+}
+
 // ---- device buffers ------------------------------------------------------------------------------
 struct DevicePool {
 	struct Entry {
@@ -155,7 +261,8 @@ struct DevicePool {
 		int device;
 	};
 	std::mutex mu;
-	std::vector<Entry> idle;
+	std::vector<Entry> idle; // oldest first
+	size_t idle_bytes = 0;
 	static DevicePool &get()
 	{
 		static DevicePool p;
@@ -172,8 +279,8 @@ struct DevicePool {
 			if (best != idle.size() && idle[best].cap <= bytes + bytes / 4 + ((size_t)16 << 20)) {
 				void *p = idle[best].p;
 				*cap = idle[best].cap;
-				idle[best] = idle.back();
-				idle.pop_back();
+				idle_bytes -= idle[best].cap;
+				idle.erase(idle.begin() + (long)best);
 				return p;
 			}
 		}
@@ -182,13 +289,12 @@ struct DevicePool {
 		if (*cap == 0)
 			*cap = round;
 		void *p = nullptr;
+		std::lock_guard<std::mutex> al(DeviceBudget::alloc_mu());
+		if (!DeviceBudget::make_room(*cap, device))
+			return nullptr;
 		if (hipMalloc(&p, *cap) != hipSuccess) {
 			(void)hipGetLastError();
-			trim(device); // parked buffers of other shapes may be what is in the way
-			if (hipMalloc(&p, *cap) != hipSuccess) {
-				(void)hipGetLastError();
-				return nullptr;
-			}
+			return nullptr;
 		}
 		return p;
 	}
@@ -196,8 +302,19 @@ struct DevicePool {
 	{
 		if (!p)
 			return;
-		std::lock_guard<std::mutex> lk(mu);
-		idle.push_back(Entry{cap, p, device});
+		std::vector<Entry> out;
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			idle.push_back(Entry{cap, p, device});
+			idle_bytes += cap;
+			while (idle_bytes > DeviceBudget::idle_limit() / 2 && idle.size() > 1) {
+				out.push_back(idle.front());
+				idle_bytes -= idle.front().cap;
+				idle.erase(idle.begin());
+			}
+		}
+		for (auto &e : out)
+			(void)hipFree(e.p);
 	}
 	void trim(int device = -1)
 	{
@@ -207,6 +324,9 @@ struct DevicePool {
 			for (auto &e : idle)
 				(device < 0 || e.device == device ? old : keep).push_back(e);
 			idle.swap(keep);
+			idle_bytes = 0;
+			for (auto &e : idle)
+				idle_bytes += e.cap;
 		}
 		for (auto &e : old)
 			(void)hipFree(e.p);
@@ -250,8 +370,32 @@ struct WorkspacePool {
 		int64_t max_chunk;
 	};
 	std::mutex mu;
-	std::vector<MfEntry> mf;
+	std::vector<MfEntry> mf; // oldest first
 	std::vector<ScanEntry> scan;
+	size_t idle_bytes = 0;
+	static size_t mf_bytes(size_t max_n, double per_pos) // what mf_workspace_create allocates, roughly
+	{
+		return max_n * 110 + (size_t)((double)max_n * per_pos) * 8 + ((size_t)64 << 20);
+	}
+	static size_t scan_bytes(const ScanWorkspace *w)
+	{
+		return ((size_t)18 << w->hash_bits) + w->seg_cap * 12 + w->comp_cap * 12 + (size_t)w->rec_cap * sizeof(MatchRec) + ((size_t)16 << 20);
+	}
+	// parked workspaces above the bound are destroyed, oldest first (call with mu held; destroy outside)
+	void evict_locked(std::vector<MfEntry> &m_out, std::vector<ScanEntry> &s_out)
+	{
+		while (idle_bytes > DeviceBudget::idle_limit() && (mf.size() + scan.size()) > 1) {
+			if (!mf.empty() && (scan.empty() || mf_bytes(mf.front().w->max_n, mf.front().per_pos) >= scan_bytes(scan.front().w))) {
+				idle_bytes -= mf_bytes(mf.front().w->max_n, mf.front().per_pos);
+				m_out.push_back(mf.front());
+				mf.erase(mf.begin());
+			} else {
+				idle_bytes -= scan_bytes(scan.front().w);
+				s_out.push_back(scan.front());
+				scan.erase(scan.begin());
+			}
+		}
+	}
 	static WorkspacePool &get()
 	{
 		static WorkspacePool p;
@@ -270,12 +414,15 @@ struct WorkspacePool {
 			if (best != mf.size()) {
 				MfWorkspace *w = mf[best].w;
 				*got_per_pos = mf[best].per_pos;
-				mf[best] = mf.back();
-				mf.pop_back();
+				idle_bytes -= mf_bytes(w->max_n, mf[best].per_pos);
+				mf.erase(mf.begin() + (long)best);
 				return w;
 			}
 		}
 		MfWorkspace *w = nullptr;
+		std::lock_guard<std::mutex> al(DeviceBudget::alloc_mu());
+		if (!DeviceBudget::make_room(mf_bytes(max_n, per_pos), device))
+			return nullptr;
 		if (mf_workspace_create(&w, max_n, per_pos) != 0) {
 			mf_workspace_destroy(w);
 			trim(device);
@@ -293,8 +440,18 @@ struct WorkspacePool {
 	{
 		if (!w)
 			return;
-		std::lock_guard<std::mutex> lk(mu);
-		mf.push_back(MfEntry{w, device, per_pos});
+		std::vector<MfEntry> m_out;
+		std::vector<ScanEntry> s_out;
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			mf.push_back(MfEntry{w, device, per_pos});
+			idle_bytes += mf_bytes(w->max_n, per_pos);
+			evict_locked(m_out, s_out);
+		}
+		for (auto &e : m_out)
+			mf_workspace_destroy(e.w);
+		for (auto &e : s_out)
+			scan_workspace_destroy(e.w);
 	}
 	ScanWorkspace *take_scan(int level, int64_t max_chunk, int device)
 	{
@@ -304,12 +461,19 @@ struct WorkspacePool {
 				if (scan[i].device == device && scan[i].level == level && scan[i].max_chunk >= max_chunk &&
 				    scan[i].max_chunk <= max_chunk + max_chunk / 2 + (1 << 20)) {
 					ScanWorkspace *w = scan[i].w;
-					scan[i] = scan.back();
-					scan.pop_back();
+					idle_bytes -= scan_bytes(w);
+					scan.erase(scan.begin() + (long)i);
 					return w;
 				}
 		}
 		ScanWorkspace *w = nullptr;
+		std::lock_guard<std::mutex> al(DeviceBudget::alloc_mu());
+		{
+			// (what scan_workspace_create is going to ask for: candidate arrays for up to 2^28 positions, table, records)
+			const size_t seg = (size_t)(max_chunk + 8192 < ((int64_t)1 << 28) ? max_chunk + 8192 : (int64_t)1 << 28);
+			if (!DeviceBudget::make_room(seg * 24 + (size_t)(max_chunk / 31 + 16) * sizeof(MatchRec) + ((size_t)2 << 30), device))
+				return nullptr;
+		}
 		if (scan_workspace_create(&w, level, max_chunk) != 0) {
 			scan_workspace_destroy(w);
 			trim(device);
@@ -326,8 +490,18 @@ struct WorkspacePool {
 	{
 		if (!w)
 			return;
-		std::lock_guard<std::mutex> lk(mu);
-		scan.push_back(ScanEntry{w, device, level, max_chunk});
+		std::vector<MfEntry> m_out;
+		std::vector<ScanEntry> s_out;
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			scan.push_back(ScanEntry{w, device, level, max_chunk});
+			idle_bytes += scan_bytes(w);
+			evict_locked(m_out, s_out);
+		}
+		for (auto &e : m_out)
+			mf_workspace_destroy(e.w);
+		for (auto &e : s_out)
+			scan_workspace_destroy(e.w);
 	}
 	void trim(int device = -1)
 	{
@@ -341,6 +515,11 @@ struct WorkspacePool {
 				(device < 0 || e.device == device ? s : sk).push_back(e);
 			mf.swap(mk);
 			scan.swap(sk);
+			idle_bytes = 0;
+			for (auto &e : mf)
+				idle_bytes += mf_bytes(e.w->max_n, e.per_pos);
+			for (auto &e : scan)
+				idle_bytes += scan_bytes(e.w);
 		}
 		for (auto &e : m)
 			mf_workspace_destroy(e.w);
@@ -348,5 +527,12 @@ struct WorkspacePool {
 			scan_workspace_destroy(e.w);
 	}
 };
+
+inline void pools_release_device(int device)
+{
+	WorkspacePool::get().trim(device);
+	DevicePool::get().trim(device);
+}
+
 
 } // namespace lrzgpu
