@@ -159,7 +159,8 @@ def pmc_traffic(kernel, workload_key):
         return None, "PMC summary is for build %s, this is build %s: not reported" % (d.get("build_id"), build_id())
     if d.get("workload_key") != workload_key:
         return None, "PMC summary is for workload %s" % d.get("workload_key")
-    k = d.get("kernels", {}).get(kernel)
+    ks = d.get("kernels", {})
+    k = ks.get(kernel + "_mw") or ks.get(kernel)  # (the resolver runs as k_resolve_mw<NW> on 2 / 4 wavefronts)
     if not k:
         return None, "kernel not in the PMC summary"
     return int(k["bytes_per_launch"]), d.get("note", "")
@@ -415,9 +416,14 @@ def main():
         }
         if verified is not None:
             line["round_trip_ok"] = verified
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    # parked buffers, workspaces and streams go back before the process ends (a profiler wrapped around this
+    # command wants to see every queue closed)
+    del out
+    torch.cuda.synchronize()
+    L.lrzgpu_trim()
 
 
 if __name__ == "__main__":

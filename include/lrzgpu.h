@@ -300,7 +300,7 @@ int lrzgpu_file_info(const uint8_t *lrz, int64_t n, lrzgpu_info *info);
 /* ---- misc ------------------------------------------------------------------------------------- */
 /* Device workspaces, pinned and pageable host buffers are cached between calls (a compressor handles
  * block after block, file after file); this returns all of it to the system. */
-void lrzgpu_trim(void);
+void lrzgpu_trim(void); /* parked buffers, workspaces and streams back to the system */
 int lrzgpu_device_count(void);
 const char *lrzgpu_version(void);
 

@@ -87,6 +87,7 @@ extern "C" void lrzgpu_trim(void)
 	WorkspacePool::get().trim();
 	DevicePool::get().trim();
 	HostPool::get().trim();
+	StreamPool::get().destroy_idle();
 }
 
 namespace lrzgpu {

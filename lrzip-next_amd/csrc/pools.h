@@ -242,6 +242,23 @@ struct StreamPool {
 			}
 		// not one of ours: leave it alone (and alive)
 	}
+	void destroy_idle() // lrzgpu_trim(): for a caller about to exit (profilers want to see every queue closed)
+	{
+		std::vector<Entry> old;
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			old.swap(idle);
+			for (auto &e : old)
+				for (size_t i = 0; i < known.size(); i++)
+					if (known[i].s == e.s) {
+						known[i] = known.back();
+						known.pop_back();
+						break;
+					}
+		}
+		for (auto &e : old)
+			(void)hipStreamDestroy(e.s);
+	}
 };
 inline int current_device_or0()
 {
