@@ -138,10 +138,26 @@ def make_cfg3(n_bytes, base_bytes, seed, device, alphabet="alnum", mutate_every=
 
 
 def build_id():
-    """Identifies the kernels/host sources a PMC summary was measured for."""
-    h = hashlib.sha256()
+    """Identifies the DEVICE code a PMC summary was measured for: every .hip translation unit of csrc/ and the
+    local headers they include, transitively (HBM bytes per launch of a kernel are a property of the kernel and of
+    the workload key stored next to it; host-only sources -- parser, hashes, read side -- do not enter)."""
+    import re
     src = os.path.join(ROOT, "lrzip-next_amd", "csrc")
-    for p in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.cpp")) + glob.glob(os.path.join(src, "*.h"))):
+    todo = sorted(glob.glob(os.path.join(src, "*.hip")))
+    seen = []
+    while todo:
+        p = todo.pop(0)
+        if p in seen or not os.path.exists(p):
+            continue
+        seen.append(p)
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(p, encoding="utf-8", errors="replace").read(), re.M):
+            for base in (os.path.dirname(p), os.path.join(ROOT, "include")):
+                q = os.path.normpath(os.path.join(base, inc))
+                if os.path.exists(q):
+                    todo.append(q)
+                    break
+    h = hashlib.sha256()
+    for p in sorted(seen):
         h.update(os.path.basename(p).encode())
         h.update(open(p, "rb").read())
     return h.hexdigest()[:16]
