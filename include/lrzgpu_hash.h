@@ -1,0 +1,56 @@
+/* lrzgpu_hash.h -- container / front-end completeness: the whole-file hashes a .lrz may carry and
+ * the magic headers of every archive version the reference still reads.  Host-only entry points of liblrzgpu.so;
+ * kept apart from lrzgpu.h, which the device code includes. */
+#ifndef LRZGPU_HASH_H
+#define LRZGPU_HASH_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- hashes: `hashes[]` of src/main.c:64-79 (code = magic[14]; libgcrypt in the reference, src/rzip.c:943-950,
+ * 1195-1219; checked on the read side in src/runzip.c:352-440) -------------------------------------------------
+ * 0 CRC (4 bytes, nothing appended to the file), 1 MD5 (16), 2 RIPEMD-160 (20), 3 SHA-256 (32), 4 SHA-384 (48),
+ * 5 SHA-512 (64), 6 SHA3-256 (32), 7 SHA3-512 (64), 8-10 SHAKE128 with 16/32/64 bytes, 11-13 SHAKE256 with 16/32/64. */
+#define LRZGPU_HASH_MAX 13
+int lrzgpu_hash_length(int hash_code);        /* bytes, -1 for an unknown code */
+const char *lrzgpu_hash_label(int hash_code); /* "MD5", "SHA3_256", ... as the reference prints them */
+/* one shot; out must hold lrzgpu_hash_length(hash_code) (<= 64) bytes.  0 or LRZGPU_E_PARAM */
+int lrzgpu_hash_buffer(int hash_code, const uint8_t *data, int64_t n, uint8_t *out);
+/* streaming (the reference feeds its hash chunk by chunk from cksumthread, src/rzip.c:564-584) */
+void *lrzgpu_hash_open(int hash_code);
+int lrzgpu_hash_update(void *h, const uint8_t *data, int64_t n);
+int lrzgpu_hash_final(void *h, uint8_t *out); /* also closes h */
+
+/* The compress entry points append the reference's default, MD5.  This rewrites the trailer of such an image (or
+ * of any 0.14 image without encryption) for another hash code: magic[14] = hash_code, the old digest dropped,
+ * `digest` (lrzgpu_hash_length(hash_code) bytes of the UNCOMPRESSED data; ignored for code 0) appended.
+ * *out is malloc()ed. */
+int lrzgpu_set_file_hash(const uint8_t *lrz, int64_t n, int hash_code, const uint8_t *digest, uint8_t **out, int64_t *out_len);
+
+/* ---- read_magic()/get_magic() of src/lrzip.c:262-585 for archive versions 0.6 - 0.14 ------------------------------ */
+typedef struct lrzgpu_magic {
+	int major, minor;
+	int magic_len;          /* bytes of the header proper: 24 (0.6, 0.7), 18 (0.8), 20 (0.9, 0.10), 21 (0.11+) */
+	int64_t st_size;        /* expected uncompressed size; 0 when encrypted (the field holds the salt then) */
+	int enc_code;           /* 0 none, 1 AES128, 2 AES256 */
+	uint8_t salt[8];
+	int costfactor;         /* salt[0] */
+	int hash_code, hash_len; /* 0 / 0: chunk CRCs only */
+	int filter_flag;        /* 0 none, 1 x86, 2 ARM, 3 ARMT, 4 PPC, 5 SPARC, 6 IA64, 7 ARM64, 8 RISC-V, 128 delta */
+	int delta;              /* delta distance when filter_flag == 128 */
+	int ctype;              /* 0.11+: 0 none, 1 lzma, 2 zpaq, 3 bzip3, 4 zstd; older: 1 when lzma properties are stored, else 0 */
+	uint32_t dict_size;     /* lzma */
+	uint8_t lzma_properties[5];
+	int zpaq_bs, zpaq_level, bzip3_bs, zstd_strategy, zstd_level;
+	int level, rzip_level;  /* 0.9+ */
+	int comment_length;     /* 0.9+; the comment itself follows the header */
+	char comment[256];
+} lrzgpu_magic;
+/* 0, LRZGPU_E_FORMAT (not an lrzip file / unsupported version / invalid compression type) or LRZGPU_E_PARAM */
+int lrzgpu_read_magic(const uint8_t *lrz, int64_t n, lrzgpu_magic *m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -19,6 +19,7 @@
 
 #include "../../include/lrzgpu.h"
 #include "lzma_dec.h"
+#include "hashes.h"
 #include "md5.h"
 
 using namespace lrzgpu;
@@ -183,9 +184,11 @@ static int decompress_impl(const uint8_t *img, int64_t n, uint8_t **out, int64_t
 	if (img[15] || img[16]) // encryption salt / filters: not written by this library
 		return LRZGPU_E_PARAM;
 	const uint64_t st_size = val(img + 6, 8);
-	const bool md5 = img[14] == 1;
-	if (img[14] > 1)
-		return LRZGPU_E_PARAM; // other hashes
+	// the hash after the last chunk: any of the reference's (src/main.c:64-79); 0 = chunk CRCs only
+	const int hash_code = img[14];
+	const int hash_len = hash_code == 0 ? 0 : hash_length(hash_code);
+	if (hash_len < 0)
+		return LRZGPU_E_FORMAT;
 	const unsigned lc = 3, lp = 0, pb = 2; // LZMA_LC/LP/PB of src/stream.c:450-456
 	size_t pos = 21 + img[20];
 	struct FreeDeleter {
@@ -319,15 +322,15 @@ static int decompress_impl(const uint8_t *img, int64_t n, uint8_t **out, int64_t
 	}
 	if (!rc && at != st_size)
 		rc = LRZGPU_E_FORMAT;
-	if (!rc && md5) {
-		uint8_t dg[16];
-		if (pos + 16 != (size_t)n)
+	if (!rc && hash_len) {
+		uint8_t dg[64];
+		if (pos + (size_t)hash_len != (size_t)n)
 			rc = LRZGPU_E_FORMAT;
 		else {
-			Md5 m;
-			m.update(dst, (size_t)st_size);
-			m.finish(dg);
-			if (memcmp(dg, img + pos, 16) != 0)
+			std::unique_ptr<Hasher> m = make_hasher(hash_code);
+			m->update(dst, (size_t)st_size);
+			m->finish(dg);
+			if (memcmp(dg, img + pos, (size_t)hash_len) != 0)
 				rc = LRZGPU_E_FORMAT;
 		}
 	} else if (!rc && pos != (size_t)n)
