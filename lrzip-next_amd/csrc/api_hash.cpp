@@ -5,9 +5,34 @@
 
 #include "../../include/lrzgpu.h"
 #include "../../include/lrzgpu_hash.h"
+#include "filters.h"
 #include "hashes.h"
 
 using namespace lrzgpu;
+
+// ---- filters (src/stream.c:1587-1628 / 1926-1990) ---------------------------------------------------------------
+extern "C" int lrzgpu_filter_supported(int filter_flag, int delta) { return filter_supported(filter_flag, delta) ? 1 : 0; }
+extern "C" int lrzgpu_filter_block(int filter_flag, int delta, uint8_t *data, int64_t n, int encode)
+{
+	if (n < 0 || (n && !data))
+		return LRZGPU_E_PARAM;
+	return filter_block(filter_flag, delta, data, (size_t)n, encode != 0) == 0 ? 0 : LRZGPU_E_PARAM;
+}
+// magic[16] of an image (0.13+ coding: 128 + code of the delta distance, else the flag), trailer untouched
+extern "C" int lrzgpu_set_file_filter(uint8_t *lrz, int64_t n, int filter_flag, int delta)
+{
+	if (!lrz || n < 21 || memcmp(lrz, "LRZI", 4) != 0 || lrz[4] != 0 || lrz[5] < 13)
+		return LRZGPU_E_PARAM;
+	if (filter_flag == FILTER_DELTA) {
+		if (delta < 1 || delta > 256 || (delta > 16 && delta % 16))
+			return LRZGPU_E_PARAM;
+		lrz[16] = (uint8_t)(128 + (delta <= 16 ? delta : delta / 16 + 15)); // write_magic, src/lrzip.c:148-156
+	} else if (filter_flag >= 0 && filter_flag <= 8)
+		lrz[16] = (uint8_t)filter_flag;
+	else
+		return LRZGPU_E_PARAM;
+	return 0;
+}
 
 extern "C" int lrzgpu_hash_length(int hash_code) { return hash_length(hash_code); }
 extern "C" const char *lrzgpu_hash_label(int hash_code) { return hash_label(hash_code); }

@@ -1,0 +1,249 @@
+// filters.cpp -- the executable-code and delta filters lrzip-next may run over a literal block before its back end
+// and undo after it (src/stream.c:1587-1628 compress side, 1926-1990 decompress side; the converters themselves are
+// the LZMA SDK's src/lzma/C/Bra.c, Bra86.c, Delta.c).  Host code, written from what the converters DO -- a branch
+// instruction's relative target becomes absolute (relative to the start of the block: the reference always starts a
+// block at pc = 0 with a fresh x86 state) -- one plain loop per instruction set; checked byte for byte against the
+// reference's converters compiled unmodified into oracle/_ref (tests/test_filters_cpu.py).
+//
+// Position independence: ARM, ARM64, PPC, SPARC (one aligned 32-bit word each), Thumb (two halfwords that cannot
+// overlap another pair), IA-64 (one 16-byte bundle) and the delta ENcoder convert every unit from its own bytes and
+// its own offset only -- those are the GPU kernels of the next step; x86 carries a three-bit history of the bytes just
+// passed and the delta DEcoder is a running sum.
+#include "filters.h"
+
+#include <cstring>
+
+namespace lrzgpu {
+namespace {
+
+inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+inline void put_le32(uint8_t *p, uint32_t v)
+{
+	p[0] = (uint8_t)v;
+	p[1] = (uint8_t)(v >> 8);
+	p[2] = (uint8_t)(v >> 16);
+	p[3] = (uint8_t)(v >> 24);
+}
+inline uint32_t be32(const uint8_t *p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | (uint32_t)p[3]; }
+inline void put_be32(uint8_t *p, uint32_t v)
+{
+	p[0] = (uint8_t)(v >> 24);
+	p[1] = (uint8_t)(v >> 16);
+	p[2] = (uint8_t)(v >> 8);
+	p[3] = (uint8_t)v;
+}
+inline uint32_t shift_by(uint32_t v, uint32_t c, bool enc) { return enc ? v + c : v - c; }
+
+// ARM (A32): BL, condition "always": the top byte of the little-endian word is 0xEB; 24-bit word offset relative to
+// the instruction + 8
+void arm(uint8_t *d, size_t n, bool enc)
+{
+	for (size_t i = 0; i + 4 <= n; i += 4)
+		if (d[i + 3] == 0xEB) {
+			const uint32_t v = shift_by(le32(d + i), (uint32_t)(i + 8) >> 2, enc);
+			put_le32(d + i, (v & 0x00FFFFFFu) | 0xEB000000u);
+		}
+}
+
+// Thumb: BL as a pair of halfwords 11110 imm11 / 11111 imm11: 22-bit halfword offset relative to the pair + 4.
+// A converted pair is stepped over as a whole (its second half cannot start another one: 11111 is not 11110).
+void armt(uint8_t *d, size_t n, bool enc)
+{
+	n &= ~(size_t)1;
+	for (size_t i = 0; i + 4 <= n; i += 2) {
+		if ((d[i + 1] & 0xF8) != 0xF0 || (d[i + 3] & 0xF8) != 0xF8)
+			continue;
+		uint32_t v = ((uint32_t)(d[i + 1] & 7) << 19) | ((uint32_t)d[i] << 11) | ((uint32_t)(d[i + 3] & 7) << 8) | d[i + 2];
+		v = shift_by(v, (uint32_t)(i + 4) >> 1, enc);
+		d[i + 1] = (uint8_t)(0xF0 | ((v >> 19) & 7));
+		d[i] = (uint8_t)(v >> 11);
+		d[i + 3] = (uint8_t)(0xF8 | ((v >> 8) & 7));
+		d[i + 2] = (uint8_t)v;
+		i += 2;
+	}
+}
+
+// PowerPC: bl (opcode 18, AA = 0, LK = 1) in a big-endian word; byte offset relative to the instruction
+void ppc(uint8_t *d, size_t n, bool enc)
+{
+	for (size_t i = 0; i + 4 <= n; i += 4) {
+		const uint32_t w = be32(d + i);
+		if ((w & 0xFC000003u) != 0x48000001u)
+			continue;
+		const uint32_t v = shift_by(w, (uint32_t)i, enc);
+		put_be32(d + i, (v & 0x03FFFFFFu) | 0x48000000u);
+	}
+}
+
+// SPARC: call (01 disp30) whose 30-bit word displacement is a sign-extended 22-bit value (the top ten bits are
+// 0100000000 or 0111111111); the converted value is brought back to that shape
+void sparc(uint8_t *d, size_t n, bool enc)
+{
+	for (size_t i = 0; i + 4 <= n; i += 4) {
+		const uint32_t top = ((uint32_t)d[i] << 2) | (d[i + 1] >> 6);
+		if (top != 0x100 && top != 0x1FF)
+			continue;
+		uint32_t v = be32(d + i) << 2;
+		v = shift_by(v, (uint32_t)i, enc) >> 2;
+		v = (((0u - ((v >> 22) & 1)) << 22) & 0x3FFFFFFFu) | (v & 0x3FFFFFu) | 0x40000000u;
+		put_be32(d + i, v);
+	}
+}
+
+// ARM64: BL (100101 imm26, word offset relative to the instruction) and ADRP (1 immlo 10000 immhi Rd, page offset
+// relative to the instruction's page) when the page offset is within +-2^20 pages... of 8 (the converter works on
+// the 21-bit immediate scaled by 8: immhi in bits 5..23 kept in place, immlo moved to bits 3..4)
+void arm64(uint8_t *d, size_t n, bool enc)
+{
+	const uint32_t flag = 1u << 20, mask = (1u << 24) - (flag << 1);
+	for (size_t i = 0; i + 4 <= n; i += 4) {
+		uint32_t v = le32(d + i);
+		if (((v - 0x94000000u) & 0xFC000000u) == 0) {
+			v = shift_by(v, (uint32_t)i >> 2, enc);
+			put_le32(d + i, (v & 0x03FFFFFFu) | 0x94000000u);
+			continue;
+		}
+		v -= 0x90000000u;
+		if ((v & 0x9F000000u) != 0)
+			continue;
+		v += flag;
+		if (v & mask)
+			continue;
+		uint32_t z = (v & 0xFFFFFFE0u) | (v >> 26);
+		z = shift_by(z, ((uint32_t)i >> 9) & ~7u, enc);
+		v &= 0x1F;
+		v |= 0x90000000u;
+		v |= z << 26;
+		v |= 0x00FFFFE0u & ((z & ((flag << 1) - 1)) - flag);
+		put_le32(d + i, v);
+	}
+}
+
+// IA-64: a 16-byte bundle = 5 template bits + three 41-bit slots; the template says which slots hold a branch unit
+// instruction; br.call (opcode 5, btype 0) carries a 21-bit bundle offset (imm20b at bits 13..32, sign at 36)
+void ia64(uint8_t *d, size_t n, bool enc)
+{
+	static const uint8_t branch_slots[32] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 6, 6, 0, 0, 7, 7, 4, 4, 0, 0, 4, 4, 0, 0};
+	for (size_t i = 0; i + 16 <= n; i += 16) {
+		const unsigned m = branch_slots[d[i] & 0x1F];
+		for (unsigned slot = 0, bit = 5; slot < 3; slot++, bit += 41) {
+			if (!((m >> slot) & 1))
+				continue;
+			uint8_t *p = d + i + (bit >> 3);
+			const unsigned sh = bit & 7;
+			uint64_t raw = 0;
+			for (int k = 0; k < 6; k++)
+				raw |= (uint64_t)p[k] << (8 * k);
+			uint64_t ins = raw >> sh;
+			if (((ins >> 37) & 0xF) != 0x5 || ((ins >> 9) & 0x7) != 0)
+				continue;
+			uint32_t v = (uint32_t)((ins >> 13) & 0xFFFFF) | ((uint32_t)(ins >> 36) & 1) << 20;
+			v = shift_by(v << 4, (uint32_t)i, enc) >> 4;
+			ins &= ~((uint64_t)0x8FFFFF << 13);
+			ins |= (uint64_t)(v & 0xFFFFF) << 13;
+			ins |= (uint64_t)(v & 0x100000) << (36 - 20);
+			raw = (raw & (((uint64_t)1 << sh) - 1)) | (ins << sh);
+			for (int k = 0; k < 6; k++)
+				p[k] = (uint8_t)(raw >> (8 * k));
+		}
+	}
+}
+
+// x86: CALL / JMP rel32 (E8 / E9) whose top byte is 00 or FF -- a plausible code offset; `recent` remembers which of
+// the last three bytes were E8/E9 themselves (an opcode byte inside the operand of another candidate makes both
+// suspect: such candidates are skipped or tested on the byte the earlier one would have covered)
+inline bool sign_byte(unsigned b) { return b == 0x00 || b == 0xFF; }
+void x86(uint8_t *d, size_t n, bool enc)
+{
+	if (n < 5)
+		return;
+	const size_t limit = n - 4; // a candidate needs its four operand bytes
+	unsigned recent = 0;
+	size_t pos = 0;
+	for (;;) {
+		size_t p = pos;
+		while (p < limit && (d[p] & 0xFE) != 0xE8)
+			p++;
+		const size_t gap = p - pos;
+		pos = p;
+		if (p >= limit)
+			return;
+		if (gap > 2)
+			recent = 0;
+		else {
+			recent >>= gap;
+			if (recent != 0 && (recent > 4 || recent == 3 || sign_byte(d[p + (recent >> 1) + 1]))) {
+				recent = (recent >> 1) | 4;
+				pos++;
+				continue;
+			}
+		}
+		if (sign_byte(d[p + 4])) {
+			uint32_t v = le32(d + p + 1);
+			const uint32_t cur = (uint32_t)pos + 5;
+			pos += 5;
+			v = shift_by(v, cur, enc);
+			if (recent != 0) {
+				const unsigned sh = (recent & 6) << 2;
+				if (sign_byte((uint8_t)(v >> sh))) {
+					v ^= ((uint32_t)0x100 << sh) - 1;
+					v = shift_by(v, cur, enc);
+				}
+				recent = 0;
+			}
+			d[p + 1] = (uint8_t)v;
+			d[p + 2] = (uint8_t)(v >> 8);
+			d[p + 3] = (uint8_t)(v >> 16);
+			d[p + 4] = (uint8_t)(0 - ((v >> 24) & 1));
+		} else {
+			recent = (recent >> 1) | 4;
+			pos++;
+		}
+	}
+}
+
+// delta: every byte minus the byte `dist` before it (zero history at the start of a block)
+void delta_enc(uint8_t *d, size_t n, unsigned dist)
+{
+	for (size_t i = n; i-- > dist;)
+		d[i] = (uint8_t)(d[i] - d[i - dist]);
+}
+void delta_dec(uint8_t *d, size_t n, unsigned dist)
+{
+	for (size_t i = dist; i < n; i++)
+		d[i] = (uint8_t)(d[i] + d[i - dist]);
+}
+
+} // namespace
+
+bool filter_supported(int flag, int delta)
+{
+	if (flag == FILTER_DELTA)
+		return delta >= 1 && delta <= 256;
+	return flag >= FILTER_X86 && flag <= FILTER_ARM64;
+}
+
+int filter_block(int flag, int delta, uint8_t *data, size_t n, bool encode)
+{
+	if (!filter_supported(flag, delta) || (n && !data))
+		return -1;
+	switch (flag) {
+	case FILTER_X86: x86(data, n, encode); break;
+	case FILTER_ARM: arm(data, n, encode); break;
+	case FILTER_ARMT: armt(data, n, encode); break;
+	case FILTER_PPC: ppc(data, n, encode); break;
+	case FILTER_SPARC: sparc(data, n, encode); break;
+	case FILTER_IA64: ia64(data, n, encode); break;
+	case FILTER_ARM64: arm64(data, n, encode); break;
+	case FILTER_DELTA:
+		if (encode)
+			delta_enc(data, n, (unsigned)delta);
+		else
+			delta_dec(data, n, (unsigned)delta);
+		break;
+	default: return -1;
+	}
+	return 0;
+}
+
+} // namespace lrzgpu

@@ -19,6 +19,7 @@
 
 #include "../../include/lrzgpu.h"
 #include "lzma_dec.h"
+#include "filters.h"
 #include "hashes.h"
 #include "md5.h"
 
@@ -105,8 +106,10 @@ size_t zstd_decompress(void *dst, size_t cap, const void *src, size_t n, bool *o
 // one stream of a chunk -> its bytes; blocks are decoded by `nthreads` workers
 // `limit`: the most bytes this stream can legitimately hold (derived from the file size in the magic);
 // every length here comes from the untrusted image, so sums are checked before they can wrap
+// `filter` / `delta`: the filter to undo on every block after its back end (literal stream only,
+// src/stream.c:1926-1990; stored blocks hold filtered bytes too)
 int stream_bytes(const uint8_t *img, const std::vector<Block> &blocks, unsigned lc, unsigned lp, unsigned pb, int nthreads,
-		 size_t limit, std::vector<uint8_t> *out)
+		 size_t limit, std::vector<uint8_t> *out, int filter = 0, int delta = 0)
 {
 	size_t total = 0;
 	std::vector<size_t> at(blocks.size());
@@ -143,6 +146,8 @@ int stream_bytes(const uint8_t *img, const std::vector<Block> &blocks, unsigned 
 					err = LRZGPU_E_FORMAT;
 			} else
 				err = LRZGPU_E_PARAM; // other back ends are outside this library
+			if (filter && !err.load() && filter_block(filter, delta, out->data() + at[i], b.u_len, false) != 0)
+				err = LRZGPU_E_PARAM;
 		}
 		} catch (const std::bad_alloc &) { // thread body: nothing may escape
 			err = LRZGPU_E_NOMEM;
@@ -181,7 +186,18 @@ static int decompress_impl(const uint8_t *img, int64_t n, uint8_t **out, int64_t
 		return LRZGPU_E_PARAM;
 	if (memcmp(img, "LRZI", 4) != 0 || img[4] != 0 || img[5] != 14)
 		return LRZGPU_E_FORMAT;
-	if (img[15] || img[16]) // encryption salt / filters: not written by this library
+	if (img[15]) // encryption: outside this library
+		return LRZGPU_E_PARAM;
+	// filter on the literal stream (magic[16], get_filter() of src/lrzip.c:304-338 for 0.13+): bit 7 = delta with
+	// its distance 1..16, 32, 48 ... 256 coded as 1..31
+	int filter = 0, delta = 0;
+	if (img[16] > 128) {
+		const int i = img[16] - 128;
+		filter = FILTER_DELTA;
+		delta = i <= 16 ? i : (i - 15) * 16;
+	} else
+		filter = img[16];
+	if (filter && !filter_supported(filter, delta))
 		return LRZGPU_E_PARAM;
 	const uint64_t st_size = val(img + 6, 8);
 	// the hash after the last chunk: any of the reference's (src/main.c:64-79); 0 = chunk CRCs only
@@ -258,7 +274,7 @@ static int decompress_impl(const uint8_t *img, int64_t n, uint8_t **out, int64_t
 			break;
 		}
 		if ((rc = stream_bytes(img, blocks[0], lc, lp, pb, host_threads, 12 * left + 4096, &s0)) != 0 ||
-		    (rc = stream_bytes(img, blocks[1], lc, lp, pb, host_threads, left, &s1)) != 0)
+		    (rc = stream_bytes(img, blocks[1], lc, lp, pb, host_threads, left, &s1, filter, delta)) != 0)
 			break;
 		// token replay
 		size_t i = 0, lit = 0;
