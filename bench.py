@@ -439,7 +439,8 @@ def main():
     # command wants to see every queue closed)
     del out
     torch.cuda.synchronize()
-    L.lrzgpu_trim()
+    L.lrzgpu_shutdown.restype = None
+    L.lrzgpu_shutdown()
 
 
 if __name__ == "__main__":

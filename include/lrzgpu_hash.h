@@ -61,6 +61,11 @@ int lrzgpu_filter_block(int filter_flag, int delta, uint8_t *data, int64_t n, in
 /* sets magic[16] of a 0.13+ image in place (for images whose literal blocks were filtered by the caller) */
 int lrzgpu_set_file_filter(uint8_t *lrz, int64_t n, int filter_flag, int delta);
 
+/* ---- misc ------------------------------------------------------------------------------------------------------
+ * lrzgpu_trim() (lrzgpu.h) returns parked buffers and workspaces; the streams the library parks instead of destroying
+ * stay open.  lrzgpu_shutdown() = lrzgpu_trim() + those streams closed: once, before exit(). */
+void lrzgpu_shutdown(void);
+
 #ifdef __cplusplus
 }
 #endif

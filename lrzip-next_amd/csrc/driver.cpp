@@ -87,6 +87,14 @@ extern "C" void lrzgpu_trim(void)
 	WorkspacePool::get().trim();
 	DevicePool::get().trim();
 	HostPool::get().trim();
+}
+
+// lrzgpu_trim() plus the parked streams: for a caller that is about to exit (profilers want every queue closed).
+// Not for use between files: a later allocation in the same process can trip the runtime over the closed queues
+// (pools.h, DeviceBudget).
+extern "C" void lrzgpu_shutdown(void)
+{
+	lrzgpu_trim();
 	StreamPool::get().destroy_idle();
 }
 
