@@ -61,6 +61,16 @@ int lrzgpu_filter_block(int filter_flag, int delta, uint8_t *data, int64_t n, in
 /* sets magic[16] of a 0.13+ image in place (for images whose literal blocks were filtered by the caller) */
 int lrzgpu_set_file_filter(uint8_t *lrz, int64_t n, int filter_flag, int delta);
 
+/* ---- scan access hooks: what control->full_tag / next_tag / match_len compute in the reference's
+ * non-sliding mode (src/rzip.c:385-393, 405-416, 431-461), over a plain host buffer.  The accelerated forms are
+ * lrzgpu_hash_search* (every tag of a chunk in k_tag_scan, match verification inside the resolver); these are the
+ * per-position meanings, for a caller that keeps its own loop. */
+uint64_t lrzgpu_full_tag(const uint8_t *buf, int64_t p);             /* XOR of hash_index[buf[p .. p + 30]] */
+uint64_t lrzgpu_next_tag(const uint8_t *buf, int64_t p, uint64_t t); /* tag at p from the tag at p - 1 */
+/* equal bytes forwards from (p0, op) up to `end` plus backwards down to max(0, last_match); 0 if fewer than 31;
+ * *rev = the backward part */
+int64_t lrzgpu_match_len(const uint8_t *buf, int64_t p0, int64_t op, int64_t end, int64_t last_match, int64_t *rev);
+
 /* ---- misc ------------------------------------------------------------------------------------------------------
  * lrzgpu_trim() (lrzgpu.h) returns parked buffers and workspaces; the streams the library parks instead of destroying
  * stay open.  lrzgpu_shutdown() = lrzgpu_trim() + those streams closed: once, before exit(). */

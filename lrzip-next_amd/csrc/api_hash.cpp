@@ -10,6 +10,50 @@
 
 using namespace lrzgpu;
 
+// ---- scan access hooks: control->full_tag / next_tag / match_len of the non-sliding mode (src/rzip.c:385-393,
+// 405-416, 431-461; installed at 1036-1039) over a plain buffer -- the host-side meaning of what k_tag_scan and the
+// resolver's match verification compute for whole chunks
+extern "C" void lrzgpu_hash_index(uint64_t out[256]);
+namespace {
+const uint64_t *tag_table()
+{
+	static uint64_t t[256];
+	static const bool once = (lrzgpu_hash_index(t), true);
+	(void)once;
+	return t;
+}
+} // namespace
+extern "C" uint64_t lrzgpu_full_tag(const uint8_t *buf, int64_t p)
+{
+	const uint64_t *hx = tag_table();
+	uint64_t t = 0;
+	for (int i = 0; i < 31; i++) // MINIMUM_MATCH
+		t ^= hx[buf[p + i]];
+	return t;
+}
+extern "C" uint64_t lrzgpu_next_tag(const uint8_t *buf, int64_t p, uint64_t t)
+{
+	const uint64_t *hx = tag_table();
+	return t ^ hx[buf[p - 1]] ^ hx[buf[p + 31 - 1]];
+}
+extern "C" int64_t lrzgpu_match_len(const uint8_t *buf, int64_t p0, int64_t op, int64_t end, int64_t last_match, int64_t *rev)
+{
+	if (rev)
+		*rev = 0;
+	if (op >= p0)
+		return 0;
+	int64_t fwd = 0;
+	while (p0 + fwd < end && buf[p0 + fwd] == buf[op + fwd])
+		fwd++;
+	const int64_t floor_p = last_match > 0 ? last_match : 0;
+	int64_t back = 0;
+	while (p0 - back > floor_p && op - back > 0 && buf[op - back - 1] == buf[p0 - back - 1])
+		back++;
+	if (rev)
+		*rev = back;
+	return fwd + back < 31 ? 0 : fwd + back;
+}
+
 // ---- filters (src/stream.c:1587-1628 / 1926-1990) ---------------------------------------------------------------
 extern "C" int lrzgpu_filter_supported(int filter_flag, int delta) { return filter_supported(filter_flag, delta) ? 1 : 0; }
 extern "C" int lrzgpu_filter_block(int filter_flag, int delta, uint8_t *data, int64_t n, int encode)

@@ -208,3 +208,47 @@ def test_read_magic_older_versions(L):
     assert _magic(L, _hdr(5, 24))[0] != 0 and _magic(L, _hdr(15, 21))[0] != 0
     assert _magic(L, _hdr(14, 21, b17=9))[0] != 0
     assert _magic(L, _hdr(14, 21)[:20])[0] != 0
+
+
+def test_scan_access_hooks(B, O, L):
+    """lrzgpu_full_tag / next_tag / match_len == single_full_tag / single_next_tag / single_match_len of src/rzip.c:
+    the tag is the XOR of the frozen hash_index[] over 31 bytes, rolled one byte at a time; match lengths against a
+    brute-force count; and the tags at the positions of the oracle's matches agree between source and destination."""
+    hx = O.hash_index()
+    L.lrzgpu_full_tag.restype = C.c_uint64
+    L.lrzgpu_full_tag.argtypes = [C.c_char_p, C.c_int64]
+    L.lrzgpu_next_tag.restype = C.c_uint64
+    L.lrzgpu_next_tag.argtypes = [C.c_char_p, C.c_int64, C.c_uint64]
+    L.lrzgpu_match_len.restype = C.c_int64
+    L.lrzgpu_match_len.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_int64)]
+    data = datagen.long_range(200000, seed=12, base_frac=0.5, mutate_every=7001)
+    n = len(data)
+
+    def tag(p):
+        t = 0
+        for i in range(31):
+            t ^= int(hx[data[p + i]])
+        return t
+    t = L.lrzgpu_full_tag(data, 0)
+    assert t == tag(0)
+    for p in range(1, 3000):
+        t = L.lrzgpu_next_tag(data, p, t)
+        if p % 97 == 0 or p < 40:
+            assert t == tag(p) == L.lrzgpu_full_tag(data, p)
+    rnd = random.Random(5)
+    half = n // 2
+    end = n - 31
+    for _ in range(300):
+        p0 = rnd.randrange(half + 100, end)
+        op = p0 - half if rnd.random() < 0.7 else rnd.randrange(0, p0)
+        last = rnd.choice([0, -1, p0 - 5, p0 - 40, half])
+        f = 0
+        while p0 + f < end and data[p0 + f] == data[op + f]:
+            f += 1
+        b = 0
+        while p0 - b > max(0, last) and op - b > 0 and data[op - b - 1] == data[p0 - b - 1]:
+            b += 1
+        want = f + b if f + b >= 31 else 0
+        rev = C.c_int64(-1)
+        assert L.lrzgpu_match_len(data, p0, op, end, last, C.byref(rev)) == want and rev.value == b
+    assert L.lrzgpu_match_len(data, 100, 100, end, 0, None) == 0 and L.lrzgpu_match_len(data, 100, 200, end, 0, None) == 0
