@@ -53,7 +53,7 @@ int lrzgpu_read_magic(const uint8_t *lrz, int64_t n, lrzgpu_magic *m);
 /* ---- filters on the literal stream (src/stream.c:1587-1628 before the back end, 1926-1990 after it;
  * converters: src/lzma/C/Bra.c, Bra86.c, Delta.c) -- host implementations, checked against the reference's own
  * converters; the read side (lrzgpu_decompress_*) undoes them on every stream-1 block.  filter_flag as in magic[16]:
- * 1 x86, 2 ARM, 3 ARMT, 4 PPC, 5 SPARC, 6 IA64, 7 ARM64, (8 RISC-V: not yet), 128 delta with distance `delta`
+ * 1 x86, 2 ARM, 3 ARMT, 4 PPC, 5 SPARC, 6 IA64, 7 ARM64, 8 RISC-V, 128 delta with distance `delta`
  * (1..16, 32, 48 ... 256).  The compress entry points do not filter yet (control has no filter field). */
 int lrzgpu_filter_supported(int filter_flag, int delta);
 /* one block in place, from pc 0 with a fresh x86 state like compthread does; encode != 0: the compress direction */

@@ -8,7 +8,7 @@
 // Position independence: ARM, ARM64, PPC, SPARC (one aligned 32-bit word each), Thumb (two halfwords that cannot
 // overlap another pair), IA-64 (one 16-byte bundle) and the delta ENcoder convert every unit from its own bytes and
 // its own offset only -- those are the GPU kernels of the next step; x86 carries a three-bit history of the bytes just
-// passed and the delta DEcoder is a running sum.
+// passed, RISC-V steps over what it converts (4 or 8 bytes) and the delta DEcoder is a running sum.
 #include "filters.h"
 
 #include <cstring>
@@ -202,6 +202,86 @@ void x86(uint8_t *d, size_t n, bool enc)
 	}
 }
 
+// RISC-V (2-byte aligned scan over 16-bit parcels whose low seven bits are the JAL or the AUIPC opcode):
+//  * JAL with rd = x1 or x5 (a call): the 20-bit byte offset, scattered over bits 12..31, becomes the absolute
+//    address, stored most significant bits first in bytes 1 (high nibble), 2, 3;
+//  * AUIPC rd, hi followed by a 32-bit instruction that reads rd (rs1 == rd, rd not x0 / x2): the pair's 32-bit
+//    pc-relative offset becomes an absolute address stored big-endian in the second word, and the first word becomes
+//    the marker "AUIPC x2" whose upper twenty bits carry the second instruction's lower twenty;
+//  * an AUIPC x2 of the input that could be mistaken for that marker (bits 12, 13 set, top five bits not 0 / 2) is
+//    escaped by trading fields with the word after it, so that the decoder meets an AUIPC whose rd is those five bits.
+// The decoder tells the three apart by the same tests and undoes each.
+inline uint32_t le16(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8; }
+inline bool rv_pair(uint32_t key, uint32_t next) { return (((next - 3) ^ (key << 8)) & 0xF8003u) == 0; } // 32-bit instruction whose rs1 is the AUIPC's rd
+inline bool rv_marker_like(uint32_t key, uint32_t top5) { return (uint32_t)((key - 0x3108u) << 18) < (top5 & 0x1Du); }
+void riscv(uint8_t *d, size_t n, bool enc)
+{
+	n &= ~(size_t)1;
+	if (n <= 6)
+		return;
+	const size_t lim = n - 6;
+	size_t i = 0;
+	while (i < lim) {
+		const uint32_t key = (le16(d + i) ^ 0x10u) + 1; // low 7 bits 0 <=> opcode 0x6F (JAL) or 0x17 (AUIPC); bits 7..11 = rd
+		if (key & 0x77) {
+			i += 2;
+			continue;
+		}
+		uint8_t *p = d + i;
+		const uint32_t a = le32(p);
+		if (!(key & 8)) { // JAL
+			if ((key - 0x100) & 0xD80) { // rd is neither x1 nor x5
+				i += 2;
+				continue;
+			}
+			if (enc) {
+				uint32_t v = ((a & 0x80000000u) >> 11) | ((a & (0x3FFu << 21)) >> 20) | ((a & (1u << 20)) >> 9) | (a & (0xFFu << 12));
+				v += (uint32_t)i;
+				p[1] = (uint8_t)(((v >> 13) & 0xF0) | ((a >> 8) & 0xF));
+				p[2] = (uint8_t)(v >> 9);
+				p[3] = (uint8_t)(v >> 1);
+			} else {
+				uint32_t v = ((uint32_t)p[3] << 1) | ((uint32_t)p[2] << 9) | ((uint32_t)(p[1] & 0xF0) << 13);
+				v -= (uint32_t)i;
+				put_le32(p, (a & 0xFFF) | ((v << 11) & 0x80000000u) | ((v << 20) & (0x3FFu << 21)) | ((v << 9) & (1u << 20)) | (v & (0xFFu << 12)));
+			}
+			i += 4;
+			continue;
+		}
+		// AUIPC
+		const uint32_t next = le32(p + 4);
+		if (key & 0xE80) { // rd is neither x0 nor x2
+			if (!rv_pair(key, next)) {
+				i += 6;
+				continue;
+			}
+			if (enc) {
+				put_le32(p, (next << 12) | 0x117u);
+				put_be32(p + 4, (a & 0xFFFFF000u) + (uint32_t)((int32_t)next >> 20) + (uint32_t)i);
+			} else { // an escaped AUIPC x2 of the original: give the fields back
+				put_le32(p, (next << 12) | 0x117u);
+				put_le32(p + 4, (a & 0xFFFFF000u) | (next >> 20));
+			}
+			i += 8;
+		} else {
+			const uint32_t top5 = a >> 27;
+			if (!rv_marker_like(key, top5)) {
+				i += 4;
+				continue;
+			}
+			if (enc) { // looks like the marker: escape it
+				put_le32(p, (top5 << 7) + 0x17u + (next & 0xFFFFF000u));
+				put_le32(p + 4, (a >> 12) | (next << 20));
+			} else { // the marker: the pair comes back from the absolute address
+				const uint32_t off = be32(p + 4) - (uint32_t)i;
+				put_le32(p, (top5 << 7) + 0x17u + ((off + 0x800u) & 0xFFFFF000u));
+				put_le32(p + 4, (a >> 12) | (off << 20));
+			}
+			i += 8;
+		}
+	}
+}
+
 // delta: every byte minus the byte `dist` before it (zero history at the start of a block)
 void delta_enc(uint8_t *d, size_t n, unsigned dist)
 {
@@ -220,7 +300,7 @@ bool filter_supported(int flag, int delta)
 {
 	if (flag == FILTER_DELTA)
 		return delta >= 1 && delta <= 256;
-	return flag >= FILTER_X86 && flag <= FILTER_ARM64;
+	return flag >= FILTER_X86 && flag <= FILTER_RISCV;
 }
 
 int filter_block(int flag, int delta, uint8_t *data, size_t n, bool encode)
@@ -235,6 +315,7 @@ int filter_block(int flag, int delta, uint8_t *data, size_t n, bool encode)
 	case FILTER_SPARC: sparc(data, n, encode); break;
 	case FILTER_IA64: ia64(data, n, encode); break;
 	case FILTER_ARM64: arm64(data, n, encode); break;
+	case FILTER_RISCV: riscv(data, n, encode); break;
 	case FILTER_DELTA:
 		if (encode)
 			delta_enc(data, n, (unsigned)delta);

@@ -14,7 +14,7 @@ enum FilterFlag {
 	FILTER_SPARC = 5,
 	FILTER_IA64 = 6,
 	FILTER_ARM64 = 7,
-	FILTER_RISCV = 8, // not implemented yet
+	FILTER_RISCV = 8,
 	FILTER_DELTA = 128
 };
 

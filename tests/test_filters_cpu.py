@@ -13,7 +13,7 @@ import datagen
 
 RAM = 80 * 100 * 1048576
 X86, ARM, ARMT, PPC, SPARC, IA64, ARM64, RISCV, DELTA = 1, 2, 3, 4, 5, 6, 7, 8, 128
-REF_NAME = {ARM: "ARM", ARMT: "ARMT", PPC: "PPC", SPARC: "SPARC", IA64: "IA64", ARM64: "ARM64"}
+REF_NAME = {ARM: "ARM", ARMT: "ARMT", PPC: "PPC", SPARC: "SPARC", IA64: "IA64", ARM64: "ARM64", RISCV: "RISCV"}
 
 
 @pytest.fixture(scope="module")
@@ -112,10 +112,30 @@ def code_like(flag, n, seed):
                     ins = (ins & ~(0xF << 37) & ~(0x7 << 9)) | (5 << 37)
                     v = (v & ~(((1 << 41) - 1) << bit)) | (ins << bit)
                     out[i:i + 16] = v.to_bytes(16, "little")
+    elif flag == RISCV:
+        i = 0
+        while i + 8 <= n:
+            r = rnd.random()
+            if r < 0.25:  # JAL with assorted link registers (x1 and x5 are the calls)
+                rd = rnd.choice([1, 5, 1, 5, 0, 2, 3, 9, 31])
+                struct.pack_into("<I", out, i, (rnd.getrandbits(20) << 12) | (rd << 7) | 0x6F)
+                i += 4
+            elif r < 0.55:  # AUIPC + an instruction that may or may not read its rd; AUIPC x2 that looks like the marker
+                rd = rnd.choice([1, 3, 5, 6, 7, 10, 17, 31, 0, 2, 2, 2])
+                hi = rnd.getrandbits(20)
+                if rd == 2 and rnd.random() < 0.6:
+                    hi |= 3
+                struct.pack_into("<I", out, i, (hi << 12) | (rd << 7) | 0x17)
+                rs1 = rd if rnd.random() < 0.7 else rnd.randrange(32)
+                op = rnd.choice([0x67, 0x13, 0x03, 0x23, 0x33, 0x01, 0x02])
+                struct.pack_into("<I", out, i + 4, (rnd.getrandbits(12) << 20) | (rs1 << 15) | (rnd.getrandbits(3) << 12) | (rnd.getrandbits(5) << 7) | op)
+                i += 8
+            else:
+                i += 2 if r < 0.7 else 4
     return bytes(out)
 
 
-@pytest.mark.parametrize("flag", [X86, ARM, ARMT, PPC, SPARC, IA64, ARM64])
+@pytest.mark.parametrize("flag", [X86, ARM, ARMT, PPC, SPARC, IA64, ARM64, RISCV])
 def test_bcj_filters_equal_reference(B, R, flag):
     for seed, n in enumerate([0, 1, 2, 3, 4, 5, 6, 7, 8, 15, 16, 17, 31, 32, 33, 63, 64, 100, 1001, 4096, 65537, 300003]):
         for data in (code_like(flag, n, seed), datagen.KINDS["random"](n, seed=seed) if n else b"", bytes([0xE8, 0, 0, 0, 0] * (n // 5))[:n]):
@@ -149,12 +169,13 @@ def test_unsupported_filters_are_refused(B):
     L = B.lib()
     L.lrzgpu_filter_block.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int64, C.c_int]
     buf = C.create_string_buffer(64)
-    for flag, delta in ((RISCV, 0), (9, 0), (0, 0), (-1, 0), (DELTA, 0), (DELTA, 257)):
+    for flag, delta in ((9, 0), (0, 0), (-1, 0), (127, 0), (DELTA, 0), (DELTA, 257)):
         assert L.lrzgpu_filter_supported(flag, delta) == 0
         assert L.lrzgpu_filter_block(flag, delta, buf, 64, 1) != 0
 
 
-@pytest.mark.parametrize("flag,delta", [(X86, 0), (ARM, 0), (ARMT, 0), (PPC, 0), (SPARC, 0), (IA64, 0), (ARM64, 0), (DELTA, 1), (DELTA, 4), (DELTA, 48)])
+@pytest.mark.parametrize("flag,delta", [(X86, 0), (ARM, 0), (ARMT, 0), (PPC, 0), (SPARC, 0), (IA64, 0), (ARM64, 0), (RISCV, 0), (DELTA, 1), (DELTA, 4),
+                                        (DELTA, 48)])
 def test_read_side_undoes_the_filter(B, O, flag, delta):
     """A -n image (stored blocks) whose literal blocks were filtered one by one the way compthread does it and whose
     magic[16] names the filter decodes to the original; with the wrong flag it does not."""
