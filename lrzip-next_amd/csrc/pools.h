@@ -187,6 +187,9 @@ struct DeviceBudget {
 	// call with alloc_mu held, before hipMalloc()ing `bytes`: false = not even after releasing what is parked
 	static bool make_room(size_t bytes, int device)
 	{
+		if (bytes < ((size_t)256 << 20))
+			return true; // (small requests are not worth a driver query each; with no stream ever destroyed the
+				     // runtime's own out-of-memory path is survivable again)
 		const size_t f0 = free_now();
 		if (f0 >= bytes + margin())
 			return true;
