@@ -22,7 +22,12 @@ void *lrzgpu_hash_open(int hash_code);
 int lrzgpu_hash_update(void *h, const uint8_t *data, int64_t n);
 int lrzgpu_hash_final(void *h, uint8_t *out); /* also closes h */
 
-/* The compress entry points append the reference's default, MD5.  This rewrites the trailer of such an image (or
+/* -H / --hash of the reference's command line: the hash the whole-file compress entry points of this process
+ * (lrzgpu_compress_buffer / _dev / _file, lrzgpu_rzip_fd) compute and append from now on; 1 (MD5) by default.
+ * control->hash_resblock receives the first 16 bytes.  The chunk-sharded entry points stay at MD5. */
+int lrzgpu_select_hash(int hash_code);
+
+/* This rewrites the trailer of an image (or
  * of any 0.14 image without encryption) for another hash code: magic[14] = hash_code, the old digest dropped,
  * `digest` (lrzgpu_hash_length(hash_code) bytes of the UNCOMPRESSED data; ignored for code 0) appended.
  * *out is malloc()ed. */

@@ -60,6 +60,7 @@
 #include "lz4_gate.h"
 #include "lzma_enc.h"
 #include "lzma_mf.h"
+#include "hashes.h"
 #include "md5.h"
 #include "pools.h"
 #include "profile.h"
@@ -81,6 +82,20 @@ extern "C" void lrzgpu_control_init(lrzgpu_control *c)
 	long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
 	c->ramsize = (pages > 0 && psz > 0) ? (int64_t)pages * psz : (int64_t)8 << 30; // src/lrzip.c:95-125
 }
+
+// -H / --hash of the reference's command line (src/main.c): the hash the compress entry points of this process
+// append from now on; 1 (MD5) until told otherwise
+static std::atomic<int> g_hash_code{1};
+extern "C" int lrzgpu_select_hash(int hash_code)
+{
+	if (lrzgpu::hash_length(hash_code) < 0)
+		return LRZGPU_E_PARAM;
+	g_hash_code.store(hash_code);
+	return 0;
+}
+namespace lrzgpu {
+int selected_hash_code() { return g_hash_code.load(); }
+} // namespace lrzgpu
 
 extern "C" void lrzgpu_trim(void)
 {
@@ -1019,11 +1034,18 @@ struct Run {
 		cleanup();
 	}
 
-	// ---- whole-input MD5 (the reference feeds it from cksumthread, src/rzip.c:564-584) ---------------
-	uint8_t digest[16];
+	// ---- whole-input hash (the reference feeds it from cksumthread, src/rzip.c:564-584): MD5 unless
+	// lrzgpu_select_hash() asked for another of hashes[] (src/main.c:64-79) ------------------------------
+	uint8_t digest[64] = {0};
+	const int hash_code = sel ? 1 : selected_hash_code(); // (chunk-sharded runs hand an MD5 to lrzgpu_assemble_chunks)
 	void md5_main()
 	{
-		Md5 m;
+		std::unique_ptr<Hasher> hasher = make_hasher(hash_code);
+		if (!hasher) {
+			fail(LRZGPU_E_PARAM);
+			return;
+		}
+		Hasher &m = *hasher;
 		if (in.host) {
 			m.update(in.host, (size_t)in.n);
 		} else if (in.n) {
@@ -1585,10 +1607,13 @@ int Run::run()
 		return ret;
 
 	if (whole_file) {
-		if (out.put(digest, 16) != 0)
+		// the hash after the last chunk (none for code 0, "CRC": the chunk CRCs are all there is) and its code in magic[14]
+		const int hash_len = hash_code == 0 ? 0 : hash_length(hash_code);
+		if (hash_len > 0 && out.put(digest, (size_t)hash_len) != 0)
 			return LRZGPU_E_IO;
 		uint8_t magic[21];
 		write_magic(magic, P.sz, in.n);
+		magic[14] = (uint8_t)hash_code;
 		if (out.finish(magic, 21) != 0)
 			return LRZGPU_E_IO;
 	}
