@@ -252,3 +252,39 @@ def test_scan_access_hooks(B, O, L):
         rev = C.c_int64(-1)
         assert L.lrzgpu_match_len(data, p0, op, end, last, C.byref(rev)) == want and rev.value == b
     assert L.lrzgpu_match_len(data, 100, 100, end, 0, None) == 0 and L.lrzgpu_match_len(data, 100, 200, end, 0, None) == 0
+
+
+def test_new_host_entry_points_survive_garbage(B, O, L):
+    """Untrusted bytes through read_magic, set_file_hash and the decoder with every filter byte: an error code or a
+    correct answer, never a crash."""
+    rnd = random.Random(99)
+    m = Magic()
+    for _ in range(3000):
+        n = rnd.choice([0, 5, 6, 17, 18, 20, 21, 24, 30, 300])
+        raw = bytearray(rnd.getrandbits(8) for _ in range(n))
+        if n >= 6 and rnd.random() < 0.8:
+            raw[0:4] = b"LRZI"
+            raw[4] = 0
+            raw[5] = rnd.choice([5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
+        L.lrzgpu_read_magic(bytes(raw), n, C.byref(m))
+        out, olen = C.POINTER(C.c_ubyte)(), C.c_int64()
+        if L.lrzgpu_set_file_hash(bytes(raw), n, rnd.randrange(-1, 16), bytes(64), C.byref(out), C.byref(olen)) == 0:
+            C.CDLL(None).free(out)
+    data = datagen.long_range(300000, seed=8)
+    img, _ = O.compress_buffer(data, compression_level=7, threads=2, processors=2, ramsize=RAM)
+    for filt in list(range(0, 12)) + [127, 128, 129, 144, 145, 159, 160, 255]:
+        bad = bytearray(img)
+        bad[16] = filt
+        try:
+            back = B.decompress_buffer(bytes(bad), host_threads=2)
+            assert back == data  # (a filter that finds nothing to convert in these literals leaves them as they are)
+        except RuntimeError:
+            assert filt != 0  # changed literals: CRC / MD5 refuse; unknown filter bytes: refused outright
+    for code in range(0, 20):
+        bad = bytearray(img)
+        bad[14] = code
+        try:
+            back = B.decompress_buffer(bytes(bad), host_threads=2)
+            assert code == 1 and back == data
+        except RuntimeError:
+            assert code != 1
