@@ -59,7 +59,11 @@ int lrzgpu_read_magic(const uint8_t *lrz, int64_t n, lrzgpu_magic *m);
  * converters: src/lzma/C/Bra.c, Bra86.c, Delta.c) -- host implementations, checked against the reference's own
  * converters; the read side (lrzgpu_decompress_*) undoes them on every stream-1 block.  filter_flag as in magic[16]:
  * 1 x86, 2 ARM, 3 ARMT, 4 PPC, 5 SPARC, 6 IA64, 7 ARM64, 8 RISC-V, 128 delta with distance `delta`
- * (1..16, 32, 48 ... 256).  The compress entry points do not filter yet (control has no filter field). */
+ * (1..16, 32, 48 ... 256). */
+/* --x86 ... --delta=N of the reference's command line (src/main.c:612-660): every literal block of the whole-file
+ * compress entry points of this process goes through this filter before its back end from now on (0 = none, the
+ * default), magic[16] says so, the lz4 test is off (src/main.c:858-861).  The converters run on the host for now. */
+int lrzgpu_select_filter(int filter_flag, int delta);
 int lrzgpu_filter_supported(int filter_flag, int delta);
 /* one block in place, from pc 0 with a fresh x86 state like compthread does; encode != 0: the compress direction */
 int lrzgpu_filter_block(int filter_flag, int delta, uint8_t *data, int64_t n, int encode);

@@ -60,6 +60,7 @@
 #include "lz4_gate.h"
 #include "lzma_enc.h"
 #include "lzma_mf.h"
+#include "filters.h"
 #include "hashes.h"
 #include "md5.h"
 #include "pools.h"
@@ -93,8 +94,26 @@ extern "C" int lrzgpu_select_hash(int hash_code)
 	g_hash_code.store(hash_code);
 	return 0;
 }
+// the filter options of the reference's command line (--x86 ... --delta=N, src/main.c:612-660): the filter every
+// literal block of the whole-file compress entry points goes through from now on; 0 = none (default)
+static std::atomic<int> g_filter_flag{0}, g_filter_delta{0};
+extern "C" int lrzgpu_select_filter(int filter_flag, int delta)
+{
+	if (filter_flag != 0 && !lrzgpu::filter_supported(filter_flag, delta))
+		return LRZGPU_E_PARAM;
+	if (filter_flag == lrzgpu::FILTER_DELTA && delta > 16 && delta % 16)
+		return LRZGPU_E_PARAM; // magic[16] codes 1..16, 32, 48 ... 256 only (src/lrzip.c:148-156)
+	g_filter_delta.store(filter_flag == lrzgpu::FILTER_DELTA ? delta : 0);
+	g_filter_flag.store(filter_flag);
+	return 0;
+}
 namespace lrzgpu {
 int selected_hash_code() { return g_hash_code.load(); }
+int selected_filter(int *delta)
+{
+	*delta = g_filter_delta.load();
+	return g_filter_flag.load();
+}
 } // namespace lrzgpu
 
 extern "C" void lrzgpu_trim(void)
@@ -250,6 +269,7 @@ struct Pipeline {
 	lrzgpu_control *ctl = nullptr;
 	Sizing sz;
 	int device = 0;
+	int filter_flag = 0, filter_delta = 0; // lrzgpu_select_filter(): every literal block through this filter first
 	int n_gpu_workers = 2, n_encoders = 1;
 	std::atomic<int> err{0};          // first failure; read by every thread of the run
 	std::function<void()> on_fail;    // wakes the run's own waiters (reader, scanners, committer)
@@ -506,6 +526,20 @@ struct Pipeline {
 				d_blk = j->chunk->stream1.p + j->ref.off;
 				if (n && !j->cancelled && d2h(j->bytes.data(), j->bytes.pinned, d_blk, (size_t)n, stage, s) != 0)
 					rc = LRZGPU_E_HIP;
+				// a filter over the literal block before its back end (src/stream.c:1587-1628; host converters for now,
+				// filters.cpp): the finder and the coder both see the filtered bytes, a stored block stores them
+				if (!rc && filter_flag && n && !j->cancelled) {
+					if (filter_block(filter_flag, filter_delta, j->bytes.data(), (size_t)n, true) != 0)
+						rc = LRZGPU_E_PARAM;
+					else if (try_backend) {
+						if (!d_stage.p && !d_stage.alloc(bufsize + 256, device))
+							rc = LRZGPU_E_NOMEM;
+						else if (hipMemcpyAsync(d_stage.p, j->bytes.data(), (size_t)n, hipMemcpyHostToDevice, s) != hipSuccess ||
+							 stream_wait(s) != hipSuccess)
+							rc = LRZGPU_E_HIP;
+						d_blk = d_stage.p;
+					}
+				}
 			}
 			if (rc) {
 				fail(rc);
@@ -1421,6 +1455,12 @@ int Run::run()
 	rc = compute_sizing(ctl, in.n, &P.sz);
 	if (rc)
 		return rc;
+	P.filter_flag = selected_filter(&P.filter_delta);
+	if (P.filter_flag) {
+		if (sel)
+			return LRZGPU_E_PARAM; // (the chunk-sharded entry points write no magic: no place for the filter byte)
+		P.sz.lz4_test = false;     // a filter switches the lz4 test off (src/main.c:858-861)
+	}
 	// host encoders: as asked, else the -p threads capped by the CPUs this process can really use
 	// (more runnable threads than the cgroup quota only buys throttling)
 	P.n_encoders = ctl->host_threads > 0 ? ctl->host_threads : (ctl->threads > 0 ? ctl->threads : 1);
@@ -1614,6 +1654,8 @@ int Run::run()
 		uint8_t magic[21];
 		write_magic(magic, P.sz, in.n);
 		magic[14] = (uint8_t)hash_code;
+		if (P.filter_flag) // write_magic, src/lrzip.c:148-156
+			magic[16] = (uint8_t)(P.filter_flag == FILTER_DELTA ? 128 + (P.filter_delta <= 16 ? P.filter_delta : P.filter_delta / 16 + 15) : P.filter_flag);
 		if (out.finish(magic, 21) != 0)
 			return LRZGPU_E_IO;
 	}
