@@ -90,32 +90,28 @@ void sparc(uint8_t *d, size_t n, bool enc)
 	}
 }
 
-// ARM64: BL (100101 imm26, word offset relative to the instruction) and ADRP (1 immlo 10000 immhi Rd, page offset
-// relative to the instruction's page) when the page offset is within +-2^20 pages... of 8 (the converter works on
-// the 21-bit immediate scaled by 8: immhi in bits 5..23 kept in place, immlo moved to bits 3..4)
+// ARM64: BL (100101 imm26: word offset relative to the instruction) and ADRP (1 immlo 10000 immhi Rd: page offset
+// relative to the instruction's page).  ADRP is only converted when its 21-bit page offset lies in [-2^17, 2^17): the
+// offset is biased by 2^17 into an 18-bit unsigned value, the page of the instruction is added (mod 2^18), the bias
+// taken off again -- so that the decoder recognises exactly the same instructions.
 void arm64(uint8_t *d, size_t n, bool enc)
 {
-	const uint32_t flag = 1u << 20, mask = (1u << 24) - (flag << 1);
 	for (size_t i = 0; i + 4 <= n; i += 4) {
-		uint32_t v = le32(d + i);
-		if (((v - 0x94000000u) & 0xFC000000u) == 0) {
-			v = shift_by(v, (uint32_t)i >> 2, enc);
-			put_le32(d + i, (v & 0x03FFFFFFu) | 0x94000000u);
+		uint32_t w = le32(d + i);
+		if ((w & 0xFC000000u) == 0x94000000u) {
+			w = (shift_by(w, (uint32_t)i >> 2, enc) & 0x03FFFFFFu) | 0x94000000u;
+			put_le32(d + i, w);
 			continue;
 		}
-		v -= 0x90000000u;
-		if ((v & 0x9F000000u) != 0)
+		if ((w & 0x9F000000u) != 0x90000000u)
 			continue;
-		v += flag;
-		if (v & mask)
-			continue;
-		uint32_t z = (v & 0xFFFFFFE0u) | (v >> 26);
-		z = shift_by(z, ((uint32_t)i >> 9) & ~7u, enc);
-		v &= 0x1F;
-		v |= 0x90000000u;
-		v |= z << 26;
-		v |= 0x00FFFFE0u & ((z & ((flag << 1) - 1)) - flag);
-		put_le32(d + i, v);
+		const uint32_t immhi = (w >> 5) & 0x7FFFFu, biased_hi = (immhi + 0x8000u) & 0x7FFFFu;
+		if (biased_hi >> 16)
+			continue; // page offset outside [-2^17, 2^17)
+		uint32_t page_off = (biased_hi << 2) | ((w >> 29) & 3); // 18 bits, biased by 2^17
+		page_off = shift_by(page_off, (uint32_t)i >> 12, enc) & 0x3FFFFu;
+		const uint32_t new_hi = ((page_off >> 2) - 0x8000u) & 0x7FFFFu;
+		put_le32(d + i, (w & 0x9F00001Fu) | ((page_off & 3) << 29) | (new_hi << 5));
 	}
 }
 
