@@ -49,6 +49,21 @@ def _zstd_raw(payload, u_len):
     return out.raw[:u_len]
 
 
+HASH_LEN = [4, 16, 20, 32, 48, 64, 32, 64, 16, 32, 64, 16, 32, 64]
+
+
+def file_hash(code, data):
+    """hashlib's value of hash `code` (None for RIPEMD-160 where this Python's OpenSSL does not offer it)."""
+    if code == 2:
+        try:
+            return hashlib.new("ripemd160", data).digest()
+        except (ValueError, TypeError):
+            return None
+    if code >= 8:
+        return (hashlib.shake_128 if code <= 10 else hashlib.shake_256)(data).digest(HASH_LEN[code])
+    return {1: hashlib.md5, 3: hashlib.sha256, 4: hashlib.sha384, 5: hashlib.sha512, 6: hashlib.sha3_256, 7: hashlib.sha3_512}[code](data).digest()
+
+
 def parse(lrz):
     """-> (header dict, [chunk dict]) with every block located but not yet decoded."""
     buf = memoryview(lrz)
@@ -84,8 +99,13 @@ def parse(lrz):
         pos = end
         if eof:
             break
-    hdr["md5_digest"] = bytes(buf[pos:pos + 16]) if hdr["md5"] else None
-    hdr["end"] = pos + (16 if hdr["md5"] else 0)
+    # the hash after the last chunk: code in magic[14] (`hashes[]`, src/main.c:64-79); MD5 is the default
+    hdr["hash_code"] = buf[14]
+    hlen = HASH_LEN[buf[14]] if 1 <= buf[14] < len(HASH_LEN) else 0
+    hdr["hash_digest"] = bytes(buf[pos:pos + hlen]) if hlen else None
+    hdr["md5_digest"] = hdr["hash_digest"] if hdr["md5"] else None
+    hdr["end"] = pos + hlen
+    hdr["filter"] = buf[16]
     return hdr, chunks
 
 
@@ -152,8 +172,12 @@ def decode(lrz, threads=8):
             at += n
     if at != hdr["st_size"]:
         raise ValueError("decoded %d bytes, header says %d" % (at, hdr["st_size"]))
-    if hdr["md5"] and hashlib.md5(out).digest() != hdr["md5_digest"]:
-        raise ValueError("MD5 trailer mismatch")
+    if hdr["filter"]:
+        raise ValueError("filtered literal blocks: this decoder has no converters (the library's read side does)")
+    if hdr["hash_digest"] is not None:
+        want = file_hash(hdr["hash_code"], out)
+        if want is not None and want != hdr["hash_digest"]:
+            raise ValueError("hash trailer mismatch")
     if hdr["end"] != len(lrz):
         raise ValueError("bytes after the MD5 trailer")
     return out

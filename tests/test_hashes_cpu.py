@@ -112,6 +112,8 @@ def test_read_side_verifies_every_hash(B, O, L, code):
     assert new[14] == code and len(new) == len(img) - 16 + (0 if code == 0 else LENGTHS[code])
     assert new[:14] == img[:14] and new[15:len(img) - 16] == img[15:len(img) - 16]
     assert B.decompress_buffer(new, host_threads=2) == data
+    import lrz_decode
+    assert bytes(lrz_decode.decode(new)) == data  # the independent Python decoder checks the digest with hashlib
     info = B.file_info(new)
     assert info.hash_code == code
     if code:
@@ -119,6 +121,9 @@ def test_read_side_verifies_every_hash(B, O, L, code):
         bad[-1] ^= 1
         with pytest.raises(RuntimeError):
             B.decompress_buffer(bytes(bad))
+        if code != 2 or lrz_decode.file_hash(2, b"") is not None:
+            with pytest.raises(ValueError):
+                lrz_decode.decode(bytes(bad))
         with pytest.raises(RuntimeError):
             B.decompress_buffer(new[:-1])  # a short digest
     # and back to MD5: the original image, byte for byte
