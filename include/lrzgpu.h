@@ -62,6 +62,26 @@ typedef struct lrzgpu_control {
 	int scan_slots;             /* rzip chunks scanned concurrently on the GPU, 0 = default (8)      */
 	/* stream API only (input, appended) */
 	int eof;                    /* control->eof: set before the last chunk's open_stream_out (src/rzip.c:1173-1174) */
+	/* per-run selections the reference keeps in rzip_control too (appended; lrzgpu_control_init() sets the defaults) */
+	int hash_code;              /* control->hash_code, -H: 0 CRC only, 1 MD5 (default) ... 13, the codes of hashes[]
+	                               (src/main.c:64-79); magic[14]; the digest is appended after the last chunk   */
+	int filter_flag;            /* control->filter_flag: 0 none, 1 x86, 2 ARM, 3 ARMT, 4 PPC, 5 SPARC, 6 IA64, 7 ARM64,
+	                               8 RISC-V, 128 delta; every literal (stream 1) block goes through it before its
+	                               back end (src/stream.c:1587-1628), magic[16], and the lz4 test is off
+	                               (src/main.c:858-861)                                                           */
+	int delta;                  /* control->delta: distance of the delta filter, 1..16, 32, 48 ... 256             */
+	int stdin_mode;             /* FLAG_STDIN: fd_in is a stream of unknown length -- chunks are max_mmap bytes each,
+	                               an input that ends exactly on a chunk boundary is followed by an empty last chunk,
+	                               open_stream_out() sizes the blocks from the first chunk (src/rzip.c:970-973,
+	                               1014-1017, 1041-1107, mmap_stdin 800-836)                                     */
+	int stdout_mode;            /* FLAG_STDOUT: maxram = ramsize / 6 (src/util.c:179-188) and the magic goes out with the
+	                               first chunk, so it carries st_size only when that chunk is also the last one
+	                               (src/stream.c:1725-1729, src/lrzip.c:141-144)                                  */
+	/* results (appended) */
+	uint8_t hash_full[64];      /* the whole digest of hash_code (hash_resblock keeps its first 16 bytes)       */
+	int backoff_would_apply;    /* lrzgpu_plan(): 1 when limit + overhead x threads exceeds what this host can give --
+	                               the reference would then shrink `limit` in 10 % steps (src/stream.c:1291-1305),
+	                               which this library does not model                                            */
 } lrzgpu_control;
 
 void lrzgpu_control_init(lrzgpu_control *c); /* initialise_control() defaults, src/lrzip.c:1813-1857 */

@@ -20,7 +20,9 @@ class Control(C.Structure):
                 ("gpu_slots", C.c_int), ("verbose", C.c_int), ("st_size", C.c_int64),
                 ("hash_resblock", C.c_uint8 * 16), ("lzma_properties", C.c_uint8 * 5), ("dictSize_used", C.c_uint32),
                 ("stream_bufsize", C.c_int64), ("threads_used", C.c_int), ("zstd_level", C.c_int),
-                ("scan_slots", C.c_int), ("eof", C.c_int)]
+                ("scan_slots", C.c_int), ("eof", C.c_int),
+                ("hash_code", C.c_int), ("filter_flag", C.c_int), ("delta", C.c_int), ("stdin_mode", C.c_int),
+                ("stdout_mode", C.c_int), ("hash_full", C.c_uint8 * 64), ("backoff_would_apply", C.c_int)]
 
 
 class ScanStats(C.Structure):
@@ -321,7 +323,8 @@ def lzma_compress(data: bytes, level=7, dict_size=1 << 25, fb=64, lc=3, lp=0, pb
 
 def make_control(level=7, rzip_level=0, threads=1, processors=1, ramsize=80 * 100 * 1048576, window=0, dict_size=0,
                  no_compress=False, lz4_test=True, threshold=100, nobemt=False, device=0, host_threads=0,
-                 gpu_slots=0, verbose=0, zstd=False, zstd_level=0, scan_slots=0):
+                 gpu_slots=0, verbose=0, zstd=False, zstd_level=0, scan_slots=0, hash_code=None, filter_flag=None,
+                 delta=0, stdin_mode=False, stdout_mode=False):
     c = Control()
     lib().lrzgpu_control_init(C.byref(c))
     c.compression_level = level
@@ -340,6 +343,13 @@ def make_control(level=7, rzip_level=0, threads=1, processors=1, ramsize=80 * 10
     c.verbose = verbose
     c.zstd_level = zstd_level
     c.scan_slots = scan_slots
+    if hash_code is not None:
+        c.hash_code = hash_code
+    if filter_flag is not None:
+        c.filter_flag = filter_flag
+        c.delta = delta
+    c.stdin_mode = 1 if stdin_mode else 0
+    c.stdout_mode = 1 if stdout_mode else 0
     return c
 
 

@@ -50,25 +50,18 @@ struct ThreadBuffers {
 	DevBuf small, block;
 	int device = -1;
 	hipStream_t s = nullptr; // own non-blocking stream: a null-stream call would wait for every blocking stream of the process
-	~ThreadBuffers()
-	{
-		if (s)
-			(void)hipStreamDestroy(s);
-	}
+	~ThreadBuffers() { StreamPool::get().give(s); } // parked, never destroyed (pools.h)
 	bool ensure(int dev, size_t block_bytes)
 	{
 		if (device != dev) {
 			small.release();
 			block.release();
-			if (s)
-				(void)hipStreamDestroy(s);
+			StreamPool::get().give(s);
 			s = nullptr;
 			device = dev;
 		}
-		if (!s && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
-			s = nullptr;
+		if (!s && !(s = pooled_stream(dev)))
 			return false;
-		}
 		if (!small.p && !small.alloc(256, dev))
 			return false;
 		if (block_bytes && block.cap < block_bytes && !block.alloc(block_bytes, dev))

@@ -35,6 +35,7 @@
 #include <dlfcn.h>
 #include <pthread.h>
 #include <sched.h>
+#include <sys/resource.h>
 
 #include <cerrno>
 #include <time.h>
@@ -71,6 +72,11 @@
 
 using namespace lrzgpu;
 
+namespace lrzgpu {
+int selected_hash_code();
+int selected_filter(int *delta);
+int control_filter(const lrzgpu_control *c, int *flag, int *delta);
+} // namespace lrzgpu
 extern "C" void lrzgpu_control_init(lrzgpu_control *c)
 {
 	memset(c, 0, sizeof(*c));
@@ -82,10 +88,13 @@ extern "C" void lrzgpu_control_init(lrzgpu_control *c)
 	c->processors = c->threads;
 	long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
 	c->ramsize = (pages > 0 && psz > 0) ? (int64_t)pages * psz : (int64_t)8 << 30; // src/lrzip.c:95-125
+	c->hash_code = lrzgpu::selected_hash_code(); // MD5 (src/lrzip.c:1842) unless lrzgpu_select_hash() changed the default
+	c->filter_flag = lrzgpu::selected_filter(&c->delta);
 }
 
-// -H / --hash of the reference's command line (src/main.c): the hash the compress entry points of this process
-// append from now on; 1 (MD5) until told otherwise
+// Defaults lrzgpu_control_init() hands out.  The selection itself lives in the control (hash_code, filter_flag, delta
+// -- where the reference keeps it, rzip_control): a run reads its own control once and nothing else, so concurrent
+// files with different selections do not see each other.
 static std::atomic<int> g_hash_code{1};
 extern "C" int lrzgpu_select_hash(int hash_code)
 {
@@ -96,23 +105,35 @@ extern "C" int lrzgpu_select_hash(int hash_code)
 }
 // the filter options of the reference's command line (--x86 ... --delta=N, src/main.c:612-660): the filter every
 // literal block of the whole-file compress entry points goes through from now on; 0 = none (default)
-static std::atomic<int> g_filter_flag{0}, g_filter_delta{0};
-extern "C" int lrzgpu_select_filter(int filter_flag, int delta)
+static std::atomic<int> g_filter{0}; // flag | delta << 8: one word, so a reader never pairs a flag with another call's delta
+static int check_filter(int filter_flag, int delta)
 {
 	if (filter_flag != 0 && !lrzgpu::filter_supported(filter_flag, delta))
 		return LRZGPU_E_PARAM;
 	if (filter_flag == lrzgpu::FILTER_DELTA && delta > 16 && delta % 16)
 		return LRZGPU_E_PARAM; // magic[16] codes 1..16, 32, 48 ... 256 only (src/lrzip.c:148-156)
-	g_filter_delta.store(filter_flag == lrzgpu::FILTER_DELTA ? delta : 0);
-	g_filter_flag.store(filter_flag);
+	return 0;
+}
+extern "C" int lrzgpu_select_filter(int filter_flag, int delta)
+{
+	if (check_filter(filter_flag, delta))
+		return LRZGPU_E_PARAM;
+	g_filter.store(filter_flag | ((filter_flag == lrzgpu::FILTER_DELTA ? delta : 0) << 8));
 	return 0;
 }
 namespace lrzgpu {
 int selected_hash_code() { return g_hash_code.load(); }
 int selected_filter(int *delta)
 {
-	*delta = g_filter_delta.load();
-	return g_filter_flag.load();
+	const int v = g_filter.load();
+	*delta = v >> 8;
+	return v & 0xFF;
+}
+int control_filter(const lrzgpu_control *c, int *flag, int *delta)
+{
+	*flag = c->filter_flag;
+	*delta = c->filter_flag == FILTER_DELTA ? c->delta : 0;
+	return check_filter(*flag, *delta);
 }
 } // namespace lrzgpu
 
@@ -1071,7 +1092,7 @@ struct Run {
 	// ---- whole-input hash (the reference feeds it from cksumthread, src/rzip.c:564-584): MD5 unless
 	// lrzgpu_select_hash() asked for another of hashes[] (src/main.c:64-79) ------------------------------
 	uint8_t digest[64] = {0};
-	const int hash_code = sel ? 1 : selected_hash_code(); // (chunk-sharded runs hand an MD5 to lrzgpu_assemble_chunks)
+	const int hash_code = ctl->hash_code; // control->hash_code, src/rzip.c:943-950, 1195-1219
 	void md5_main()
 	{
 		std::unique_ptr<Hasher> hasher = make_hasher(hash_code);
@@ -1324,7 +1345,10 @@ struct Run {
 		int r = scan_chunk_device(S.sw, cc->d_in, chunk_size, P.sz.rzip_level, &vr, &sr, F.ms, progress);
 		if (r)
 			return r < -50 ? r : (r == -4 ? LRZGPU_E_NOMEM : LRZGPU_E_INTERNAL);
-		cc->vr_out = vr;
+		{
+			std::lock_guard<std::mutex> lk(mu); // scanners read a predecessor's vr_out under mu (predicted_vr)
+			cc->vr_out = vr;
+		}
 		EmitResult er;
 		emit_streams(sr.records, chunk_size, cc->chunk_bytes, sr.crc, &er);
 		cc->stream0.swap(er.stream0);
@@ -1434,11 +1458,11 @@ struct Run {
 	{
 		if (index == 0)
 			return 0;
+		if (sel && sel->victim_in && sel->victim_in[index] >= 0)
+			return sel->victim_in[index]; // the caller's word comes first (lrzgpu.h: "gives the value chunk k starts from")
 		const ChunkCtx *prev = chunks[(size_t)index - 1].get();
 		if (prev->scanned)
 			return prev->vr_out;
-		if (sel && sel->victim_in && sel->victim_in[index] >= 0)
-			return sel->victim_in[index];
 		return 0;
 	}
 
@@ -1452,15 +1476,11 @@ int Run::run()
 		return rc;
 	P.ctl = ctl;
 	P.device = ctl->device;
-	rc = compute_sizing(ctl, in.n, &P.sz);
+	rc = sizing_for_input(ctl, in.n, &P.sz);
 	if (rc)
 		return rc;
-	P.filter_flag = selected_filter(&P.filter_delta);
-	if (P.filter_flag) {
-		if (sel)
-			return LRZGPU_E_PARAM; // (the chunk-sharded entry points write no magic: no place for the filter byte)
-		P.sz.lz4_test = false;     // a filter switches the lz4 test off (src/main.c:858-861)
-	}
+	if (control_filter(ctl, &P.filter_flag, &P.filter_delta) || hash_length(hash_code) < 0)
+		return LRZGPU_E_PARAM;
 	// host encoders: as asked, else the -p threads capped by the CPUs this process can really use
 	// (more runnable threads than the cgroup quota only buys throttling)
 	P.n_encoders = ctl->host_threads > 0 ? ctl->host_threads : (ctl->threads > 0 ? ctl->threads : 1);
@@ -1479,18 +1499,20 @@ int Run::run()
 	ctl->st_size = in.n;
 	speculate = !getenv("LRZGPU_NO_OVERLAP");
 
-	// the chunks of the file (src/rzip.c:1041: at least one pass, even for an empty input)
+	// the chunks of the file (src/rzip.c:1041: at least one pass, even for an empty input; STDIN mode: one more,
+	// empty, when the input ends exactly where a chunk does)
 	{
-		int64_t len = in.n, pass = 0;
-		while (!pass || len > 0) {
-			pass++;
+		std::vector<int64_t> sizes;
+		chunk_sizes_for(ctl, P.sz, in.n, &sizes);
+		int64_t offset = 0;
+		for (size_t k = 0; k < sizes.size(); k++) {
 			std::unique_ptr<ChunkCtx> cc(new ChunkCtx());
-			cc->index = (int)chunks.size();
-			cc->offset = in.n - len;
-			cc->size = P.sz.max_chunk < len ? P.sz.max_chunk : len;
+			cc->index = (int)k;
+			cc->offset = offset;
+			cc->size = sizes[k];
 			cc->chunk_bytes = chunk_bytes_for(cc->size);
-			len -= cc->size;
-			cc->last = len <= 0;
+			offset += cc->size;
+			cc->last = k + 1 == sizes.size();
 			chunks.push_back(std::move(cc));
 		}
 	}
@@ -1562,12 +1584,21 @@ int Run::run()
 						break;
 					}
 				}
+				{
+					std::lock_guard<std::mutex> lk(mu);
+					cc->scanned = false; // its vr_out is not to be trusted while it is scanned again
+				}
 				int src = scan_chunk(*rescanner, cc, prev->vr_out);
 				if (!src)
 					src = rescanner->F.poll(true);
 				if (src) {
 					ret = src;
 					break;
+				}
+				{
+					std::lock_guard<std::mutex> lk(mu);
+					cc->scanned = true;
+					cv.notify_all();
 				}
 			}
 		}
@@ -1652,15 +1683,14 @@ int Run::run()
 		if (hash_len > 0 && out.put(digest, (size_t)hash_len) != 0)
 			return LRZGPU_E_IO;
 		uint8_t magic[21];
-		write_magic(magic, P.sz, in.n);
-		magic[14] = (uint8_t)hash_code;
-		if (P.filter_flag) // write_magic, src/lrzip.c:148-156
-			magic[16] = (uint8_t)(P.filter_flag == FILTER_DELTA ? 128 + (P.filter_delta <= 16 ? P.filter_delta : P.filter_delta / 16 + 15) : P.filter_flag);
+		write_magic_for(magic, ctl, P.sz, in.n, chunks.size());
 		if (out.finish(magic, 21) != 0)
 			return LRZGPU_E_IO;
 	}
-	if (want_md5)
+	if (want_md5) {
 		memcpy(ctl->hash_resblock, digest, 16);
+		memcpy(ctl->hash_full, digest, sizeof(ctl->hash_full));
+	}
 	if (tracing())
 		fprintf(stderr, "lrzgpu driver: %zu chunks, %d scanners: last scan done %.2f  last finder %.2f  last encode %.2f  all blocks %.2f  md5 joined %.2f  assembled %.2f s (since start); early blocks %lld, redone chunks %lld, rescans (victim_round) %lld; worker sums: block copy+gate %.2f finder %.2f lists D2H %.2f, encoders busy %.2f idle %.2f s\n",
 			chunks.size(), scan_slots, t_scan_last - t0, P.t_last_mf - t0, P.t_last_enc - t0, t_blocks - t0, t_md5 - t0, now_s() - t0,
@@ -1963,10 +1993,14 @@ extern "C" int lrzgpu_assemble_chunks(lrzgpu_control *control, int64_t st_size, 
 		return LRZGPU_E_PARAM;
 	return abi_guard([&] {
 		Sizing s;
-		int r = compute_sizing(control, st_size, &s);
+		int r = sizing_for_input(control, st_size, &s);
 		if (r)
 			return r;
-		size_t total = 21 + 16;
+		int ff = 0, fd = 0;
+		const int hash_len = control->hash_code == 0 ? 0 : hash_length(control->hash_code);
+		if (hash_len < 0 || control_filter(control, &ff, &fd))
+			return LRZGPU_E_PARAM;
+		size_t total = 21 + (size_t)hash_len;
 		for (int c = 0; c < n_chunks; c++) {
 			if (chunk_len[c] < 0 || !chunk_img[c])
 				return LRZGPU_E_PARAM;
@@ -1975,13 +2009,13 @@ extern "C" int lrzgpu_assemble_chunks(lrzgpu_control *control, int64_t st_size, 
 		uint8_t *o = (uint8_t *)malloc(total);
 		if (!o)
 			return LRZGPU_E_NOMEM;
-		write_magic(o, s, st_size);
+		write_magic_for(o, control, s, st_size, (size_t)n_chunks);
 		size_t at = 21;
 		for (int c = 0; c < n_chunks; c++) {
 			big_copy(o + at, chunk_img[c], (size_t)chunk_len[c]);
 			at += (size_t)chunk_len[c];
 		}
-		memcpy(o + at, md5, 16);
+		memcpy(o + at, md5, (size_t)hash_len);
 		*out = o;
 		*out_len = (int64_t)total;
 		control->st_size = st_size;
@@ -1994,18 +2028,62 @@ extern "C" int lrzgpu_assemble_chunks(lrzgpu_control *control, int64_t st_size, 
 
 // ---- host-only helpers (no device needed) ----------------------------------------------------
 
+// Would malloc(bytes) fail on this host right now?  open_stream_out() probes exactly that (src/stream.c:1291-1305)
+// and shrinks `limit` -- hence the block size -- in 10 % steps until it succeeds; this library sizes the blocks as if
+// the first attempt succeeded and says so here.  A large malloc is an anonymous mmap: the kernel refuses it when it
+// exceeds the address-space rlimit, or, by overcommit mode: 0 (heuristic) more than RAM + swap in one piece, 2
+// (strict) more than CommitLimit - Committed_AS; mode 1 never refuses.
+static bool host_would_refuse(int64_t bytes)
+{
+	if (bytes <= 0)
+		return false;
+	struct rlimit rl;
+	if (getrlimit(RLIMIT_AS, &rl) == 0 && rl.rlim_cur != RLIM_INFINITY && (uint64_t)bytes > (uint64_t)rl.rlim_cur)
+		return true;
+	int mode = 0;
+	if (FILE *f = fopen("/proc/sys/vm/overcommit_memory", "r")) {
+		if (fscanf(f, "%d", &mode) != 1)
+			mode = 0;
+		fclose(f);
+	}
+	if (mode == 1)
+		return false;
+	long long mem_total = 0, swap_total = 0, commit_limit = 0, committed = 0;
+	if (FILE *f = fopen("/proc/meminfo", "r")) {
+		char key[64];
+		long long v;
+		while (fscanf(f, "%63s %lld%*[^\n]", key, &v) == 2) {
+			if (!strcmp(key, "MemTotal:"))
+				mem_total = v;
+			else if (!strcmp(key, "SwapTotal:"))
+				swap_total = v;
+			else if (!strcmp(key, "CommitLimit:"))
+				commit_limit = v;
+			else if (!strcmp(key, "Committed_AS:"))
+				committed = v;
+		}
+		fclose(f);
+	}
+	if (!mem_total)
+		return false;
+	if (mode == 2)
+		return bytes > (commit_limit - committed) * 1024;
+	return bytes > (mem_total + swap_total) * 1024;
+}
+
 extern "C" int lrzgpu_plan(lrzgpu_control *control, int64_t st_size, int64_t *chunk_size)
 {
 	if (!control || st_size < 0)
 		return LRZGPU_E_PARAM;
 	Sizing s;
-	int r = compute_sizing(control, st_size, &s);
+	int r = sizing_for_input(control, st_size, &s);
 	if (r)
 		return r;
 	control->stream_bufsize = s.stream_bufsize;
 	control->dictSize_used = s.dict_size;
 	control->threads_used = s.threads;
 	control->st_size = st_size;
+	control->backoff_would_apply = host_would_refuse(s.malloc_test) ? 1 : 0;
 	if (chunk_size)
 		*chunk_size = s.max_chunk < st_size ? s.max_chunk : st_size;
 	return 0;

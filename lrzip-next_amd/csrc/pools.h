@@ -272,6 +272,21 @@ inline int current_device_or0()
 	}
 	return d;
 }
+// a plain non-blocking stream on `device` (the current one when < 0) from the pool; give it back with
+// StreamPool::get().give(), never hipStreamDestroy()
+inline hipStream_t pooled_stream(int device = -1)
+{
+	const int dev = device >= 0 ? device : current_device_or0();
+	hipStream_t s = StreamPool::get().take(dev, 0);
+	if (s)
+		return s;
+	if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+		(void)hipGetLastError();
+		return nullptr;
+	}
+	StreamPool::get().created(s, dev, 0);
+	return s;
+}
 
 // ---- device buffers ------------------------------------------------------------------------------
 struct DevicePool {

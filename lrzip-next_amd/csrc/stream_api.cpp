@@ -27,6 +27,7 @@
 #include "common.h"
 #include "lz4_gate.h"
 #include "lzma_enc.h"
+#include "filters.h"
 #include "lzma_mf.h"
 #include "pools.h"
 #include "stream_layer.h"
@@ -48,8 +49,7 @@ struct BlockBackend {
 	{
 		WorkspacePool::get().give_mf(ws, ws_per_pos, device);
 		ws = nullptr;
-		if (s)
-			(void)hipStreamDestroy(s);
+		StreamPool::get().give(s); // parked, never destroyed (pools.h)
 		s = nullptr;
 		d_block.release();
 		d_small.release();
@@ -59,7 +59,7 @@ struct BlockBackend {
 		device = dev;
 		if (select_device(dev))
 			return LRZGPU_E_NODEVICE;
-		if (!s && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess)
+		if (!s && !(s = pooled_stream(dev)))
 			return LRZGPU_E_HIP;
 		return 0;
 	}
@@ -199,8 +199,13 @@ int backend_block(lrzgpu_control *control, const Sizing &sz, BlockBackend &be, l
 	}
 	for (;;) { // lzma_compress_buf(), src/stream.c:429-494
 		LzmaParams lp;
-		if (lzma_normalize(lp, control->compression_level, control->dictSize_used ? control->dictSize_used : sz.dict_size, 3, 0, 2,
-				   control->compression_level < 7 ? 32 : 64) != LZ_OK)
+		static std::mutex level_mu; // several workers share one control: the level is read and lowered under a lock
+		int level;
+		{
+			std::lock_guard<std::mutex> lk(level_mu);
+			level = control->compression_level;
+		}
+		if (lzma_normalize(lp, level, control->dictSize_used ? control->dictSize_used : sz.dict_size, 3, 0, 2, level < 7 ? 32 : 64) != LZ_OK)
 			return -1;
 		size_t dlen = (size_t)((double)t->s_len * 1.02);
 		dlen = (dlen + kPage - 1) / kPage * kPage;
@@ -211,8 +216,12 @@ int backend_block(lrzgpu_control *control, const Sizing &sz, BlockBackend &be, l
 		const int r = be.lzma(lp, t->s_buf, (size_t)t->s_len, c_buf, dlen, &out_len);
 		if (r != LZ_OK) {
 			free(c_buf);
-			if (r == LZ_ERROR_MEM && control->compression_level > 1) {
-				control->compression_level--; // "Can't allocate enough RAM for compression window, trying smaller"
+			if (r == LZ_ERROR_MEM && level > 1) {
+				// "Can't allocate enough RAM for compression window, trying smaller": one step per failed level,
+				// however many workers fail at it together
+				std::lock_guard<std::mutex> lk(level_mu);
+				if (control->compression_level == level)
+					control->compression_level = level - 1;
 				continue;
 			}
 			return r == LZ_ERROR_OUTPUT_EOF ? 0 : -1;
@@ -244,7 +253,15 @@ struct StreamOut { // struct stream_info, src/include/lrzip_private.h:592-620 (c
 	lrzgpu_control *control = nullptr;
 	int fd = -1, num_streams = 2, chunk_bytes = 0, eof = 0;
 	int64_t size = 0, bufsize = 0;
-	std::vector<uint8_t> buf[2];
+	// stream buffers: malloc()ed like the reference's (src/stream.c:1337-1345), handed to the worker as they are
+	// (clear_buffer 1836-1875: "the stream buffer has been given to the thread, allocate a new one") and freed by it
+	uint8_t *buf[2] = {nullptr, nullptr};
+	int64_t buflen[2] = {0, 0};
+	~StreamOut()
+	{
+		free(buf[0]);
+		free(buf[1]);
+	}
 	// writer state, touched only by the thread whose turn it is
 	bool header_written = false;
 	int64_t initial_pos = 0, cur_pos = 0, last_head[2] = {0, 0};
@@ -264,6 +281,7 @@ struct Ring {
 	int err = 0;
 	Sizing sz;
 	bool sized = false;
+	int filter_flag = 0, filter_delta = 0; // latched from the control with the sizing
 	int fd = -1;
 	int64_t file_pos = -1; // next byte the ordered writer puts out
 	lrzgpu_control *control = nullptr;
@@ -336,6 +354,16 @@ int write_block(Ring &R, Task *t)
 	return 0;
 }
 
+void drop_sinfo(Ring &R, StreamOut *so) // R.mu held
+{
+	for (size_t i = 0; i < R.sinfos.size(); i++)
+		if (R.sinfos[i].get() == so) {
+			R.sinfos[i] = std::move(R.sinfos.back());
+			R.sinfos.pop_back();
+			return;
+		}
+}
+
 void worker_main(Ring *Rp)
 {
 	Ring &R = *Rp;
@@ -354,7 +382,12 @@ void worker_main(Ring *Rp)
 		}
 		int rc = 0;
 		try {
-			int r = failed_already ? 0 : backend_block(R.control, R.sz, be, &t->ct);
+			// compthread, src/stream.c:1587-1628: the filter runs over a literal block before whatever back end
+			// follows (stored blocks included); host converters here -- the whole-file driver filters in HBM
+			if (!failed_already && R.filter_flag && t->ct.streamno == 1 && t->ct.s_len &&
+			    filter_block(R.filter_flag, R.filter_delta, t->ct.s_buf, (size_t)t->ct.s_len, true) != 0)
+				rc = LRZGPU_E_PARAM;
+			int r = (failed_already || rc) ? 0 : backend_block(R.control, R.sz, be, &t->ct);
 			if (r) { // "Unable to compress in parallel, waiting for previous thread to complete before trying again"
 				std::unique_lock<std::mutex> lk(R.mu);
 				R.cv_turn.wait(lk, [&] { return R.output_ticket == t->ticket; });
@@ -383,21 +416,23 @@ void worker_main(Ring *Rp)
 
 int hand_off(Ring &R, StreamOut *s, int streamno) // clear_buffer(), src/stream.c:1836-1875
 {
-	std::vector<uint8_t> &b = s->buf[streamno];
 	std::unique_ptr<Task> t(new Task());
 	t->sinfo = s;
 	t->ct.streamno = streamno;
-	t->ct.s_len = t->ct.c_len = (int64_t)b.size();
+	t->ct.s_len = t->ct.c_len = s->buflen[streamno];
 	t->ct.c_type = CTYPE_NONE;
-	t->ct.s_buf = (uint8_t *)malloc(b.size() ? b.size() : 1);
+	// the buffer itself goes to the worker (no copy); the stream gets a new one with its next byte
+	t->ct.s_buf = s->buf[streamno] ? s->buf[streamno] : (uint8_t *)malloc(1);
 	if (!t->ct.s_buf)
 		return LRZGPU_E_NOMEM;
-	memcpy(t->ct.s_buf, b.data(), b.size());
-	b.clear();
+	s->buf[streamno] = nullptr;
+	s->buflen[streamno] = 0;
 	std::unique_lock<std::mutex> lk(R.mu);
 	R.cv_room.wait(lk, [&] { return R.in_flight < R.slots || R.err; }); // the slot's semaphore
-	if (R.err)
+	if (R.err) {
+		free(t->ct.s_buf);
 		return R.err;
+	}
 	t->ticket = R.next_ticket++;
 	R.in_flight++;
 	s->pending++;
@@ -485,10 +520,10 @@ extern "C" void *lrzgpu_open_stream_out(lrzgpu_control *control, int f, unsigned
 			R.file_pos = (int64_t)lseek(f, 0, SEEK_CUR);
 			if (R.file_pos < 0)
 				return nullptr; // the ordered writer patches headers in place: the output must be seekable
+		} else if (f != R.fd) {
+			return nullptr; // one output file per prepare/close cycle: the ordered writer owns its position
 		}
 		s->bufsize = R.sz.stream_bufsize;
-		for (auto &b : s->buf)
-			b.reserve((size_t)s->bufsize);
 		StreamOut *raw = s.get();
 		R.sinfos.push_back(std::move(s));
 		return raw;
@@ -517,14 +552,16 @@ extern "C" int lrzgpu_write_stream(lrzgpu_control *control, void *ss, int stream
 		return LRZGPU_E_PARAM;
 	try {
 		while (len) { // src/stream.c:2198-2216
-			std::vector<uint8_t> &b = s->buf[streamno];
-			int64_t k = s->bufsize - (int64_t)b.size();
+			if (!s->buf[streamno] && !(s->buf[streamno] = (uint8_t *)malloc((size_t)s->bufsize)))
+				return LRZGPU_E_NOMEM;
+			int64_t k = s->bufsize - s->buflen[streamno];
 			if (k > len)
 				k = len;
-			b.insert(b.end(), p, p + k);
+			memcpy(s->buf[streamno] + s->buflen[streamno], p, (size_t)k);
+			s->buflen[streamno] += k;
 			p += k;
 			len -= k;
-			if ((int64_t)b.size() == s->bufsize) {
+			if (s->buflen[streamno] == s->bufsize) {
 				int r = lrzgpu_flush_buffer(control, ss, streamno);
 				if (r)
 					return r;
@@ -544,7 +581,12 @@ extern "C" int lrzgpu_close_stream_out(lrzgpu_control *control, void *ss)
 	int rc = 0;
 	for (int i = 0; i < s->num_streams && !rc; i++) // unconditional, zero-length blocks included (src/stream.c:2258-2259)
 		rc = lrzgpu_flush_buffer(control, ss, i);
+	// both buffers are with the workers now; the handle goes when its last block has been written
+	Ring &R = Ring::get();
+	std::lock_guard<std::mutex> lk(R.mu);
 	s->closed = true;
+	if (s->pending == 0)
+		drop_sinfo(R, s);
 	return rc;
 }
 

@@ -46,13 +46,13 @@ uint32_t level_dict(int level) // src/util.c:108-127
 int64_t overhead_for(uint32_t dict) { return ((int64_t)dict * 23 / 2) + 6 * ONE_MB + 16384; } // src/util.c:131
 } // namespace
 
-int compute_sizing(const lrzgpu_control *c, int64_t st_size, Sizing *out)
+int compute_sizing(const lrzgpu_control *c, int64_t st_size, Sizing *out, int64_t chunk_limit_arg)
 {
 	Sizing s;
 	s.level = c->compression_level;
 	s.rzip_level = c->rzip_compression_level ? c->rzip_compression_level : c->compression_level; // src/main.c:779-780
 	s.no_compress = (c->flags & LRZGPU_FLAG_NO_COMPRESS) != 0;
-	s.lz4_test = (c->flags & LRZGPU_FLAG_THRESHOLD) != 0 && !s.no_compress; // src/main.c:858-861
+	s.lz4_test = (c->flags & LRZGPU_FLAG_THRESHOLD) != 0 && !s.no_compress && !c->filter_flag; // src/main.c:858-861
 	s.nobemt = (c->flags & LRZGPU_FLAG_NOBEMT) != 0;
 	s.threshold = c->threshold;
 	if (s.level < 1 || s.level > 9 || s.rzip_level < 1 || s.rzip_level > 9 || c->threads < 1 || c->ramsize <= 0)
@@ -81,8 +81,8 @@ int compute_sizing(const lrzgpu_control *c, int64_t st_size, Sizing *out)
 	s.dict_size = c->dictSize ? c->dictSize : level_dict(s.level);
 	s.overhead = lzma ? overhead_for(s.dict_size) : 0;
 
-	// setup_ram(), src/util.c:179-188 (not writing to stdout)
-	const int64_t usable_ram = c->ramsize / 3;
+	// setup_ram(), src/util.c:179-188: a sixth when the compressed file is held back for stdout
+	const int64_t usable_ram = c->stdout_mode ? c->ramsize / 6 : c->ramsize / 3;
 	const int64_t maxram = round_to_page(usable_ram);
 
 	// rzip_fd(), src/rzip.c:999-1013
@@ -90,9 +90,11 @@ int compute_sizing(const lrzgpu_control *c, int64_t st_size, Sizing *out)
 	int64_t max_chunk = c->window ? c->window * CHUNK_MULTIPLE : c->ramsize / 3 * 2;
 	if (max_mmap > max_chunk)
 		max_mmap = max_chunk;
-	if (max_chunk < st_size)
+	// (STDIN: control->st_size is still 0 at this point of rzip_fd(), so the window is never rounded)
+	if (!c->stdin_mode && max_chunk < st_size)
 		max_chunk = round_to_page(max_chunk);
 	s.max_chunk = max_chunk;
+	s.max_mmap = max_mmap;
 
 	// prepare_streamout_threads(), src/stream.c:1099-1102
 	s.threads = c->threads;
@@ -102,7 +104,7 @@ int compute_sizing(const lrzgpu_control *c, int64_t st_size, Sizing *out)
 		s.threads = 1;
 
 	// open_stream_out() first call, src/stream.c:1169-1331
-	int64_t chunk_limit = max_chunk < st_size ? max_chunk : st_size;
+	int64_t chunk_limit = chunk_limit_arg >= 0 ? chunk_limit_arg : (max_chunk < st_size ? max_chunk : st_size);
 	if (chunk_limit < kPage)
 		chunk_limit = kPage;
 	const int testbufs = s.no_compress ? 1 : 2;
@@ -144,7 +146,9 @@ int compute_sizing(const lrzgpu_control *c, int64_t st_size, Sizing *out)
 	else if (limit > chunk_limit)
 		limit = chunk_limit;
 	// (the reference shrinks `limit` by 10% steps while malloc(limit + overhead*threads) fails;
-	//  that host-dependent retry is not modelled: the allocation is assumed to succeed)
+	//  that host-dependent retry is not modelled: the allocation is assumed to succeed -- lrzgpu_plan() reports
+	//  when this host would refuse it)
+	s.malloc_test = limit + s.overhead * s.threads;
 	if (lzma && limit / s.threads > STREAM_BUFSIZE) {
 		int64_t a = s.overhead - (int64_t)s.dict_size;
 		s.stream_bufsize = round_up_page((limit > a ? limit : a) / s.threads);
@@ -156,6 +160,35 @@ int compute_sizing(const lrzgpu_control *c, int64_t st_size, Sizing *out)
 	}
 	*out = s;
 	return 0;
+}
+
+int sizing_for_input(const lrzgpu_control *c, int64_t n, Sizing *out)
+{
+	if (!c->stdin_mode)
+		return compute_sizing(c, n, out);
+	Sizing pre;
+	int r = compute_sizing(c, 0, &pre);
+	if (r)
+		return r;
+	const int64_t first = pre.max_mmap < n ? pre.max_mmap : n;
+	r = compute_sizing(c, first, out, first);
+	if (!r)
+		out->max_chunk = pre.max_mmap;
+	return r;
+}
+
+void chunk_sizes_for(const lrzgpu_control *c, const Sizing &s, int64_t n, std::vector<int64_t> *sizes)
+{
+	sizes->clear();
+	int64_t len = n;
+	bool stdin_eof = false;
+	while (sizes->empty() || len > 0 || (c->stdin_mode && !stdin_eof)) {
+		const int64_t size = s.max_chunk < len ? s.max_chunk : len;
+		if (size < s.max_chunk)
+			stdin_eof = true; // a short read: control->eof = st->stdin_eof = 1
+		sizes->push_back(size);
+		len -= size;
+	}
 }
 
 void block_order(const std::vector<uint8_t> &stream0, int chunk_bytes, int64_t stream1_len, int64_t bufsize,
@@ -267,6 +300,23 @@ void write_magic(uint8_t magic[21], const Sizing &s, int64_t st_size)
 	}
 	magic[19] = (uint8_t)((s.rzip_level << 4) + s.level);
 	magic[20] = 0; // comment length
+}
+
+// magic[16], write_magic() src/lrzip.c:146-156: the filter's code, the delta distance folded into 128 + 1..31
+uint8_t filter_magic_byte(int filter_flag, int delta)
+{
+	if (filter_flag == 128)
+		return (uint8_t)(128 + (delta <= 16 ? delta : delta / 16 + 15));
+	return (uint8_t)filter_flag;
+}
+
+void write_magic_for(uint8_t magic[21], const lrzgpu_control *c, const Sizing &s, int64_t st_size, size_t n_chunks)
+{
+	// "else if (control->eof)" (src/lrzip.c:141-144): to a file the magic is written after the last chunk; to stdout
+	// with the first block of the first chunk (src/stream.c:1725-1729), when eof is set only if that chunk is the last
+	write_magic(magic, s, (c->stdout_mode && n_chunks > 1) ? 0 : st_size);
+	magic[14] = (uint8_t)c->hash_code;
+	magic[16] = filter_magic_byte(c->filter_flag, c->delta);
 }
 
 } // namespace lrzgpu

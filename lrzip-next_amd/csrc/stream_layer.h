@@ -29,11 +29,21 @@ struct Sizing {
 	int64_t overhead = 0;
 	int64_t stream_bufsize = 0;
 	int64_t max_chunk = 0;    // rzip chunk size
+	int64_t max_mmap = 0;     // control->max_mmap: the chunk size of STDIN mode (src/rzip.c:1046, 1075)
 	int threshold = 100;
+	int64_t malloc_test = 0;  // limit + overhead * threads: what open_stream_out() tries to malloc (src/stream.c:1292)
 };
 
-// Everything the reference derives from (flags, -p, -m, -w, file size) before the first chunk.
-int compute_sizing(const lrzgpu_control *c, int64_t st_size, Sizing *out);
+// Everything the reference derives from (flags, -p, -m, -w, file size) before the first chunk.  st_size is what
+// control->st_size holds when open_stream_out() is called first: the file size, or in STDIN mode the size of the
+// first chunk; chunk_limit is that call's argument (< 0: derive it, min(max_chunk, st_size)).
+int compute_sizing(const lrzgpu_control *c, int64_t st_size, Sizing *out, int64_t chunk_limit = -1);
+// The same for a whole run over n input bytes, STDIN mode included: max_chunk is the size of every chunk but the
+// last, blocks are sized from the first chunk.
+int sizing_for_input(const lrzgpu_control *c, int64_t n, Sizing *out);
+// the chunk sizes of an n-byte input in file order (src/rzip.c:1041-1186; STDIN: an input that ends on a chunk
+// boundary gets an empty last chunk, mmap_stdin 800-836)
+void chunk_sizes_for(const lrzgpu_control *c, const Sizing &s, int64_t n, std::vector<int64_t> *sizes);
 
 inline int chunk_bytes_for(int64_t chunk_size) // src/rzip.c:1129-1133
 {
@@ -70,5 +80,9 @@ size_t chunk_image_size(int chunk_bytes, const std::vector<DoneBlock> &blocks);
 void write_chunk_raw(uint8_t *out, int chunk_bytes, bool eof, int64_t chunk_size, const std::vector<DoneBlock> &blocks);
 
 void write_magic(uint8_t magic[21], const Sizing &s, int64_t st_size); // src/lrzip.c:131-208
+// the same with the per-run selections of the control: hash code, filter byte, and (STDOUT mode) no size when the
+// magic went out before the last chunk was known
+void write_magic_for(uint8_t magic[21], const lrzgpu_control *c, const Sizing &s, int64_t st_size, size_t n_chunks);
+uint8_t filter_magic_byte(int filter_flag, int delta);
 
 } // namespace lrzgpu

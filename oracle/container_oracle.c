@@ -124,6 +124,8 @@ struct driver {
 	lrzo_file_stats *fs;
 };
 
+static void (*g_filter)(unsigned char *, size_t);
+void lrzo_set_filter(void (*convert)(unsigned char *, size_t)) { g_filter = convert; }
 static size_t (*g_zstd_compress)(void *, size_t, const void *, size_t, int);
 void lrzo_set_zstd(size_t (*compress)(void *, size_t, const void *, size_t, int)) { g_zstd_compress = compress; }
 
@@ -131,6 +133,9 @@ static void compress_block(struct driver *d, struct block *b)
 {
 	b->c_type = CTYPE_NONE;
 	b->c_len = b->s_len;
+	/* compthread, src/stream.c:1587-1628: filters run over stream 1 whatever the back end (even none) */
+	if (d->prm->filter_flag && b->streamno == 1 && g_filter)
+		g_filter(b->buf, (size_t)b->s_len);
 	if (d->prm->no_compress || b->c_len < 64)
 		return;
 	if (d->lz4_test && !lrzo_lz4_compresses(b->buf, b->s_len, d->prm->threshold))
@@ -265,7 +270,7 @@ static void sink_put1(void *ctx, i64 off, i64 len)
 	}
 }
 
-struct plan_out { int threads; uint32_t dict_size; i64 bufsize, max_chunk; };
+struct plan_out { int threads; uint32_t dict_size; i64 bufsize, max_chunk, max_mmap; };
 
 /* setup_overhead / setup_ram / rzip_fd sizing / prepare_streamout_threads / open_stream_out */
 static void make_plan(const lrzo_params *prm, i64 n, struct plan_out *po)
@@ -277,10 +282,12 @@ static void make_plan(const lrzo_params *prm, i64 n, struct plan_out *po)
 	/* setup_overhead / setup_ram */
 	d.dict_size = prm->dict_size ? prm->dict_size : dict_for_level(d.level);
 	overhead = lzma_on ? lzma_overhead(d.dict_size) : 0;
-	usable_ram = prm->ramsize / 3;
+	usable_ram = prm->stdout_mode ? prm->ramsize / 6 : prm->ramsize / 3; /* src/util.c:179-188 */
 	maxram = round_to_page(usable_ram);
 
-	/* rzip_fd sizing, src/rzip.c:999-1020 */
+	/* rzip_fd sizing, src/rzip.c:999-1020.  STDIN: control->st_size is still 0 here, so max_chunk is never
+	 * rounded, and every pass takes chunk_size = mmap_size = max_mmap (1075); `n` is then the FIRST chunk's
+	 * size: what control->st_size holds when open_stream_out() sizes the blocks (mmap_stdin 835) */
 	max_mmap = round_to_page(maxram);
 	if (prm->window)
 		max_chunk = prm->window * CHUNK_MULTIPLE;
@@ -288,8 +295,9 @@ static void make_plan(const lrzo_params *prm, i64 n, struct plan_out *po)
 		max_chunk = prm->ramsize / 3 * 2;
 	if (max_mmap > max_chunk)
 		max_mmap = max_chunk;
-	if (max_chunk < n)
+	if (!prm->stdin_mode && max_chunk < n)
 		max_chunk = round_to_page(max_chunk);
+	po->max_mmap = max_mmap;
 
 	/* prepare_streamout_threads, src/stream.c:1099-1102 */
 	d.threads = prm->threads;
@@ -385,7 +393,7 @@ int lrzo_compress_buffer(const lrzo_params *prm, const uchar *in, i64 n, lrzo_lz
 	d.level = prm->compression_level;
 	rzip_level = prm->rzip_level ? prm->rzip_level : prm->compression_level;
 	lzma_on = !prm->no_compress && !prm->zstd;
-	d.lz4_test = prm->lz4_test && !prm->no_compress; /* src/main.c:858-861 */
+	d.lz4_test = prm->lz4_test && !prm->no_compress && !prm->filter_flag; /* src/main.c:858-861 */
 	if (lzma_on && !lzma)
 		return -1;
 	if (prm->zstd && !prm->no_compress) {
@@ -411,11 +419,18 @@ int lrzo_compress_buffer(const lrzo_params *prm, const uchar *in, i64 n, lrzo_lz
 
 	{
 		struct plan_out po;
-		make_plan(prm, prm->file_size > n ? prm->file_size : n, &po);
+		i64 size_seen = prm->file_size > n ? prm->file_size : n;
+		if (prm->stdin_mode) {
+			make_plan(prm, 0, &po);
+			max_chunk = po.max_mmap; /* every pass: chunk_size = mmap_size = max_mmap, src/rzip.c:1046, 1075 */
+			size_seen = max_chunk < n ? max_chunk : n;
+		}
+		make_plan(prm, size_seen, &po);
 		d.threads = po.threads;
 		d.dict_size = po.dict_size;
 		d.bufsize = po.bufsize;
-		max_chunk = po.max_chunk;
+		if (!prm->stdin_mode)
+			max_chunk = po.max_chunk;
 	}
 	lfs.stream_bufsize = d.bufsize;
 	lfs.threads_used = d.threads;
@@ -435,8 +450,10 @@ int lrzo_compress_buffer(const lrzo_params *prm, const uchar *in, i64 n, lrzo_lz
 	/* chunk loop, src/rzip.c:1041-1186 */
 	len = n;
 	{
-		int pass = 0;
-		while (!pass || len > 0) {
+		int pass = 0, stdin_eof = 0;
+		/* STDIN: a chunk that fills its buffer does not know it was the last; the next pass reads 0 bytes,
+		 * sets eof and writes an empty chunk (mmap_stdin "Empty file" branch, src/rzip.c:821-826) */
+		while (!pass || len > 0 || (prm->stdin_mode && !stdin_eof)) {
 			i64 offset = n - len, chunk_size = max_chunk < len ? max_chunk : len;
 			int bits = 8, cbytes;
 			lrzo_sink sink;
@@ -446,6 +463,8 @@ int lrzo_compress_buffer(const lrzo_params *prm, const uchar *in, i64 n, lrzo_lz
 				bits++;
 			cbytes = bits / 8 + (bits % 8 ? 1 : 0);
 			pass++;
+			if (prm->stdin_mode && chunk_size < max_chunk)
+				stdin_eof = 1; /* short read: control->eof = st->stdin_eof = 1 */
 
 			chunk_sizes = realloc(chunk_sizes, sizeof(i64) * (size_t)(nchunks + 1));
 			chunk_cbytes = realloc(chunk_cbytes, sizeof(int) * (size_t)(nchunks + 1));
@@ -546,10 +565,14 @@ int lrzo_compress_buffer(const lrzo_params *prm, const uchar *in, i64 n, lrzo_lz
 		magic[5] = 14;
 		{
 			int i;
-			for (i = 0; i < 8; i++)
-				magic[6 + i] = (uchar)((uint64_t)n >> (8 * i));
+				/* "else if (control->eof)": to a file the magic is written last (eof set by then); to STDOUT with the
+			 * first block of the first chunk, when eof is only set if that chunk is also the last */
+			if (!prm->stdout_mode || nchunks == 1)
+				for (i = 0; i < 8; i++)
+					magic[6 + i] = (uchar)((uint64_t)n >> (8 * i));
 		}
 		magic[14] = 1; /* MD5 */
+		magic[16] = (uchar)prm->filter_flag;
 		if (prm->zstd && !prm->no_compress) { /* src/lrzip.c:177-183 */
 			magic[17] = (uchar)((zstd_strategy << 4) + 4);
 			magic[18] = (uchar)d.zstd_level;

@@ -126,7 +126,19 @@ typedef struct {
 	i64 file_size;             /* timing samples only: when > n, in[0..n) is the head of a file of this size --
 	                              chunking and block sizing are those of the whole file, the chunks inside the
 	                              head are compressed, and the image returned is not a complete .lrz */
+	int stdin_mode;            /* FLAG_STDIN: the input is a stream of unknown length (src/rzip.c:970-973, 1014-1017,
+	                              1041-1107, mmap_stdin 800-836): chunks of max_mmap bytes, EOF only noticed by a
+	                              short read, blocks sized from the first chunk */
+	int stdout_mode;           /* FLAG_STDOUT: maxram = ramsize / 6 (src/util.c:179-188); the magic is written with the
+	                              first chunk (src/stream.c:1725-1729) and carries st_size only if eof is already set
+	                              (src/lrzip.c:141-144) */
+	int filter_flag;           /* magic[16] value: 0 none, 1..8 BCJ, 128 + code for delta (src/lrzip.c:146-156); with a
+	                              filter the lz4 test is off (src/main.c:858-861) and lrzo_set_filter()'s converter
+	                              runs over every stream-1 block before its back end (src/stream.c:1587-1628) */
 } lrzo_params;
+/* the converter for filter_flag: one stream-1 block in place, from pc 0 / fresh state (the tests bind the
+ * reference's own Bra.c / Bra86.c / Delta.c from oracle/_ref here) */
+void lrzo_set_filter(void (*convert)(unsigned char *buf, size_t len));
 /* ZSTD_compress of the host's libzstd (the oracle has no zstd of its own: the reference links the
  * system library too, so parity is against the same build). */
 void lrzo_set_zstd(size_t (*compress)(void *, size_t, const void *, size_t, int));

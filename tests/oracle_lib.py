@@ -26,7 +26,7 @@ class Params(C.Structure):
                 ("threads", C.c_int), ("processors", C.c_int), ("ramsize", C.c_int64), ("window", C.c_int64),
                 ("lz4_test", C.c_int), ("threshold", C.c_int), ("nobemt", C.c_int), ("dict_size", C.c_uint32),
                 ("workers", C.c_int), ("verbose", C.c_int), ("zstd", C.c_int), ("zstd_level", C.c_int),
-                ("file_size", C.c_int64)]
+                ("file_size", C.c_int64), ("stdin_mode", C.c_int), ("stdout_mode", C.c_int), ("filter_flag", C.c_int)]
 
 
 class FileStats(C.Structure):
@@ -175,9 +175,57 @@ def lzma_uncompress_ref(comp: bytes, props: bytes, out_len: int):
     return rc, dst.raw[:dlen.value]
 
 
-def compress_buffer(data, **kw):
+FILTER_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t)
+_FILTER_NAMES = {2: "ARM", 3: "ARMT", 4: "PPC", 5: "SPARC", 6: "IA64", 7: "ARM64", 8: "RISCV"}
+
+
+def ref_filter(flag, delta=0, encode=True):
+    """The reference's own converter for one block (oracle/_ref: Bra.c, Bra86.c, BraIA64.c, Delta.c compiled
+    unmodified), called the way compthread / ucompthread call it (src/stream.c:1587-1628, 1926-1990): pc 0,
+    fresh x86 / delta state.  Returns a python callable (address, length)."""
+    R = ref_lzma()
+    sfx = "Enc" if encode else "Dec"
+    if flag == 1:
+        f = getattr(R, "z7_BranchConvSt_X86_" + sfx)
+        f.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint32)]
+        f.restype = C.c_void_p
+
+        def run(p, n):
+            st = C.c_uint32(0)  # Z7_BRANCH_CONV_ST_X86_STATE_INIT_VAL
+            f(p, n, 0, C.byref(st))
+    elif flag == 128:
+        init, conv = R.Delta_Init, (R.Delta_Encode if encode else R.Delta_Decode)
+        init.argtypes = [C.c_void_p]
+        conv.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_size_t]
+
+        def run(p, n):
+            st = C.create_string_buffer(256)  # DELTA_STATE_SIZE
+            init(st)
+            conv(st, delta, p, n)
+    else:
+        f = getattr(R, "z7_BranchConv_%s_%s" % (_FILTER_NAMES[flag], sfx))
+        f.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32]
+        f.restype = C.c_void_p
+
+        def run(p, n):
+            f(p, n, 0)
+    return run
+
+
+def magic16(flag, delta=0):
+    """write_magic()'s filter byte, src/lrzip.c:146-156"""
+    if flag == 128:
+        return 128 + (delta if delta <= 16 else (delta >> 4) + 15)
+    return flag
+
+
+_keep_filter = []
+
+
+def compress_buffer(data, filter_flag=0, filter_delta=0, **kw):
     """Whole-file oracle compress -> (.lrz bytes, FileStats).  data: bytes, or a numpy uint8 array
-    (no copy: multi-GiB inputs)."""
+    (no copy: multi-GiB inputs).  filter_flag / filter_delta: run the reference's converter over every
+    literal block first (oracle/_ref) and say so in magic[16]."""
     L = lib()
     p = Params()
     L.lrzo_params_default(C.byref(p))
@@ -185,6 +233,15 @@ def compress_buffer(data, **kw):
         if not hasattr(p, k):
             raise KeyError(k)
         setattr(p, k, v)
+    L.lrzo_set_filter.argtypes = [C.c_void_p]
+    if filter_flag:
+        run = ref_filter(filter_flag, filter_delta, True)
+        cb = FILTER_FN(lambda ptr, n: run(ptr, n))
+        _keep_filter[:] = [cb]
+        L.lrzo_set_filter(C.cast(cb, C.c_void_p))
+        p.filter_flag = magic16(filter_flag, filter_delta)
+    else:
+        L.lrzo_set_filter(None)
     fn = None
     if p.zstd and not p.no_compress:
         z = C.CDLL("libzstd.so.1")  # the system library, as the reference links it
