@@ -22,9 +22,10 @@ void *lrzgpu_hash_open(int hash_code);
 int lrzgpu_hash_update(void *h, const uint8_t *data, int64_t n);
 int lrzgpu_hash_final(void *h, uint8_t *out); /* also closes h */
 
-/* -H / --hash of the reference's command line: the hash the whole-file compress entry points of this process
- * (lrzgpu_compress_buffer / _dev / _file, lrzgpu_rzip_fd) compute and append from now on; 1 (MD5) by default.
- * control->hash_resblock receives the first 16 bytes.  The chunk-sharded entry points stay at MD5. */
+/* The hash of a run is control->hash_code (lrzgpu.h), 1 = MD5 unless changed: the whole-file entry points compute
+ * and append it; the chunk-sharded ones compute it when asked to (with_md5) and lrzgpu_assemble_chunks appends
+ * lrzgpu_hash_length(control->hash_code) bytes.  control->hash_full receives the digest, hash_resblock its first 16
+ * bytes.  lrzgpu_select_hash() sets the default lrzgpu_control_init() hands out (-H of the reference's command line). */
 int lrzgpu_select_hash(int hash_code);
 
 /* This rewrites the trailer of an image (or
@@ -60,10 +61,17 @@ int lrzgpu_read_magic(const uint8_t *lrz, int64_t n, lrzgpu_magic *m);
  * converters; the read side (lrzgpu_decompress_*) undoes them on every stream-1 block.  filter_flag as in magic[16]:
  * 1 x86, 2 ARM, 3 ARMT, 4 PPC, 5 SPARC, 6 IA64, 7 ARM64, 8 RISC-V, 128 delta with distance `delta`
  * (1..16, 32, 48 ... 256). */
-/* --x86 ... --delta=N of the reference's command line (src/main.c:612-660): every literal block of the whole-file
- * compress entry points of this process goes through this filter before its back end from now on (0 = none, the
- * default), magic[16] says so, the lz4 test is off (src/main.c:858-861).  The converters run on the host for now. */
+/* The filter of a run is control->filter_flag / control->delta (lrzgpu.h), as in the reference's rzip_control: every
+ * literal block goes through it before its back end, magic[16] says so, the lz4 test is off (src/main.c:858-861).
+ * In the whole-file and chunk-sharded entry points the block is filtered in HBM where the scan left it
+ * (lrzgpu_filter_block_dev below); the stream API filters its host buffers with the host converters.
+ * lrzgpu_select_filter() / lrzgpu_select_hash() only set the DEFAULTS lrzgpu_control_init() hands out from then on
+ * (--x86 ... --delta=N, -H of the reference's command line, src/main.c:612-660); a run reads nothing but its control. */
 int lrzgpu_select_filter(int filter_flag, int delta);
+/* the compress direction over a block resident on `device` (d_data 4-byte aligned), in place: one thread per
+ * word / Thumb pair / IA-64 bundle; x86 and RISC-V as candidate compaction + per-run resolution + parallel conversion
+ * (csrc/filters_gpu.hip); bit-identical to lrzgpu_filter_block(..., encode = 1) */
+int lrzgpu_filter_block_dev(int filter_flag, int delta, void *d_data, int64_t n, int device);
 int lrzgpu_filter_supported(int filter_flag, int delta);
 /* one block in place, from pc 0 with a fresh x86 state like compthread does; encode != 0: the compress direction */
 int lrzgpu_filter_block(int filter_flag, int delta, uint8_t *data, int64_t n, int encode);

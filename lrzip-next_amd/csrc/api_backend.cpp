@@ -14,6 +14,8 @@
 #include "lz4_gate.h"
 #include "lzma_enc.h"
 #include "lzma_mf.h"
+#include "filters.h"
+#include "filters_gpu.h"
 #include "pools.h"
 #include "profile.h"
 
@@ -395,4 +397,26 @@ extern "C" void lrzgpu_profile_get(lrzgpu_profile *out)
 	ProfileStore &ps = ProfileStore::get();
 	std::lock_guard<std::mutex> lk(ps.mu);
 	*out = ps.p;
+}
+
+// ---- filters on the device: one block resident in HBM, compress direction, in place -------------------
+extern "C" int lrzgpu_filter_block_dev(int filter_flag, int delta, void *d_data, int64_t n, int device)
+{
+	int rc = select_device(device);
+	if (rc)
+		return rc;
+	if (n < 0 || (n && !d_data) || !filter_supported(filter_flag, delta))
+		return LRZGPU_E_PARAM;
+	try {
+		ThreadBuffers &tb = thread_buffers();
+		const size_t need = filter_scratch_bytes(filter_flag, (size_t)n);
+		if (!tb.ensure(device, need))
+			return LRZGPU_E_NOMEM;
+		const int r = filter_block_device(filter_flag, delta, (uint8_t *)d_data, (size_t)n, tb.block.p, tb.block.cap, tb.s);
+		if (r)
+			return r == -1 ? LRZGPU_E_PARAM : (r == -2 ? LRZGPU_E_NOMEM : LRZGPU_E_HIP);
+		return stream_wait(tb.s) == hipSuccess ? 0 : LRZGPU_E_HIP;
+	} catch (...) {
+		return LRZGPU_E_INTERNAL;
+	}
 }

@@ -62,6 +62,7 @@
 #include "lzma_enc.h"
 #include "lzma_mf.h"
 #include "filters.h"
+#include "filters_gpu.h"
 #include "hashes.h"
 #include "md5.h"
 #include "pools.h"
@@ -481,7 +482,7 @@ struct Pipeline {
 		}
 		MfWorkspace *ws = nullptr;
 		double ws_per_pos = 0;
-		DevBuf d_stage;
+		DevBuf d_stage, d_scratch;
 		uint8_t *stage[2] = {nullptr, nullptr};
 		double per_pos = 16;
 		const size_t bufsize = (size_t)sz.stream_bufsize;
@@ -490,6 +491,7 @@ struct Pipeline {
 			WorkspacePool::get().give_mf(ws, ws_per_pos, device);
 			ws = nullptr;
 			d_stage.release();
+			d_scratch.release();
 			for (int k = 0; k < 2; k++)
 				if (stage[k])
 					(void)hipHostFree(stage[k]);
@@ -544,23 +546,20 @@ struct Pipeline {
 					d_blk = d_stage.p;
 				}
 			} else {
-				d_blk = j->chunk->stream1.p + j->ref.off;
-				if (n && !j->cancelled && d2h(j->bytes.data(), j->bytes.pinned, d_blk, (size_t)n, stage, s) != 0)
-					rc = LRZGPU_E_HIP;
-				// a filter over the literal block before its back end (src/stream.c:1587-1628; host converters for now,
-				// filters.cpp): the finder and the coder both see the filtered bytes, a stored block stores them
-				if (!rc && filter_flag && n && !j->cancelled) {
-					if (filter_block(filter_flag, filter_delta, j->bytes.data(), (size_t)n, true) != 0)
-						rc = LRZGPU_E_PARAM;
-					else if (try_backend) {
-						if (!d_stage.p && !d_stage.alloc(bufsize + 256, device))
-							rc = LRZGPU_E_NOMEM;
-						else if (hipMemcpyAsync(d_stage.p, j->bytes.data(), (size_t)n, hipMemcpyHostToDevice, s) != hipSuccess ||
-							 stream_wait(s) != hipSuccess)
-							rc = LRZGPU_E_HIP;
-						d_blk = d_stage.p;
-					}
+				uint8_t *d_lit = j->chunk->stream1.p + j->ref.off;
+				d_blk = d_lit;
+				// a filter over the literal block before its back end (src/stream.c:1587-1628), where the scan left it:
+				// in HBM, in place (filters_gpu.hip) -- the finder, the coder's host copy and a stored block all see the
+				// filtered bytes.  (A block is filtered once: a cancelled one is rebuilt by a fresh gather.)
+				if (filter_flag && n && !j->cancelled) {
+					const size_t need = filter_scratch_bytes(filter_flag, (size_t)n);
+					if (need > d_scratch.cap && !d_scratch.alloc(filter_scratch_bytes(filter_flag, bufsize), device))
+						rc = LRZGPU_E_NOMEM;
+					else if (filter_block_device(filter_flag, filter_delta, d_lit, (size_t)n, d_scratch.p, d_scratch.cap, s) != 0)
+						rc = LRZGPU_E_HIP;
 				}
+				if (!rc && n && !j->cancelled && d2h(j->bytes.data(), j->bytes.pinned, d_blk, (size_t)n, stage, s) != 0)
+					rc = LRZGPU_E_HIP;
 			}
 			if (rc) {
 				fail(rc);
