@@ -95,10 +95,12 @@ int lrzgpu_rzip_fd(lrzgpu_control *control, int fd_in, int fd_out);
 
 /* compress_file() for plain files: magic placeholder, rzip_fd, write_magic -- src/lrzip.c:1464.
  * Both fd entry points read a regular fd_in chunk by chunk and write every chunk as soon as its blocks are done
- * (host memory holds the blocks in flight, not the file).  A pipe as fd_in is spooled to memory first, as the
- * reference does for STDIN (src/lrzip.c:627-922), and then compressed like a regular file of that size: the
- * reference's STDIN mode sizes its chunks differently and leaves st_size out of the magic -- NOT reproduced
- * (valid .lrz, not byte-identical to piped reference output).  A non-seekable fd_out gets the image at the end. */
+ * (host memory holds the blocks in flight, not the file).  control->stdin_mode / stdout_mode reproduce the
+ * reference reading STDIN / writing STDOUT byte for byte (chunks of max_mmap bytes cut as mmap_stdin() cuts them,
+ * blocks sized from the first chunk, maxram = ramsize / 6 and a size-less magic for STDOUT; src/rzip.c:800-836,
+ * 970-973, 1014-1017, 1041-1107, src/util.c:179-188, src/stream.c:1725-1729): the fd is then read as a stream from
+ * its current offset.  A pipe as fd_in WITHOUT stdin_mode is spooled and compressed like a regular file of that
+ * size.  A non-seekable fd_out gets the image at the end. */
 int lrzgpu_compress_file(lrzgpu_control *control, int fd_in, int fd_out);
 
 /* Same container, memory to memory. in: host buffer. *out is malloc'd (caller frees with free()). */
@@ -117,7 +119,8 @@ int lrzgpu_compress_buffer_dev(lrzgpu_control *control, const void *d_in, int64_
  * (src/rzip.c:308): victim_in[k] >= 0 gives the value chunk k starts from, victim_in == NULL or a
  * negative entry lets the library predict it (what chunk k-1 left when this call scanned it, else 0);
  * on_chunk reports the value used and the value left, so the caller that owns the file can check the
- * chain victim_out[k-1] == victim_in[k] and ask again for a chunk whose guess was wrong.
+ * chain victim_out[k-1] == victim_in[k] and ask again for a chunk whose guess was wrong: what on_chunk reports
+ * is authoritative -- with stride > 1 the library cannot check the chain itself (it does with stride == 1).
  * with_md5: also compute the MD5 of the whole input into control->hash_resblock (one caller does).
  * lrzgpu_assemble_chunks (host only): magic + the chunk images in order + MD5 = the .lrz file. */
 typedef int (*lrzgpu_chunk_fn)(void *ctx, int chunk_index, int64_t victim_in, int64_t victim_out,

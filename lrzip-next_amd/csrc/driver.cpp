@@ -1874,14 +1874,15 @@ extern "C" int lrzgpu_compress_buffer_dev(lrzgpu_control *control, const void *d
 }
 
 // fd_in -> source.  Regular files are read chunk by chunk as the scan needs them (the reference maps one
-// chunk at a time, src/rzip.c:1057-1107); a pipe is spooled first, as the reference does for STDIN
-// (src/lrzip.c:627-922) -- but then compressed like a regular file of that size: the reference's STDIN
-// mode sizes its chunks differently and leaves st_size out of the magic, which is not reproduced.
-static int source_from_fd(int fd, CompressSource *s, std::vector<uint8_t> *spool)
+// chunk at a time, src/rzip.c:1057-1107).  With control->stdin_mode (FLAG_STDIN) the fd is read as a stream from
+// its current offset, whatever it is, and the run chunks it the way mmap_stdin() does (src/rzip.c:800-836: the
+// reference fills one anonymous mapping per chunk; the bytes are the same, so they are spooled here and cut up by
+// chunk_sizes_for()).  A pipe without stdin_mode is spooled and compressed like a regular file of that size.
+static int source_from_fd(int fd, bool as_stream, CompressSource *s, std::vector<uint8_t> *spool)
 {
-	const off_t cur = lseek(fd, 0, SEEK_CUR);
+	const off_t cur = as_stream ? (off_t)-1 : lseek(fd, 0, SEEK_CUR);
 	if (cur < 0) {
-		if (errno != ESPIPE)
+		if (!as_stream && errno != ESPIPE)
 			return LRZGPU_E_IO;
 		std::vector<uint8_t> tmp((size_t)1 << 20);
 		for (;;) {
@@ -1921,7 +1922,7 @@ static int compress_fd(lrzgpu_control *control, int fd_in, int fd_out, bool with
 	return abi_guard([&] {
 		CompressSource s;
 		std::vector<uint8_t> spool;
-		int r = source_from_fd(fd_in, &s, &spool);
+		int r = source_from_fd(fd_in, control->stdin_mode != 0, &s, &spool);
 		if (r)
 			return r;
 		FdSink sink;

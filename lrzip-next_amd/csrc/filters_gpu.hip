@@ -427,7 +427,7 @@ size_t filter_scratch_bytes(int flag, size_t n)
 	(void)hipcub::DeviceSelect::If(nullptr, temp2, it, (uint32_t *)nullptr, (int *)nullptr, items, IsRvCandidate{nullptr});
 	if (temp2 > temp)
 		temp = temp2;
-	return 256 + cap * 4 + cap + 256 + temp + 4096;
+	return 256 + ((cap * 4 + 255) & ~(size_t)255) + ((cap + 255) & ~(size_t)255) + temp + 4096;
 }
 
 int filter_block_device(int flag, int delta, uint8_t *d, size_t n, uint8_t *scratch, size_t scratch_bytes, hipStream_t s)
@@ -479,8 +479,9 @@ int filter_block_device(int flag, int delta, uint8_t *d, size_t n, uint8_t *scra
 		unsigned long long *d_total = (unsigned long long *)scratch;
 		int *d_count = (int *)(scratch + 64);
 		uint32_t *d_pos = (uint32_t *)(scratch + 256);
-		uint8_t *d_mark = scratch + 256 + cap * 4;
-		uint8_t *d_temp = scratch + 256 + cap * 4 + ((cap + 255) & ~(size_t)255);
+		uint8_t *d_mark = scratch + 256 + ((cap * 4 + 255) & ~(size_t)255);
+		uint8_t *d_temp = d_mark + ((cap + 255) & ~(size_t)255); // 256-byte aligned like the scratch itself: rocPRIM lays its
+		                                                         // scan state out relative to this pointer
 		size_t temp = scratch_bytes - (size_t)(d_temp - scratch);
 		if (hipMemsetAsync(scratch, 0, 256, s) != hipSuccess)
 			return -3;

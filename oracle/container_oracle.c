@@ -363,6 +363,10 @@ static void make_plan(const lrzo_params *prm, i64 n, struct plan_out *po)
 int lrzo_plan(const lrzo_params *prm, i64 n, lrzo_file_stats *fs)
 {
 	struct plan_out po;
+	if (prm->stdin_mode) { /* blocks are sized from the first chunk, and every chunk is max_mmap bytes */
+		make_plan(prm, 0, &po);
+		n = po.max_mmap < n ? po.max_mmap : n;
+	}
 	make_plan(prm, n, &po);
 	memset(fs, 0, sizeof(*fs));
 	fs->stream_bufsize = po.bufsize;

@@ -102,13 +102,25 @@ def test_filtered_image_equals_oracle_image(B, O, flag, delta):
     assert got == want and got[16] == 0
 
 
+def salted_noise(n, seed):
+    """noise with CALL-like byte patterns (E8/E9 xx xx xx 00/FF) every ~40 bytes"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    x = rng.integers(0, 256, n, dtype=np.uint8)
+    idx = rng.choice(n - 8, n // 40, replace=False)
+    x[idx] = np.where(rng.random(idx.size) < 0.8, 0xE8, 0xE9)
+    x[idx + 4] = np.where(rng.random(idx.size) < 0.5, 0x00, 0xFF)
+    return x.tobytes()
+
+
 def test_filter_with_small_blocks_and_many_chunks(B, O):
-    """Several chunks and several literal blocks per chunk (-w 1 is not small enough: small -m instead), x86 filter."""
-    data = b"".join(F.code_like(F.X86, 700000 + 13 * k, seed=k) for k in range(12))
-    kw = dict(threads=2, processors=2, ramsize=12 * 1048576 * 3)
-    want, fs = O.compress_buffer(data, filter_flag=F.X86, compression_level=5, workers=4, **kw)
-    got, _ = B.compress_buffer(data, level=5, host_threads=4, filter_flag=F.X86, **kw)
-    assert fs.n_blocks > 4
+    """Several chunks and several literal blocks per chunk (a small -m: 20 MiB chunks, 5 MiB blocks), x86 filter over
+    noise salted with CALL-like bytes."""
+    data = salted_noise(45 * 1048576 + 321, 7)
+    kw = dict(threads=2, processors=2, ramsize=30 * 1048576)
+    want, fs = O.compress_buffer(data, filter_flag=F.X86, compression_level=1, workers=4, **kw)
+    got, _ = B.compress_buffer(data, level=1, host_threads=4, filter_flag=F.X86, **kw)
+    assert fs.n_chunks == 3 and fs.n_blocks > 12
     assert got == want
     assert B.decompress_buffer(got, host_threads=2) == data
 
@@ -135,14 +147,14 @@ def test_hash_code_is_a_field_of_the_control(B, O):
 
 
 def test_sharded_entry_points_honour_hash_and_filter(B):
-    """lrzgpu_compress_chunks + lrzgpu_assemble_chunks with a SHA-256 and the ARM64 filter in the control: the same
+    """lrzgpu_compress_chunks + lrzgpu_assemble_chunks with a SHA-256 and the x86 filter in the control: the same
     file as the whole-file entry point."""
-    data = b"".join(F.code_like(F.ARM64, 900000 + k, seed=50 + k) for k in range(6))
-    kw = dict(level=7, threads=2, processors=2, ramsize=12 * 1048576 * 3, host_threads=4, hash_code=3, filter_flag=F.ARM64)
+    data = salted_noise(45 * 1048576 + 99, 8)
+    kw = dict(level=1, threads=2, processors=2, ramsize=30 * 1048576, host_threads=4, hash_code=3, filter_flag=F.X86)
     whole, ctl = B.compress_buffer(data, **kw)
     _, chunk = B.plan(len(data), **{k: v for k, v in kw.items() if k != "host_threads"})
     n_chunks = (len(data) + chunk - 1) // chunk
-    assert n_chunks >= 3
+    assert n_chunks == 3
     imgs = {}
     digest = None
     for first in range(2):
@@ -153,5 +165,5 @@ def test_sharded_entry_points_honour_hash_and_filter(B):
             digest = bytes(c.hash_full)[:32]
     assert digest == hashlib.sha256(data).digest()
     out, _ = B.assemble_chunks([imgs[k] for k in range(n_chunks)], len(data), digest, ctl=B.make_control(**kw))
-    assert bytes(out) == whole
+    assert bytes(out) == whole and whole[14] == 3 and whole[16] == 1
     assert B.decompress_buffer(whole, host_threads=2) == data

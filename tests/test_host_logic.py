@@ -54,6 +54,39 @@ def test_plan_equals_oracle_sizing(B, O, st_size):
                         assert c.threads_used == fs.threads_used and c.dictSize_used == fs.dict_size, key
 
 
+@pytest.mark.parametrize("st_size", [0, 5000, 10 << 20, 700 << 20, 16 << 30])
+def test_plan_equals_oracle_sizing_stdin_stdout(B, O, st_size):
+    """The same with FLAG_STDIN (blocks sized from the first max_mmap-byte chunk, src/rzip.c:1014-1017, 1075;
+    mmap_stdin 835) and FLAG_STDOUT (maxram = ramsize / 6, src/util.c:179-188)."""
+    import ctypes
+    for level in (5, 7):
+        for threads, procs in ((1, 1), (8, 8), (256, 256)):
+            for ram in (80 * 100 << 20, 16 << 30, 3000 << 30):
+                for window in (0, 1, 21):
+                    for si, so in ((1, 0), (0, 1), (1, 1)):
+                        c, chunk = B.plan(st_size, level=level, threads=threads, processors=procs, ramsize=ram,
+                                          window=window, stdin_mode=si, stdout_mode=so)
+                        p = O.Params()
+                        O.lib().lrzo_params_default(ctypes.byref(p))
+                        p.compression_level, p.threads, p.processors, p.ramsize = level, threads, procs, ram
+                        p.window, p.stdin_mode, p.stdout_mode = window, si, so
+                        fs = O.FileStats()
+                        O.lib().lrzo_plan(ctypes.byref(p), st_size, ctypes.byref(fs))
+                        key = (st_size, level, threads, procs, ram, window, si, so)
+                        assert c.stream_bufsize == fs.stream_bufsize, key
+                        assert c.threads_used == fs.threads_used and c.dictSize_used == fs.dict_size, key
+                        assert c.backoff_would_apply in (0, 1)
+
+
+def test_plan_reports_the_malloc_backoff(B):
+    """open_stream_out() probes malloc(limit + overhead x threads) and shrinks `limit` while it fails
+    (src/stream.c:1291-1305); the library does not model that and says when this host would refuse the probe."""
+    c, _ = B.plan(1 << 40, level=9, threads=256, processors=256, ramsize=1 << 60)  # an absurd -m: no host gives that
+    assert c.backoff_would_apply == 1
+    c, _ = B.plan(10 << 20, level=7, threads=1, processors=1, ramsize=80 * 100 << 20)
+    assert c.backoff_would_apply == 0
+
+
 def test_container_store_equals_oracle_no_compress(B, O):
     """Block order, headers, chaining, magic: product container writer vs oracle for -n, 1 and 3 chunks."""
     data = datagen.long_range(3 * 1048576 + 17, seed=2) + datagen.random_bytes(1500000, seed=3)
