@@ -79,6 +79,7 @@ typedef struct lrzgpu_control {
 	                               (src/stream.c:1725-1729, src/lrzip.c:141-144)                                  */
 	/* results (appended) */
 	uint8_t hash_full[64];      /* the whole digest of hash_code (hash_resblock keeps its first 16 bytes)       */
+	int fd_out;                 /* control->fd_out: where lrzgpu_write_1g() / lrzgpu_put_fdout() write (read side)  */
 	int backoff_would_apply;    /* lrzgpu_plan(): 1 when limit + overhead x threads exceeds what this host can give --
 	                               the reference would then shrink `limit` in 10 % steps (src/stream.c:1291-1305),
 	                               which this library does not model                                            */
@@ -154,6 +155,26 @@ void *lrzgpu_open_stream_out(lrzgpu_control *control, int f, unsigned int n, int
 int lrzgpu_flush_buffer(lrzgpu_control *control, void *sinfo, int stream);
 int lrzgpu_write_stream(lrzgpu_control *control, void *ss, int streamno, const uint8_t *p, int64_t len);
 int lrzgpu_close_stream_out(lrzgpu_control *control, void *ss);
+
+/* ---- stream layer, read side: src/include/stream.h:20-21, 26, 29, 31, 32 -----------------------------------
+ * For a caller that replays the rzip tokens itself, the way runzip_chunk() does (src/runzip.c:139-370): it reads the
+ * chunk_bytes byte of a chunk with read_1g, opens the chunk's two streams, pulls token headers / match offsets from
+ * stream 0 and literal bytes from stream 1, writes what it reconstructs with write_1g, and closes the chunk.
+ *   open_stream_in   src/stream.c:1352-1506  f stands right after the chunk_bytes byte; reads the eof flag into
+ *                    control->eof, adds the chunk size to control->st_size, checks the two initial stream headers;
+ *                    blocks are then fetched and decoded ahead of the reader by worker threads (fill_buffer
+ *                    2023-2195, ucompthread 1883-2021: stored / LZMA / zstd blocks; the filter named by
+ *                    control->filter_flag / delta -- the caller takes them from the magic, lrzgpu_read_magic -- is
+ *                    undone on every literal block)
+ *   read_stream      src/stream.c:2220-2250  bytes read (fewer than asked for at the end of the stream), -1 on failure
+ *   close_stream_in  src/stream.c:2299-2319  leaves f where the next chunk, or the hash, starts; frees the handle
+ *   write_1g / put_fdout   src/stream.c:802-850   to control->fd_out;  read_1g  src/stream.c:897-945 */
+void *lrzgpu_open_stream_in(lrzgpu_control *control, int f, int n, char cbytes);
+int64_t lrzgpu_read_stream(lrzgpu_control *control, void *ss, int streamno, uint8_t *p, int64_t len);
+int lrzgpu_close_stream_in(lrzgpu_control *control, void *ss);
+int64_t lrzgpu_write_1g(lrzgpu_control *control, const void *buf, int64_t len);
+int64_t lrzgpu_read_1g(lrzgpu_control *control, int fd, void *buf, int64_t len);
+int64_t lrzgpu_put_fdout(lrzgpu_control *control, const void *offset_buf, int64_t ret);
 
 /* The per-block back-end dispatch seam: static int lzma_compress_buf(rzip_control*, struct compress_thread*,
  * int current_thread), src/stream.c:429-494 (and zstd_compress_buf 167-230 under LRZGPU_FLAG_ZSTD), called

@@ -22,7 +22,8 @@ class Control(C.Structure):
                 ("stream_bufsize", C.c_int64), ("threads_used", C.c_int), ("zstd_level", C.c_int),
                 ("scan_slots", C.c_int), ("eof", C.c_int),
                 ("hash_code", C.c_int), ("filter_flag", C.c_int), ("delta", C.c_int), ("stdin_mode", C.c_int),
-                ("stdout_mode", C.c_int), ("hash_full", C.c_uint8 * 64), ("backoff_would_apply", C.c_int)]
+                ("stdout_mode", C.c_int), ("hash_full", C.c_uint8 * 64), ("fd_out", C.c_int),
+                ("backoff_would_apply", C.c_int)]
 
 
 class ScanStats(C.Structure):
@@ -440,6 +441,25 @@ class Info(C.Structure):
                 ("hash_code", C.c_int), ("lzma", C.c_int), ("dict_prop", C.c_int), ("level", C.c_int),
                 ("rzip_level", C.c_int), ("chunks", C.c_int64), ("blocks", C.c_int64), ("blocks_lzma", C.c_int64),
                 ("stream_c_len", C.c_int64 * 2), ("stream_u_len", C.c_int64 * 2)]
+
+
+class Magic(C.Structure):
+    _fields_ = [("major", C.c_int), ("minor", C.c_int), ("magic_len", C.c_int), ("st_size", C.c_int64), ("enc_code", C.c_int),
+                ("salt", C.c_uint8 * 8), ("costfactor", C.c_int), ("hash_code", C.c_int), ("hash_len", C.c_int),
+                ("filter_flag", C.c_int), ("delta", C.c_int), ("ctype", C.c_int), ("dict_size", C.c_uint32),
+                ("lzma_properties", C.c_uint8 * 5), ("zpaq_bs", C.c_int), ("zpaq_level", C.c_int), ("bzip3_bs", C.c_int),
+                ("zstd_strategy", C.c_int), ("zstd_level", C.c_int), ("level", C.c_int), ("rzip_level", C.c_int),
+                ("comment_length", C.c_int), ("comment", C.c_char * 256)]
+
+
+def read_magic(img: bytes):
+    m = Magic()
+    f = lib().lrzgpu_read_magic
+    f.argtypes = [C.c_char_p, C.c_int64, C.POINTER(Magic)]
+    rc = f(img, len(img), C.byref(m))
+    if rc != 0:
+        raise RuntimeError("lrzgpu_read_magic rc=%d" % rc)
+    return m
 
 
 def file_info(img: bytes):

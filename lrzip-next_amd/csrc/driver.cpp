@@ -91,6 +91,7 @@ extern "C" void lrzgpu_control_init(lrzgpu_control *c)
 	c->ramsize = (pages > 0 && psz > 0) ? (int64_t)pages * psz : (int64_t)8 << 30; // src/lrzip.c:95-125
 	c->hash_code = lrzgpu::selected_hash_code(); // MD5 (src/lrzip.c:1842) unless lrzgpu_select_hash() changed the default
 	c->filter_flag = lrzgpu::selected_filter(&c->delta);
+	c->fd_out = -1;
 }
 
 // Defaults lrzgpu_control_init() hands out.  The selection itself lives in the control (hash_code, filter_flag, delta

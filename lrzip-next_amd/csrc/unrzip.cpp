@@ -210,7 +210,12 @@ static int decompress_impl(const uint8_t *img, int64_t n, uint8_t **out, int64_t
 	struct FreeDeleter {
 		void operator()(uint8_t *p) const { free(p); }
 	};
-	std::unique_ptr<uint8_t, FreeDeleter> dst_owner((uint8_t *)malloc(st_size ? st_size : 1));
+	// An image written to STDOUT in several chunks carries no size (the magic went out before the last chunk was
+	// known, src/stream.c:1725-1729): the output then grows chunk by chunk by the size each chunk header states
+	// (open_stream_in adds them up the same way, src/stream.c:1419)
+	const bool sized = st_size != 0;
+	size_t dst_cap = sized ? (size_t)st_size : 1;
+	std::unique_ptr<uint8_t, FreeDeleter> dst_owner((uint8_t *)malloc(dst_cap));
 	uint8_t *dst = dst_owner.get();
 	if (!dst)
 		return LRZGPU_E_NOMEM;
@@ -230,6 +235,25 @@ static int decompress_impl(const uint8_t *img, int64_t n, uint8_t **out, int64_t
 		}
 		const size_t base = pos + 2 + (size_t)cb, hlen = 1 + 3 * (size_t)cb;
 		size_t end = base + 2 * hlen;
+		if (!sized) {
+			const uint64_t chunk_field = val(img + pos + 2, cb); // >= the chunk's bytes (never below one page)
+			if (chunk_field > ((uint64_t)1 << 46) || at + chunk_field < at) {
+				rc = LRZGPU_E_FORMAT;
+				break;
+			}
+			if (at + chunk_field > dst_cap) {
+				uint8_t *bigger = (uint8_t *)realloc(dst, (size_t)(at + chunk_field));
+				if (!bigger) {
+					rc = LRZGPU_E_NOMEM;
+					break;
+				}
+				(void)dst_owner.release();
+				dst_owner.reset(bigger);
+				dst = bigger;
+				dst_cap = (size_t)(at + chunk_field);
+			}
+		}
+		const uint64_t out_limit = sized ? st_size : (uint64_t)dst_cap;
 		std::vector<Block> blocks[2];
 		for (int s = 0; s < 2 && !rc; s++) {
 			size_t h = base + (size_t)s * hlen;
@@ -268,7 +292,7 @@ static int decompress_impl(const uint8_t *img, int64_t n, uint8_t **out, int64_t
 		std::vector<uint8_t> s0, s1;
 		// what is left of the file bounds both streams: literals byte for byte, tokens by 3 + cb <= 11
 		// bytes per token that covers at least one byte, plus the 7-byte tail
-		const size_t left = (size_t)(st_size - at);
+		const size_t left = (size_t)(out_limit - at);
 		if (left > (size_t)-1 / 16) {
 			rc = LRZGPU_E_FORMAT;
 			break;
@@ -293,7 +317,7 @@ static int decompress_impl(const uint8_t *img, int64_t n, uint8_t **out, int64_t
 					done = true;
 					break;
 				}
-				if (lit + ln > s1.size() || at + ln > st_size) {
+				if (lit + ln > s1.size() || at + ln > out_limit) {
 					rc = LRZGPU_E_FORMAT;
 					break;
 				}
@@ -307,7 +331,7 @@ static int decompress_impl(const uint8_t *img, int64_t n, uint8_t **out, int64_t
 				}
 				const uint64_t ofs = val(s0.data() + i, cb);
 				i += (size_t)cb;
-				if (ofs == 0 || ofs > at - chunk0 || at + ln > st_size) { // matches stay inside their chunk
+				if (ofs == 0 || ofs > at - chunk0 || at + ln > out_limit) { // matches stay inside their chunk
 					rc = LRZGPU_E_FORMAT;
 					break;
 				}
@@ -336,7 +360,7 @@ static int decompress_impl(const uint8_t *img, int64_t n, uint8_t **out, int64_t
 		if (eof)
 			break;
 	}
-	if (!rc && at != st_size)
+	if (!rc && sized && at != st_size)
 		rc = LRZGPU_E_FORMAT;
 	if (!rc && hash_len) {
 		uint8_t dg[64];
@@ -344,7 +368,7 @@ static int decompress_impl(const uint8_t *img, int64_t n, uint8_t **out, int64_t
 			rc = LRZGPU_E_FORMAT;
 		else {
 			std::unique_ptr<Hasher> m = make_hasher(hash_code);
-			m->update(dst, (size_t)st_size);
+			m->update(dst, (size_t)at);
 			m->finish(dg);
 			if (memcmp(dg, img + pos, (size_t)hash_len) != 0)
 				rc = LRZGPU_E_FORMAT;
@@ -354,7 +378,7 @@ static int decompress_impl(const uint8_t *img, int64_t n, uint8_t **out, int64_t
 	if (rc)
 		return rc;
 	*out = dst_owner.release();
-	*out_len = (int64_t)st_size;
+	*out_len = (int64_t)at;
 	return 0;
 }
 

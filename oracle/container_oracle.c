@@ -273,7 +273,7 @@ static void sink_put1(void *ctx, i64 off, i64 len)
 struct plan_out { int threads; uint32_t dict_size; i64 bufsize, max_chunk, max_mmap; };
 
 /* setup_overhead / setup_ram / rzip_fd sizing / prepare_streamout_threads / open_stream_out */
-static void make_plan(const lrzo_params *prm, i64 n, struct plan_out *po)
+static int make_plan(const lrzo_params *prm, i64 n, struct plan_out *po)
 {
 	struct { int threads, level; uint32_t dict_size; i64 bufsize; } d;
 	i64 maxram, usable_ram, max_mmap, max_chunk, overhead, limit;
@@ -340,6 +340,8 @@ static void make_plan(const lrzo_params *prm, i64 n, struct plan_out *po)
 				goto retry;
 			}
 		}
+		if (d.threads < 1)
+			return -1; /* -m too small for one LZMA thread: the reference divides by zero below (src/stream.c:1316) */
 		if (n > 0 && n < limit)
 			limit = n > STREAM_BUFSIZE ? n : STREAM_BUFSIZE;
 		else if (limit > chunk_limit)
@@ -358,16 +360,19 @@ static void make_plan(const lrzo_params *prm, i64 n, struct plan_out *po)
 	po->dict_size = d.dict_size;
 	po->bufsize = d.bufsize;
 	po->max_chunk = max_chunk;
+	return 0;
 }
 
 int lrzo_plan(const lrzo_params *prm, i64 n, lrzo_file_stats *fs)
 {
 	struct plan_out po;
 	if (prm->stdin_mode) { /* blocks are sized from the first chunk, and every chunk is max_mmap bytes */
-		make_plan(prm, 0, &po);
+		if (make_plan(prm, 0, &po))
+			return -1;
 		n = po.max_mmap < n ? po.max_mmap : n;
 	}
-	make_plan(prm, n, &po);
+	if (make_plan(prm, n, &po))
+		return -1;
 	memset(fs, 0, sizeof(*fs));
 	fs->stream_bufsize = po.bufsize;
 	fs->threads_used = po.threads;
@@ -425,11 +430,13 @@ int lrzo_compress_buffer(const lrzo_params *prm, const uchar *in, i64 n, lrzo_lz
 		struct plan_out po;
 		i64 size_seen = prm->file_size > n ? prm->file_size : n;
 		if (prm->stdin_mode) {
-			make_plan(prm, 0, &po);
+			if (make_plan(prm, 0, &po))
+				return -1;
 			max_chunk = po.max_mmap; /* every pass: chunk_size = mmap_size = max_mmap, src/rzip.c:1046, 1075 */
 			size_seen = max_chunk < n ? max_chunk : n;
 		}
-		make_plan(prm, size_seen, &po);
+		if (make_plan(prm, size_seen, &po))
+			return -1;
 		d.threads = po.threads;
 		d.dict_size = po.dict_size;
 		d.bufsize = po.bufsize;

@@ -14,9 +14,9 @@ PAGE = 4096
 
 
 def modes(B, O, data, ram, si, so, **kw):
-    want, fs = O.compress_buffer(data, compression_level=7, threads=2, processors=2, ramsize=ram, workers=4,
+    want, fs = O.compress_buffer(data, compression_level=1, threads=2, processors=2, ramsize=ram, workers=4,
                                  stdin_mode=si, stdout_mode=so, **{k: int(v) for k, v in kw.items()})
-    got, ctl = B.compress_buffer(data, level=7, threads=2, processors=2, ramsize=ram, host_threads=4,
+    got, ctl = B.compress_buffer(data, level=1, threads=2, processors=2, ramsize=ram, host_threads=4,
                                  stdin_mode=si, stdout_mode=so, **kw)
     assert got == want, (len(data), ram, si, so, kw)
     assert B.decompress_buffer(got, host_threads=2) == data
@@ -25,7 +25,7 @@ def modes(B, O, data, ram, si, so, **kw):
 
 @pytest.mark.parametrize("si,so", [(1, 0), (0, 1), (1, 1)])
 def test_stdin_stdout_images_equal_oracle(B, O, si, so):
-    ram = 36 << 20                      # maxram 12 MiB (6 MiB to stdout): the STDIN chunk size
+    ram = 60 << 20                      # maxram 20 MiB (10 MiB to stdout): the STDIN chunk size; -L1 fits that
     chunk = (ram // (6 if so else 3)) // PAGE * PAGE
     base = datagen.long_range(chunk, seed=5)
     for n in (0, 1, 4095, 100000, chunk - 1, chunk, chunk + 1, 2 * chunk, 2 * chunk + 12345):
@@ -42,10 +42,10 @@ def test_stdin_stdout_images_equal_oracle(B, O, si, so):
 
 def test_stdin_mode_differs_from_file_mode_where_the_reference_does(B, O):
     """Same bytes, same flags: as a file the input is one chunk sized from st_size; from STDIN several."""
-    ram = 36 << 20
-    data = datagen.text_like(30 << 20, seed=9)
-    as_file, _ = B.compress_buffer(data, level=7, threads=2, processors=2, ramsize=ram, host_threads=4)
-    want_file, fs_file = O.compress_buffer(data, compression_level=7, threads=2, processors=2, ramsize=ram, workers=4)
+    ram = 60 << 20
+    data = datagen.text_like(50 << 20, seed=9)
+    as_file, _ = B.compress_buffer(data, level=1, threads=2, processors=2, ramsize=ram, host_threads=4)
+    want_file, fs_file = O.compress_buffer(data, compression_level=1, threads=2, processors=2, ramsize=ram, workers=4)
     as_stdin, fs_stdin = modes(B, O, data, ram, 1, 0)
     assert as_file == want_file
     assert fs_stdin.n_chunks == 3 and fs_file.n_chunks == 2 and as_file != as_stdin
@@ -53,9 +53,9 @@ def test_stdin_mode_differs_from_file_mode_where_the_reference_does(B, O):
 
 def test_pipe_into_compress_file_with_stdin_mode(B, O, tmp_path):
     import ctypes as C
-    ram = 36 << 20
-    data = datagen.long_range(15 << 20, seed=11)
-    want, _ = O.compress_buffer(data, compression_level=7, threads=2, processors=2, ramsize=ram, workers=4, stdin_mode=1)
+    ram = 60 << 20
+    data = datagen.long_range(25 << 20, seed=11)
+    want, _ = O.compress_buffer(data, compression_level=1, threads=2, processors=2, ramsize=ram, workers=4, stdin_mode=1)
     r, w = os.pipe()
 
     def feed():
@@ -66,7 +66,7 @@ def test_pipe_into_compress_file_with_stdin_mode(B, O, tmp_path):
     t.start()
     out = tmp_path / "piped.lrz"
     fo = os.open(out, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
-    c = B.make_control(level=7, threads=2, processors=2, ramsize=ram, host_threads=4, stdin_mode=True)
+    c = B.make_control(level=1, threads=2, processors=2, ramsize=ram, host_threads=4, stdin_mode=True)
     try:
         assert B.lib().lrzgpu_compress_file(C.byref(c), r, fo) == 0
     finally:
