@@ -236,7 +236,11 @@ static int decompress_impl(const uint8_t *img, int64_t n, uint8_t **out, int64_t
 		const size_t base = pos + 2 + (size_t)cb, hlen = 1 + 3 * (size_t)cb;
 		size_t end = base + 2 * hlen;
 		if (!sized) {
-			const uint64_t chunk_field = val(img + pos + 2, cb); // >= the chunk's bytes (never below one page)
+			// >= the chunk's bytes: never below one page -- of which a one-byte field keeps only the low byte
+			// (src/stream.c:1150-1152, 1747: "Chunk size: smaller than 4,096 bytes" on the read side)
+			uint64_t chunk_field = val(img + pos + 2, cb);
+			if (chunk_field < 4096)
+				chunk_field = 4096;
 			if (chunk_field > ((uint64_t)1 << 46) || at + chunk_field < at) {
 				rc = LRZGPU_E_FORMAT;
 				break;
