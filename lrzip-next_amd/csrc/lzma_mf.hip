@@ -105,14 +105,21 @@ __global__ void __launch_bounds__(256) k_flag_heads(const uint32_t *__restrict__
 		flags[k] = (k == 0 || skey[k] != skey[k - 1]) ? 1 : 0;
 }
 
+// bucket lengths; *n_long = how many of them have at least `long_min` positions (those go to k_bt_wave)
 __global__ void __launch_bounds__(256) k_seg_len(const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ nseg_p,
-						 uint32_t n4, uint32_t *__restrict__ seg_len)
+						 uint32_t n4, uint32_t *__restrict__ seg_len, uint32_t long_min, uint32_t *__restrict__ n_long)
 {
 	uint32_t nseg = *nseg_p;
 	uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
 	uint32_t stride = gridDim.x * blockDim.x;
-	for (; s < nseg; s += stride)
-		seg_len[s] = (s + 1 < nseg ? seg_start[s + 1] : n4) - seg_start[s];
+	uint32_t mine = 0;
+	for (; s < nseg; s += stride) {
+		const uint32_t len = (s + 1 < nseg ? seg_start[s + 1] : n4) - seg_start[s];
+		seg_len[s] = len;
+		mine += len >= long_min ? 1u : 0u;
+	}
+	if (mine)
+		atomicAdd(n_long, mine);
 }
 
 constexpr int kMaxRec = 128; // u32 entries per position: 2 * (2 hash pairs + cut (<= 48)) -> 100
@@ -155,24 +162,172 @@ __device__ __forceinline__ uint32_t prefix_mismatch(const uint32_t a[5], const u
 	const uint32_t x2 = a[4] ^ b[4];
 	return x2 ? 16 + ((uint32_t)(__ffs((int)x2) - 1) >> 3) : 20;
 }
-__device__ __forceinline__ uint32_t prefix_byte(const uint32_t a[5], uint32_t k) { return (a[k >> 2] >> (8 * (k & 3))) & 0xFF; }
+// (selects, not a[k >> 2]: a register array indexed by a variable goes to scratch memory)
+__device__ __forceinline__ uint32_t prefix_byte(const uint32_t a[5], uint32_t k)
+{
+	const uint32_t w = k < 4 ? a[0] : k < 8 ? a[1] : k < 12 ? a[2] : k < 16 ? a[3] : a[4];
+	return (w >> (8 * (k & 3))) & 0xFF;
+}
 
+// bytes 0..19 at a position as a node prefix (zero beyond the end of the block: never compared)
+__device__ __forceinline__ void node_prefix(const uint8_t *cur, uint32_t avail, uint32_t w[5])
+{
+	if (avail >= kNodeBytes) {
+		const uint64_t q0 = load_u64(cur), q1 = load_u64(cur + 8);
+		w[0] = (uint32_t)q0;
+		w[1] = (uint32_t)(q0 >> 32);
+		w[2] = (uint32_t)q1;
+		w[3] = (uint32_t)(q1 >> 32);
+		w[4] = load_u32(cur + 16);
+	} else {
+#pragma unroll
+		for (int k = 0; k < 5; k++)
+			w[k] = 0;
+#pragma unroll
+		for (uint32_t k = 0; k < kNodeBytes; k++) // (static indices)
+			if (k < avail)
+				w[k >> 2] |= (uint32_t)cur[k] << (8 * (k & 3));
+	}
+}
+
+// agreement of the current position with a visited node: starts from min(len0, len1) like the reference, the first 20
+// bytes from the node itself, the rest from the block (unaligned loads stay inside [0, len_limit) <= avail)
+__device__ __forceinline__ uint32_t agree_len(const uint32_t nw[5], const uint32_t mw[5], const uint8_t *cur, const uint8_t *pb, uint32_t len,
+					      uint32_t len_limit)
+{
+	if (len < kNodeBytes) {
+		const uint32_t m = prefix_mismatch(nw, mw);
+		const uint32_t lim = len_limit < kNodeBytes ? len_limit : kNodeBytes;
+		len = m < lim ? m : lim;
+	}
+	if (len >= kNodeBytes && len < len_limit) {
+		while (len + 32 <= len_limit) {
+			uint64_t x[4];
+#pragma unroll
+			for (int w = 0; w < 4; w++)
+				x[w] = load_u64(pb + len + 8 * w) ^ load_u64(cur + len + 8 * w);
+#pragma unroll
+			for (int w = 0; w < 4; w++)
+				if (x[w])
+					return len + 8 * w + ((uint32_t)(__ffsll((long long)x[w]) - 1) >> 3);
+			len += 32;
+		}
+		while (len + 8 <= len_limit) {
+			const uint64_t x = load_u64(pb + len) ^ load_u64(cur + len);
+			if (x)
+				return len + ((uint32_t)(__ffsll((long long)x) - 1) >> 3);
+			len += 8;
+		}
+		while (len != len_limit && pb[len] == cur[len])
+			++len;
+	}
+	return len;
+}
+
+// LZ-thread merge: MixMatches3 (h2/h3 candidates nearer than the first tree match); returns the number of entries
+__device__ __forceinline__ uint32_t mix_matches(const uint8_t *__restrict__ src, const uint8_t *cur, uint32_t i, uint32_t pos, uint32_t dict,
+						 bool have_tree, uint32_t first_dist1, const uint32_t *__restrict__ prev2,
+						 const uint32_t *__restrict__ prev3, uint32_t mix[4])
+{
+	uint32_t nmix = 0;
+	const uint32_t min_pos = have_tree ? pos - first_dist1 : (pos > dict ? pos - dict : 1);
+	// (a first tree match at distance 1 leaves nothing nearer: no loads at all)
+	const uint32_t c2 = min_pos < pos ? prev2[i] : 0, c3 = min_pos < pos ? prev3[i] : 0;
+	bool done = false;
+	if (c2 >= min_pos && src[c2 - 1] == cur[0]) {
+		mix[1] = pos - c2 - 1;
+		if (src[c2 - 1 + 2] == cur[2]) {
+			mix[0] = 3;
+			done = true;
+		} else
+			mix[0] = 2;
+		nmix = 2;
+	}
+	if (!done && c3 >= min_pos && src[c3 - 1] == cur[0]) {
+		if (nmix == 0) { // (static indices: mix[] stays in registers)
+			mix[0] = 3;
+			mix[1] = pos - c3 - 1;
+		} else {
+			mix[2] = 3;
+			mix[3] = pos - c3 - 1;
+		}
+		nmix += 2;
+	}
+	return nmix;
+}
+__device__ __forceinline__ void put_mix(uint32_t *o, const uint32_t mix[4], uint32_t nmix)
+{
+	if (nmix >= 2) {
+		o[0] = mix[0];
+		o[1] = mix[1];
+	}
+	if (nmix == 4) {
+		o[2] = mix[2];
+		o[3] = mix[3];
+	}
+}
+
+// Output space for the lists of one wavefront: the wave takes the pool in pieces (one returning global atomic per
+// kChunk entries instead of one per position -- a ~1 us round trip each) and hands them out with a prefix sum over the
+// lanes' counts.  Every lane of the wave must call this (cnt = 0 for lanes with nothing to write).
+struct WaveAlloc {
+	unsigned long long base; // wave-uniform
+	uint32_t free_;
+	uint32_t chunk; // entries per piece: 8192 on real blocks, less where the pool itself is small
+};
+static inline uint32_t pool_chunk(unsigned long long pool_cap)
+{
+	const unsigned long long c = pool_cap / 4096;
+	return (uint32_t)(c < 64 ? 64 : (c > 8192 ? 8192 : c));
+}
+__device__ __forceinline__ unsigned long long wave_take(WaveAlloc &a, uint32_t cnt, unsigned long long *__restrict__ cursor)
+{
+	// inclusive prefix sum over the 64 lanes
+	uint32_t incl = cnt;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t v = __shfl_up(incl, o);
+		if ((int)(threadIdx.x & 63) >= o)
+			incl += v;
+	}
+	const uint32_t total = __shfl(incl, 63);
+	if (total == 0)
+		return 0;
+	if (total > a.free_) { // (what is left of the old piece is simply not used)
+		const uint32_t take = total > a.chunk ? total : a.chunk;
+		unsigned long long b = 0;
+		if ((threadIdx.x & 63) == 0)
+			b = atomicAdd(cursor, (unsigned long long)take);
+		a.base = __shfl(b, 0);
+		a.free_ = take;
+	}
+	const unsigned long long st = a.base + (incl - cnt);
+	a.base += total;
+	a.free_ -= total;
+	return st;
+}
+
+// ---- short buckets: one lane per bucket ---------------------------------------------------------------------------
+// The lane replays its bucket's positions in order.  Match records are collected in LDS (one column per lane), output
+// space comes from wave_take().  The loop over the bucket is wave-uniform (lanes whose bucket is done idle along), so
+// that the allocation can be a wave operation; buckets are scheduled by length, a wave's 64 buckets are alike.
 __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint32_t n,
 					   const uint32_t *__restrict__ spos,
 					   const uint32_t *__restrict__ seg_len_sorted, const uint32_t *__restrict__ seg_start_sorted,
-					   const uint32_t *__restrict__ nseg_p,
+					   const uint32_t *__restrict__ nseg_p, uint32_t first_seg,
 					   BtNode *__restrict__ node,
 					   const uint32_t *__restrict__ prev2, const uint32_t *__restrict__ prev3,
 					   uint32_t dict, uint32_t fb, uint32_t cut,
 					   uint8_t *__restrict__ counts, uint64_t *__restrict__ tmp_start,
 					   uint32_t *__restrict__ pool, unsigned long long *__restrict__ cursor,
-					   unsigned long long pool_cap, int *__restrict__ err)
+					   unsigned long long pool_cap, uint32_t chunk, int *__restrict__ err)
 {
-	const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-	if (g >= *nseg_p)
-		return;
-	const uint32_t k0 = seg_start_sorted[g];
-	const uint32_t L = seg_len_sorted[g];
+	__shared__ uint32_t rec_s[kMaxRec][64];
+	const uint32_t lane = threadIdx.x;
+	const uint32_t g = first_seg + blockIdx.x * blockDim.x + threadIdx.x;
+	const bool have = g < *nseg_p;
+	const uint32_t k0 = have ? seg_start_sorted[g] : 0;
+	const uint32_t L = have ? seg_len_sorted[g] : 0;
 	const uint32_t cyc_size = dict + 1;
 	uint32_t prev = 0; // 1-based position of the previous element of this bucket
 	// runs of one byte value put millions of consecutive positions into one bucket; each of them
@@ -180,216 +335,134 @@ __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint
 	// sons.  Once that has happened for pos-1, pos only has to look at one new byte.
 	bool run_ok = false;
 	uint32_t run_s0 = 0, run_s1 = 0;
-	unsigned long long loc_base = 0;
-	uint32_t loc_free = 0;
+	WaveAlloc wa{0, 0, chunk};
 
-	for (uint32_t j = 0; j < L; j++) {
-		const uint32_t self = k0 + j; // sorted index of this position = its node
-		const uint32_t i = spos[self];
-		const uint32_t pos = i + 1;
-		const uint8_t *cur = src + i;
-		const uint32_t avail = n - i;
-		const uint32_t len_limit = avail < fb ? avail : fb;
-		const uint32_t cbs = pos < cyc_size ? pos : cyc_size;
-		uint32_t rec[kMaxRec];
-		uint32_t nrec = 0;
-		uint32_t delta = pos - prev; // prev == 0 -> delta == pos >= cbs -> empty
-		// the node of this position: its first 20 bytes (zero beyond the end of the block: never compared)
-		BtNode me;
-		me.pos = pos;
-		if (avail >= kNodeBytes) {
-			const uint64_t q0 = load_u64(cur), q1 = load_u64(cur + 8);
-			me.w[0] = (uint32_t)q0;
-			me.w[1] = (uint32_t)(q0 >> 32);
-			me.w[2] = (uint32_t)q1;
-			me.w[3] = (uint32_t)(q1 >> 32);
-			me.w[4] = load_u32(cur + 16);
-		} else {
-#pragma unroll
-			for (int k = 0; k < 5; k++)
-				me.w[k] = 0;
-			for (uint32_t k = 0; k < avail; k++)
-				me.w[k >> 2] |= (uint32_t)cur[k] << (8 * (k & 3));
-		}
-		me.son0 = me.son1 = 0;
+	for (uint32_t j = 0; __any(j < L); j++) {
+		const bool act = j < L;
+		uint32_t nrec = 0, nmix = 0, i = 0, pos = 0, len_limit = 0;
+		uint32_t mix[4];
+		const uint8_t *cur = src;
+		if (act) {
+			const uint32_t self = k0 + j; // sorted index of this position = its node
+			i = spos[self];
+			pos = i + 1;
+			cur = src + i;
+			const uint32_t avail = n - i;
+			len_limit = avail < fb ? avail : fb;
+			const uint32_t cbs = pos < cyc_size ? pos : cyc_size;
+			uint32_t delta = pos - prev; // prev == 0 -> delta == pos >= cbs -> empty
+			BtNode me;
+			me.pos = pos;
+			node_prefix(cur, avail, me.w);
+			me.son0 = me.son1 = 0;
 
-		if (delta >= cbs) {
-			node[self] = me;
-			run_ok = false;
-		} else if (run_ok && delta == 1 && len_limit == fb && cur[fb - 1] == cur[fb - 2]) {
-			me.son0 = run_s0;
-			me.son1 = run_s1;
-			node[self] = me;
-			rec[0] = fb;
-			rec[1] = 0;
-			nrec = 2;
-		} else {
-			run_ok = false;
-			node[self] = me;
-			// ptr0 / ptr1 of the reference: where the next "greater" / "smaller" subtree root goes.  They
-			// start at this position's own pair, then move into visited nodes.
-			uint32_t *ptr0 = &node[self].son1, *ptr1 = &node[self].son0;
-			uint32_t len0 = 0, len1 = 0, max_len = 3, cv = cut;
-			uint32_t cur_ref = self; // sorted index + 1 of the predecessor in the bucket (j > 0 here)
-			for (;;) {
-				BtNode *np = node + (cur_ref - 1);
-				const BtNode N = *np;
-				delta = pos - N.pos;
-				if (delta >= cbs) {
-					*ptr0 = *ptr1 = 0;
-					break;
-				}
-				const uint8_t *pb = cur - delta;
-				uint32_t len = len0 < len1 ? len0 : len1;
-				bool full = false;
-				uint32_t b_node, b_cur; // the bytes that decide the branch
-				if (len < kNodeBytes) {
-					const uint32_t m = prefix_mismatch(N.w, me.w);
-					const uint32_t lim = len_limit < kNodeBytes ? len_limit : kNodeBytes;
-					len = m < lim ? m : lim;
-				}
-				if (len >= kNodeBytes && len < len_limit) {
-					// agreement beyond the cached prefix: the block itself (unaligned loads stay inside
-					// [0, len_limit) <= avail)
-					while (len + 32 <= len_limit) {
-						uint64_t x[4];
-#pragma unroll
-						for (int w = 0; w < 4; w++)
-							x[w] = load_u64(pb + len + 8 * w) ^ load_u64(cur + len + 8 * w);
-						bool hit = false;
-#pragma unroll
-						for (int w = 0; w < 4; w++)
-							if (!hit && x[w]) {
-								len += 8 * w + ((uint32_t)(__ffsll((long long)x[w]) - 1) >> 3);
-								hit = true;
-							}
-						if (hit)
-							goto cmp_done;
-						len += 32;
-					}
-					while (len + 8 <= len_limit) {
-						const uint64_t x = load_u64(pb + len) ^ load_u64(cur + len);
-						if (x) {
-							len += (uint32_t)(__ffsll((long long)x) - 1) >> 3;
-							goto cmp_done;
-						}
-						len += 8;
-					}
-					while (len != len_limit && pb[len] == cur[len])
-						++len;
-				}
-			cmp_done:
-				full = len == len_limit;
-				if (max_len < len) {
-					max_len = len;
-					rec[nrec++] = len;
-					rec[nrec++] = delta - 1;
-					if (full) {
-						*ptr1 = N.son0;
-						*ptr0 = N.son1;
-						if (delta == 1 && nrec == 2 && len_limit == fb && pos == prev + 1) {
-							run_ok = true; // first step, full length, distance 1
-							run_s0 = N.son0;
-							run_s1 = N.son1;
-						}
+			if (delta >= cbs) {
+				node[self] = me;
+				run_ok = false;
+			} else if (run_ok && delta == 1 && len_limit == fb && cur[fb - 1] == cur[fb - 2]) {
+				me.son0 = run_s0;
+				me.son1 = run_s1;
+				node[self] = me;
+				rec_s[0][lane] = fb;
+				rec_s[1][lane] = 0;
+				nrec = 2;
+			} else {
+				run_ok = false;
+				node[self] = me;
+				// ptr0 / ptr1 of the reference: where the next "greater" / "smaller" subtree root goes.  They
+				// start at this position's own pair, then move into visited nodes.
+				uint32_t *ptr0 = &node[self].son1, *ptr1 = &node[self].son0;
+				uint32_t len0 = 0, len1 = 0, max_len = 3, cv = cut;
+				uint32_t cur_ref = self; // sorted index + 1 of the predecessor in the bucket (j > 0 here)
+				for (;;) {
+					BtNode *np = node + (cur_ref - 1);
+					const BtNode N = *np;
+					delta = pos - N.pos;
+					if (delta >= cbs) {
+						*ptr0 = *ptr1 = 0;
 						break;
 					}
+					const uint8_t *pb = cur - delta;
+					const uint32_t len = agree_len(N.w, me.w, cur, pb, len0 < len1 ? len0 : len1, len_limit);
+					if (max_len < len) {
+						max_len = len;
+						rec_s[nrec][lane] = len;
+						rec_s[nrec + 1][lane] = delta - 1;
+						nrec += 2;
+						if (len == len_limit) {
+							*ptr1 = N.son0;
+							*ptr0 = N.son1;
+							if (delta == 1 && nrec == 2 && len_limit == fb && pos == prev + 1) {
+								run_ok = true; // first step, full length, distance 1
+								run_s0 = N.son0;
+								run_s1 = N.son1;
+							}
+							break;
+						}
+					}
+					// (len < len_limit here: a full-length agreement that is not a new maximum cannot happen --
+					// max_len < len_limit until the first one, which breaks)
+					uint32_t b_node, b_cur; // the bytes that decide the branch
+					if (len < kNodeBytes) {
+						b_node = prefix_byte(N.w, len);
+						b_cur = prefix_byte(me.w, len);
+					} else {
+						b_node = pb[len];
+						b_cur = cur[len];
+					}
+					uint32_t next;
+					if (b_node < b_cur) {
+						*ptr1 = cur_ref;
+						ptr1 = &np->son1;
+						len1 = len;
+						next = N.son1;
+					} else {
+						*ptr0 = cur_ref;
+						ptr0 = &np->son0;
+						len0 = len;
+						next = N.son0;
+					}
+					if (next >= cur_ref) { // corrupt tree (cannot happen): stop like the reference
+						*err = 2;
+						*ptr0 = *ptr1 = 0;
+						break;
+					}
+					if (--cv == 0 || next == 0) {
+						*ptr0 = *ptr1 = 0;
+						break;
+					}
+					cur_ref = next;
 				}
-				// (len < len_limit here: a full-length agreement that is not a new maximum cannot happen --
-				// max_len < len_limit until the first one, which breaks)
-				if (len < kNodeBytes) {
-					b_node = prefix_byte(N.w, len);
-					b_cur = prefix_byte(me.w, len);
-				} else {
-					b_node = pb[len];
-					b_cur = cur[len];
-				}
-				uint32_t next;
-				if (b_node < b_cur) {
-					*ptr1 = cur_ref;
-					ptr1 = &np->son1;
-					len1 = len;
-					next = N.son1;
-				} else {
-					*ptr0 = cur_ref;
-					ptr0 = &np->son0;
-					len0 = len;
-					next = N.son0;
-				}
-				if (next >= cur_ref) { // corrupt tree (cannot happen): stop like the reference
-					*err = 2;
-					*ptr0 = *ptr1 = 0;
-					break;
-				}
-				if (--cv == 0 || next == 0) {
-					*ptr0 = *ptr1 = 0;
-					break;
-				}
-				cur_ref = next;
 			}
-		}
-		prev = pos;
-
-		// LZ-thread merge: MixMatches3 (h2/h3 candidates nearer than the first tree match)
-		uint32_t mix[4];
-		uint32_t nmix = 0;
-		{
-			const uint32_t min_pos = nrec ? pos - rec[1] : (pos > dict ? pos - dict : 1);
-			// (a first tree match at distance 1 leaves nothing nearer: no loads at all)
-			const uint32_t c2 = min_pos < pos ? prev2[i] : 0, c3 = min_pos < pos ? prev3[i] : 0;
-			bool done = false;
-			if (c2 >= min_pos && src[c2 - 1] == cur[0]) {
-				mix[1] = pos - c2 - 1;
-				if (src[c2 - 1 + 2] == cur[2]) {
-					mix[0] = 3;
-					done = true;
-				} else
-					mix[0] = 2;
-				nmix = 2;
-			}
-			if (!done && c3 >= min_pos && src[c3 - 1] == cur[0]) {
-				mix[nmix++] = 3;
-				mix[nmix++] = pos - c3 - 1;
-			}
+			prev = pos;
+			nmix = mix_matches(src, cur, i, pos, dict, nrec != 0, nrec ? rec_s[1][lane] : 0, prev2, prev3, mix);
 		}
 		const uint32_t cnt = nmix + nrec;
-		counts[i] = (uint8_t)cnt;
-		if (cnt) {
-			// output space: one returning atomic per position is a ~1 us round trip; a lane that walks a
-			// long bucket alone takes its space in pieces (a short bucket wastes nothing)
-			unsigned long long st;
-			if (L >= 64) {
-				if (cnt > loc_free) {
-					uint32_t take = (L - j) < 256 ? (L - j) * 4 : 1024;
-					if (take < cnt)
-						take = cnt;
-					loc_base = atomicAdd(cursor, (unsigned long long)take);
-					loc_free = take;
+		const unsigned long long st = wave_take(wa, cnt, cursor);
+		if (act) {
+			counts[i] = (uint8_t)cnt;
+			if (cnt) {
+				tmp_start[i] = st;
+				if (st + cnt > pool_cap) {
+					*err = 1;
+				} else {
+					uint32_t *o = pool + st;
+					put_mix(o, mix, nmix);
+					for (uint32_t k = 0; k < nrec; k++)
+						o[nmix + k] = rec_s[k][lane];
 				}
-				st = loc_base;
-				loc_base += cnt;
-				loc_free -= cnt;
-			} else
-				st = atomicAdd(cursor, (unsigned long long)cnt);
-			tmp_start[i] = st;
-			if (st + cnt > pool_cap) {
-				*err = 1;
-			} else {
-				uint32_t *o = pool + st;
-				for (uint32_t k = 0; k < nmix; k++)
-					o[k] = mix[k];
-				for (uint32_t k = 0; k < nrec; k++)
-					o[nmix + k] = rec[k];
 			}
 		}
 
 		// Inside a run of one byte value every further position repeats this one: a full-length match
 		// at distance 1, no nearer h2/h3 candidate, the predecessor's two sons.  They need no tree
-		// reads, so a lane that owns a multi-million-position bucket of zeros writes them eight at a
-		// time (one load of the next bucket entries, one of the next bytes) instead of walking.
-		if (run_ok && L >= 64 && len_limit == fb) {
+		// reads, so the lane writes them eight at a time (one load of the next bucket entries, one of the
+		// next bytes) instead of walking.  (Long run buckets go to k_bt_wave, which does 64 at a time.)
+		if (act && run_ok && L >= 64 && len_limit == fb) {
 			const uint32_t b = cur[fb - 1];
 			uint32_t t = 0; // positions done beyond this one
+			unsigned long long loc_base = 0;
+			uint32_t loc_free = 0;
 			for (;;) {
 				if (j + 1 + t + 8 > L || (unsigned long long)i + t + 8 + fb > n)
 					break;
@@ -415,19 +488,18 @@ __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint
 					node[k0 + j + 1 + t + q] = rn;
 					counts[iq] = 2;
 					if (loc_free < 2) {
-						uint32_t take = (L - j) < 256 ? (L - j) * 4 : 1024;
-						loc_base = atomicAdd(cursor, (unsigned long long)take);
-						loc_free = take;
+						loc_free = chunk < 1024 ? chunk : 1024;
+						loc_base = atomicAdd(cursor, (unsigned long long)loc_free);
 					}
-					const unsigned long long st = loc_base;
+					const unsigned long long rs = loc_base;
 					loc_base += 2;
 					loc_free -= 2;
-					tmp_start[iq] = st;
-					if (st + 2 > pool_cap)
+					tmp_start[iq] = rs;
+					if (rs + 2 > pool_cap)
 						*err = 1;
 					else {
-						pool[st] = fb;
-						pool[st + 1] = 0;
+						pool[rs] = fb;
+						pool[rs + 1] = 0;
 					}
 				}
 				t += ok;
@@ -436,6 +508,303 @@ __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint
 			}
 			j += t;
 			prev = pos + t;
+		}
+	}
+}
+
+// ---- long buckets: one WAVEFRONT per bucket, walks pipelined ----------------------------------------------------------
+// The serial order of a bucket is a chain: the walk of position j starts at the node of position j - 1 and re-roots the
+// tree.  But at any moment an unfinished walk owns exactly TWO slots of the tree -- the two link words its next
+// "smaller" / "greater" subtree root will be written to (first the two sons of its own node, then sons of visited
+// nodes) -- every other word it wrote is final, and a node's position and bytes never change.  The subtree an
+// unfinished walk may still visit hangs below those two slots and is reachable from newer roots only THROUGH them.
+// So a later walk may run ahead as long as it never reads a slot an earlier unfinished walk still owns: it then sees
+// exactly what the serial order would have shown it.
+//
+// Lane t of the wave runs one walk; walks are started in bucket order as lanes fall free (64 in flight).  A slot that
+// is owned is MARKED in memory: the owner stores kPending into it when it takes it (its own node is created with two
+// pending sons; moving into a visited node's son marks that son in the same step that resolves the slot left behind)
+// and the real value when it resolves it.  A walk that loads kPending where it wants to go stalls and looks again in
+// the next round; the oldest unfinished walk never meets a mark (marks only lie in regions no older walk can reach),
+// so the wave always makes progress.  All tree words are read and written with agent-scope atomics (they go to L2:
+// no stale L1 lines between the lanes of the wave) and a fence separates a round's stores from the next round's loads.
+// Runs of one byte value (every position: full-length match with its predecessor at the first step) would serialise
+// the pipeline; when the oldest walk in flight hits one the wave switches to writing such positions 64 at a time.
+constexpr uint32_t kPending = 0xFFFFFFFFu;
+__device__ __forceinline__ uint32_t ld_coh(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint64_t ld_coh64(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_coh(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_coh64(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void store_node_coh(BtNode *np, const BtNode &v)
+{
+	uint64_t *q = reinterpret_cast<uint64_t *>(np);
+	st_coh64(q + 1, (uint64_t)v.pos | ((uint64_t)v.w[0] << 32));
+	st_coh64(q + 2, (uint64_t)v.w[1] | ((uint64_t)v.w[2] << 32));
+	st_coh64(q + 3, (uint64_t)v.w[3] | ((uint64_t)v.w[4] << 32));
+	st_coh64(q + 0, (uint64_t)v.son0 | ((uint64_t)v.son1 << 32));
+}
+
+enum : uint32_t { W_IDLE = 0, W_LOAD = 1, W_SONS = 2, W_FINISH = 3, W_OVER = 4 };
+
+__global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src, uint32_t n,
+						const uint32_t *__restrict__ spos,
+						const uint32_t *__restrict__ seg_len_sorted, const uint32_t *__restrict__ seg_start_sorted,
+						BtNode *node,
+						const uint32_t *__restrict__ prev2, const uint32_t *__restrict__ prev3,
+						uint32_t dict, uint32_t fb, uint32_t cut,
+						uint8_t *__restrict__ counts, uint64_t *__restrict__ tmp_start,
+						uint32_t *__restrict__ pool, unsigned long long *__restrict__ cursor,
+						unsigned long long pool_cap, uint32_t chunk, int *__restrict__ err)
+{
+	__shared__ uint32_t rec_s[kMaxRec][64];
+	const uint32_t lane = threadIdx.x;
+	const uint64_t lt_mask = ((uint64_t)1 << lane) - 1;
+	const uint32_t k0 = seg_start_sorted[blockIdx.x];
+	const uint32_t L = seg_len_sorted[blockIdx.x];
+	const uint32_t cyc_size = dict + 1;
+	uint32_t *const words = reinterpret_cast<uint32_t *>(node); // slot (x, side) = words[8 * x + side]
+	WaveAlloc wa{0, 0, chunk};
+	uint32_t next_j = 0; // wave-uniform: the next position of the bucket that has no walk yet
+
+	// per-lane walk state
+	uint32_t state = W_IDLE;
+	uint32_t wj = 0, i = 0, pos = 0, len_limit = 0, cbs = 0, prev_pos = 0;
+	uint32_t mw[5] = {0, 0, 0, 0, 0};
+	uint32_t slot0 = 0, slot1 = 0; // ptr0 / ptr1 of the reference as word indices
+	uint32_t len0 = 0, len1 = 0, max_len = 3, cv = 0, cur_ref = 0, nrec = 0;
+	// the node the walk stands on, kept while it waits for a son
+	uint32_t n_len = 0;  // agreement with it
+	uint32_t n_side = 0; // 0 / 1: the son it will descend into; 2: full-length agreement, both sons are taken over
+	bool run_hit = false;
+	uint32_t run_s0 = 0, run_s1 = 0;
+
+	for (;;) {
+		// ---- start walks on free lanes, in bucket order --------------------------------------------------------
+		{
+			const bool idle = state == W_IDLE;
+			const uint64_t m = __ballot(idle);
+			if (m) {
+				const uint32_t j = next_j + (uint32_t)__popcll(m & lt_mask);
+				if (idle) {
+					if (j >= L)
+						state = W_OVER;
+					else {
+						wj = j;
+						const uint32_t self = k0 + j;
+						i = spos[self];
+						pos = i + 1;
+						prev_pos = j ? spos[self - 1] + 1 : 0;
+						const uint32_t avail = n - i;
+						len_limit = avail < fb ? avail : fb;
+						cbs = pos < cyc_size ? pos : cyc_size;
+						node_prefix(src + i, avail, mw);
+						nrec = 0;
+						run_hit = false;
+						BtNode me;
+						me.pos = pos;
+#pragma unroll
+						for (int k = 0; k < 5; k++)
+							me.w[k] = mw[k];
+						if (pos - prev_pos >= cbs) { // (prev_pos == 0: the bucket's first position)
+							me.son0 = me.son1 = 0;
+							state = W_FINISH;
+						} else {
+							me.son0 = me.son1 = kPending;
+							slot0 = 8 * self + 1; // ptr0 = &son1, ptr1 = &son0
+							slot1 = 8 * self;
+							len0 = len1 = 0;
+							max_len = 3;
+							cv = cut;
+							cur_ref = self; // sorted index + 1 of the predecessor
+							state = W_LOAD;
+						}
+						store_node_coh(node + self, me);
+					}
+				}
+				next_j += (uint32_t)__popcll(m);
+				if (next_j > L)
+					next_j = L;
+			}
+		}
+		if (__ballot(state != W_OVER) == 0)
+			break;
+		__threadfence(); // the stores of this round (new nodes, resolved and marked slots) before the loads of the next
+
+		// ---- one step of every walk -----------------------------------------------------------------------------
+		if (state == W_LOAD || state == W_SONS) {
+			const uint32_t x = cur_ref - 1;
+			const uint64_t *q = reinterpret_cast<const uint64_t *>(node + x);
+			const uint64_t sons = ld_coh64(q);
+			uint32_t s0 = (uint32_t)sons, s1 = (uint32_t)(sons >> 32);
+			bool go = true;
+			if (state == W_LOAD) {
+				const uint64_t a = ld_coh64(q + 1), b = ld_coh64(q + 2), c = ld_coh64(q + 3);
+				const uint32_t npos = (uint32_t)a;
+				const uint32_t nw[5] = {(uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32), (uint32_t)c, (uint32_t)(c >> 32)};
+				const uint32_t delta = pos - npos;
+				if (delta >= cbs) {
+					st_coh(words + slot0, 0);
+					st_coh(words + slot1, 0);
+					state = W_FINISH;
+					go = false;
+				} else {
+					const uint8_t *cur = src + i, *pb = cur - delta;
+					const uint32_t len = agree_len(nw, mw, cur, pb, len0 < len1 ? len0 : len1, len_limit);
+					n_len = len;
+					n_side = 0;
+					if (max_len < len) {
+						max_len = len;
+						rec_s[nrec][lane] = len;
+						rec_s[nrec + 1][lane] = delta - 1;
+						nrec += 2;
+						if (len == len_limit) {
+							n_side = 2;
+							run_hit = delta == 1 && nrec == 2 && len_limit == fb && pos == prev_pos + 1;
+						}
+					}
+					if (n_side != 2) {
+						uint32_t b_node, b_cur;
+						if (len < kNodeBytes) {
+							b_node = prefix_byte(nw, len);
+							b_cur = prefix_byte(mw, len);
+						} else {
+							b_node = pb[len];
+							b_cur = cur[len];
+						}
+						n_side = b_node < b_cur ? 1 : 0;
+					}
+					state = W_SONS;
+				}
+			}
+			if (go) {
+				if (n_side == 2) {
+					if (s0 != kPending && s1 != kPending) {
+						st_coh(words + slot1, s0);
+						st_coh(words + slot0, s1);
+						run_s0 = s0;
+						run_s1 = s1;
+						state = W_FINISH;
+					} else
+						run_hit = run_hit && true; // waits; the verdict stands
+				} else {
+					const uint32_t next = n_side ? s1 : s0;
+					if (next != kPending) {
+						const uint32_t taken = 8 * x + n_side; // &x.son1 (smaller) / &x.son0
+						if (n_side) {
+							st_coh(words + slot1, cur_ref);
+							slot1 = taken;
+							len1 = n_len;
+						} else {
+							st_coh(words + slot0, cur_ref);
+							slot0 = taken;
+							len0 = n_len;
+						}
+						if (next >= cur_ref) { // corrupt tree (cannot happen): stop like the reference
+							*err = 2;
+							st_coh(words + slot0, 0);
+							st_coh(words + slot1, 0);
+							state = W_FINISH;
+						} else if (--cv == 0 || next == 0) {
+							st_coh(words + slot0, 0);
+							st_coh(words + slot1, 0);
+							state = W_FINISH;
+						} else {
+							st_coh(words + taken, kPending); // ours until this walk writes its next subtree root there
+							cur_ref = next;
+							state = W_LOAD;
+						}
+					}
+				}
+			}
+		}
+
+		// ---- a run of one byte value at the head of the pipeline: 64 positions per round -------------------------------
+		// (the walk that found it is the oldest in flight: everything younger stands at its first node, waiting for a
+		//  son of its predecessor, and has written nothing but its own node -- those walks are simply started again)
+		uint32_t run_from = L; // wave-uniform after the ballot below
+		{
+			const bool hit = state == W_FINISH && run_hit && len_limit == fb;
+			const uint64_t hm = __ballot(hit);
+			if (hm) {
+				const int src_lane = __ffsll((long long)hm) - 1;
+				const uint32_t hj = __shfl(wj, src_lane);
+				// older walks still in flight?
+				const uint64_t older = __ballot((state == W_LOAD || state == W_SONS || state == W_FINISH) && wj < hj);
+				if (!older && __popcll(hm) == 1)
+					run_from = hj;
+			}
+		}
+
+		// ---- finished walks: h2 / h3 candidates, lists out -----------------------------------------------------------------
+		{
+			const bool fin = state == W_FINISH && (run_from == L || wj <= run_from);
+			uint32_t mix[4];
+			uint32_t nmix = 0;
+			if (fin)
+				nmix = mix_matches(src, src + i, i, pos, dict, nrec != 0, nrec ? rec_s[1][lane] : 0, prev2, prev3, mix);
+			const uint32_t cnt = fin ? nmix + nrec : 0;
+			const unsigned long long st = wave_take(wa, cnt, cursor);
+			if (fin) {
+				counts[i] = (uint8_t)cnt;
+				if (cnt) {
+					tmp_start[i] = st;
+					if (st + cnt > pool_cap)
+						*err = 1;
+					else {
+						uint32_t *o = pool + st;
+						put_mix(o, mix, nmix);
+						for (uint32_t k = 0; k < nrec; k++)
+							o[nmix + k] = rec_s[k][lane];
+					}
+				}
+				state = W_IDLE;
+			}
+		}
+
+		if (run_from != L) {
+			// the lane of walk run_from holds the run's byte and sons
+			const uint64_t om = __ballot(wj == run_from && run_hit);
+			const int ol = __ffsll((long long)om) - 1;
+			const uint32_t ri = __shfl(i, ol), rs0 = __shfl(run_s0, ol), rs1 = __shfl(run_s1, ol);
+			const uint32_t b = src[ri + fb - 1];
+			uint32_t t = 0;
+			for (;;) {
+				const uint32_t idx = run_from + 1 + t + lane; // position of the bucket this lane looks at
+				const uint32_t iq = ri + t + 1 + lane;
+				bool ok = idx < L && (unsigned long long)iq + fb <= n;
+				if (ok)
+					ok = spos[k0 + idx] == iq && src[iq + fb - 1] == b;
+				const uint64_t okm = __ballot(ok);
+				const uint32_t m = okm == ~(uint64_t)0 ? 64u : (uint32_t)(__ffsll((long long)~okm) - 1); // leading run of ok lanes
+				const bool mine = lane < m;
+				const unsigned long long st = wave_take(wa, mine ? 2u : 0u, cursor);
+				if (mine) {
+					BtNode rn;
+					rn.son0 = rs0;
+					rn.son1 = rs1;
+					rn.pos = iq + 1;
+#pragma unroll
+					for (int k = 0; k < 5; k++)
+						rn.w[k] = b * 0x01010101u; // fb >= 20 bytes of the run lie ahead of every one of them
+					store_node_coh(node + k0 + idx, rn);
+					counts[iq] = 2;
+					tmp_start[iq] = st;
+					if (st + 2 > pool_cap)
+						*err = 1;
+					else {
+						pool[st] = fb;
+						pool[st + 1] = 0;
+					}
+				}
+				t += m;
+				if (m < 64)
+					break;
+			}
+			// everything younger starts again behind the run
+			next_j = run_from + 1 + t;
+			if (state != W_OVER || next_j < L)
+				state = W_IDLE;
+			run_hit = false;
 		}
 	}
 }
@@ -746,18 +1115,30 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 		tb = w->cub_bytes;
 		HIPCHK(hipcub::DeviceSelect::Flagged(w->cub_tmp, tb, hipcub::CountingInputIterator<uint32_t>(0), w->flags,
 						     w->seg_start, d_nseg, (int)n4, s));
-		hipLaunchKernelGGL(k_seg_len, dim3(g), dim3(256), 0, s, w->seg_start, d_nseg, n4, w->seg_len);
-		uint32_t nseg = 0;
-		HIPCHK(hipMemcpyAsync(&nseg, d_nseg, 4, hipMemcpyDeviceToHost, s));
+		// buckets of at least this many positions get a wavefront each (k_bt_wave), the rest a lane each (k_bt)
+		uint32_t long_min = 1024;
+		if (const char *e = getenv("LRZGPU_BT_WAVE_MIN")) { // read per call: tests force 1 (every bucket through the
+			const long v = atol(e);                      // pipelined kernel) and a huge value (none) inside one process
+			long_min = (uint32_t)(v < 1 ? 1 : (v > 0x7FFFFFFF ? 0x7FFFFFFF : v));
+		}
+		hipLaunchKernelGGL(k_seg_len, dim3(g), dim3(256), 0, s, w->seg_start, d_nseg, n4, w->seg_len, long_min, d_nseg + 1);
+		uint32_t nseg_long[2] = {0, 0};
+		HIPCHK(hipMemcpyAsync(nseg_long, d_nseg, 8, hipMemcpyDeviceToHost, s));
 		HIPCHK(stream_wait(s));
+		const uint32_t nseg = nseg_long[0], nlong = nseg_long[1] > nseg_long[0] ? nseg_long[0] : nseg_long[1];
 		// longest buckets first
 		tb = w->cub_bytes;
 		HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(w->cub_tmp, tb, w->seg_len, w->seg_len_s, w->seg_start,
 								    w->seg_start_s, (int)nseg, 0, 32, s));
 		t_bt = new EventTimer(s);
-		hipLaunchKernelGGL(k_bt, dim3((nseg + 63) / 64), dim3(64), 0, s, d_src, (uint32_t)n, w->spos, w->seg_len_s,
-				   w->seg_start_s, d_nseg, (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, w->counts, w->tmp_start,
-				   w->pool_tmp, d_cursor, w->pool_cap, d_err);
+		if (nlong)
+			hipLaunchKernelGGL(k_bt_wave, dim3(nlong), dim3(64), 0, s, d_src, (uint32_t)n, w->spos, w->seg_len_s, w->seg_start_s,
+					   (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, w->counts, w->tmp_start, w->pool_tmp, d_cursor,
+					   w->pool_cap, pool_chunk(w->pool_cap), d_err);
+		if (nseg > nlong)
+			hipLaunchKernelGGL(k_bt, dim3((nseg - nlong + 63) / 64), dim3(64), 0, s, d_src, (uint32_t)n, w->spos, w->seg_len_s,
+					   w->seg_start_s, d_nseg, nlong, (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, w->counts,
+					   w->tmp_start, w->pool_tmp, d_cursor, w->pool_cap, pool_chunk(w->pool_cap), d_err);
 		t_bt->stop();
 	}
 	{

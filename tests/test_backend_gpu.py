@@ -193,3 +193,39 @@ def test_mf_stream_in_btbuf_format(B, O):
             assert cur == buf[0] and (cur >= (1 << 16) - 2 * fb or pos == len(data))
         assert pos == len(data)
         L.lrzgpu_lzma_mf_close(h)
+
+
+@pytest.mark.parametrize("wave_min", ["1", "64", "1000000000"])
+def test_match_lists_with_forced_bucket_kernels(B, O, wave_min):
+    """The two BT kernels on the same data: LRZGPU_BT_WAVE_MIN=1 sends EVERY bucket through the pipelined
+    wave-per-bucket kernel (k_bt_wave: walks of one bucket in flight together, pending-slot marks, the 64-wide run
+    path), a huge value sends every bucket through the lane-per-bucket kernel (k_bt).  A 5000-word vocabulary gives
+    buckets of 10^4..10^5 positions, a two-symbol alphabet long walks with full-length agreements, runs the bulk path,
+    a small dictionary the window cut-off inside walks."""
+    import os
+    old = os.environ.get("LRZGPU_BT_WAVE_MIN")
+    os.environ["LRZGPU_BT_WAVE_MIN"] = wave_min
+    try:
+        rng = np.random.default_rng(11)
+        cases = [
+            (datagen.text_like(1200000, seed=31), 1 << 25, 64),
+            (datagen.KINDS["few"](400000, seed=32), 1 << 25, 64),
+            (bytes(rng.integers(0, 2, 300000, dtype=np.uint8)), 1 << 25, 64),
+            (datagen.phrase_mix(500000, seed=33), 1 << 16, 32),
+            (datagen.text_like(3000, seed=34) + bytes(200000) + datagen.text_like(3000, seed=35) + b"\x07" * 70000 + b"ab" * 50000, 1 << 25, 64),
+            (bytes(100000), 1 << 25, 64),
+            (b"abcabcabd" * 30000, 1 << 12, 64),
+        ]
+        for n in (0, 1, 3, 4, 5, 63, 64, 65, 129, 1000):
+            cases.append((datagen.KINDS["few"](n, seed=n + 1), 1 << 25, 64))
+        for data, dict_size, fb in cases:
+            cut = 16 + fb // 2
+            oc, op = _lists_from_oracle(O, data, dict_size, fb, cut)
+            gc, gp = B.lzma_match_lists(data, dict_size=dict_size, fb=fb, cut=cut, per_pos=110)
+            assert np.array_equal(gc, oc), (wave_min, len(data), dict_size)
+            assert np.array_equal(gp, op), (wave_min, len(data), dict_size)
+    finally:
+        if old is None:
+            del os.environ["LRZGPU_BT_WAVE_MIN"]
+        else:
+            os.environ["LRZGPU_BT_WAVE_MIN"] = old
