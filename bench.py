@@ -58,7 +58,9 @@ class Profile(C.Structure):
                                           "lz4_bytes", "mf_positions", "mf_entries")] + \
                [("scan_wall_ms", C.c_double), ("resolve_dbg", C.c_int64 * 16), ("long_compare_ms", C.c_double),
                 ("long_compare_launches", C.c_int64), ("long_compare_bytes", C.c_int64), ("spec_rollbacks", C.c_int64),
-                ("spec_cancelled_blocks", C.c_int64), ("victim_rescans", C.c_int64)]
+                ("spec_cancelled_blocks", C.c_int64), ("victim_rescans", C.c_int64),
+                ("union_ms", C.c_double * 8), ("peak_concurrency", C.c_double * 8),
+                ("pipeline_s", C.c_double * 8)]
 
 
 ALPHABETS = {
@@ -200,6 +202,77 @@ def usable_cpus():
     return max(1.0, n)
 
 
+def gpu_state():
+    """Clocks / power / performance level of GPU 0 as rocm-smi reports them right now (context for run-to-run
+    spread: the same launches took 378 ms on one box and 544 ms on another in round 2)."""
+    import subprocess
+    try:
+        out = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--showperflevel", "--showtemp", "--json"],
+                             capture_output=True, text=True, timeout=20).stdout
+        d = json.loads(out)
+        card = d[sorted(d)[0]]
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(t in kl for t in ("sclk", "mclk", "fclk", "power", "performance level", "temperature (sensor junction)")):
+                keep[k] = v
+        return keep
+    except Exception as e:  # no rocm-smi, no permission: say so
+        return {"unavailable": repr(e)[:120]}
+
+
+def file_to_file_leg(B, buf, n_bytes, fresh_ctl):
+    """The metric as test/speedtest.sh:98 defines it -- file in, file out: the identical bytes as a FILE (tmpfs, so
+    the page cache is what the reference's mmap would read too), lrzgpu_compress_file() from its fd to the fd of an
+    output file on the same tmpfs.  Input pages go host -> HBM over PCIe inside the timed region, the image is
+    written with write().  One warm-up pass, one timed pass."""
+    import torch
+    best = None
+    for d in ("/dev/shm", "/tmp"):
+        try:
+            st = os.statvfs(d)
+            if st.f_bavail * st.f_frsize > n_bytes * 1.7:
+                best = d
+                break
+        except OSError:
+            pass
+    if best is None:
+        return {"skipped": "no tmpfs with room for input + image"}
+    src, dst = os.path.join(best, "lrzgpu_bench_in.bin"), os.path.join(best, "lrzgpu_bench_out.lrz")
+    try:
+        with open(src, "wb") as f:
+            piece = 1 << 30
+            for o in range(0, n_bytes, piece):
+                f.write(buf[o:min(n_bytes, o + piece)].cpu().numpy().tobytes())
+        times = []
+        size = 0
+        for _ in range(2):
+            fi = os.open(src, os.O_RDONLY)
+            fo = os.open(dst, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
+            c = fresh_ctl()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rc = B.lib().lrzgpu_compress_file(C.byref(c), fi, fo)
+            os.fsync(fo)
+            dt = time.perf_counter() - t0
+            os.close(fi)
+            os.close(fo)
+            if rc != 0:
+                return {"error": rc}
+            times.append(dt)
+            size = os.path.getsize(dst)
+        return {"value": round(n_bytes / 1048576 / times[-1], 2), "unit": "MB/s (2^20 B/s)", "seconds": round(times[-1], 2),
+                "first_pass_seconds": round(times[0], 2), "output_bytes": size,
+                "what": "lrzgpu_compress_file(fd of a %d-byte file on %s -> fd of a file on %s): pread + H2D of every chunk, "
+                        "write() of every chunk image, magic rewritten at the end; second of two passes" % (n_bytes, best, best)}
+    finally:
+        for pth in (src, dst):
+            try:
+                os.unlink(pth)
+            except OSError:
+                pass
+
+
 def cpu_baseline(buf, n_bytes, sample_bytes, ctl_kw, cores, desc):
     """Oracle driver (CPU restatement of rzip/lz4/container + the reference's own LZMA build, numThreads=2
     per block like the reference) on the HEAD of the identical buffer with the identical flags; chunking
@@ -215,6 +288,7 @@ def cpu_baseline(buf, n_bytes, sample_bytes, ctl_kw, cores, desc):
                                 workers=cores, file_size=n_bytes)
     dt = time.time() - t0
     return {"value": round(sample_bytes / 1048576 / dt, 2), "unit": "MB/s", "cores": cores, "kind": "port",
+            "whole_file": bool(sample_bytes >= n_bytes),
             "sample": "the first %d bytes (%d whole rzip chunk(s)) of the IDENTICAL buffer (%s), identical flags and "
                       "block size (%d B, as for the whole file); oracle rzip/lz4/container restatement (one scan "
                       "thread, like the reference) + oracle/_ref LzmaCompress (reference LZMA sources, numThreads=2 "
@@ -233,7 +307,9 @@ def main():
                     help="file size in MiB (default: 16384 for cfg3, 4096 for cfg2)")
     ap.add_argument("--window", type=int, default=-1, help="-w (x100 MiB); default 21 for cfg3 (8 chunks of 16 GiB), unset for cfg2")
     ap.add_argument("--base-mib", type=int, default=0, help="cfg3 base block (default: file size / 16)")
-    ap.add_argument("--cpu-sample-chunks", type=int, default=1, help="rzip chunks of the same buffer the CPU baseline compresses")
+    ap.add_argument("--cpu-sample-chunks", type=int, default=0,
+                    help="rzip chunks of the same buffer the CPU baseline compresses (0 = the WHOLE file, the default)")
+    ap.add_argument("--no-file-leg", action="store_true", help="skip the untimed-for-`value` file-to-file step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--threads", type=int, default=0, help="-p (default: host cores)")
     ap.add_argument("--host-threads", type=int, default=0,
@@ -337,6 +413,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    state_before = gpu_state() if rank == 0 else None
     L.lrzgpu_profile_reset()
     fence()
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
@@ -355,6 +432,7 @@ def main():
 
     prof = Profile()
     L.lrzgpu_profile_get(C.byref(prof))
+    state_after = gpu_state() if rank == 0 else None
 
     if rank == 0:
         total_mib = args.steps * (n_bytes / 1048576)  # one file per step, whatever the number of GPUs
@@ -376,6 +454,8 @@ def main():
         # The dominant kernel = most accumulated device time (HIP events on the launching streams).  Several
         # launches of it run side by side (one resolver per chunk, one finder per GPU slot), so the sum can
         # exceed the wall time; `achieved` is per launch, as the contract asks.
+        KIND = {"k_tag_scan": 0, "k_resolve": 1, "k_crc32_tiles": 2, "k_gather_runs": 3, "k_lz4_size": 4, "k_bt": 5,
+                "finder (keys + sorts + k_bt + k_gather)": 6, "k_long_compare": 7}
         dom = max(kernels, key=lambda k: kernels[k][0])
         ms, launches, alg_bytes = kernels[dom]
         avg_ms = ms / max(launches, 1)
@@ -398,6 +478,11 @@ def main():
                     "per_kernel_ms_per_step": {k: round(v[0] / steps, 2) for k, v in kernels.items()},
                     "per_kernel_GBps": {k: (round(v[2] / (v[0] * 1e-3) / 1e9, 3) if v[0] > 0 else 0.0)
                                         for k, v in kernels.items()},
+                    # launches of one kernel run side by side (a resolver per chunk, a finder per GPU slot): the sums
+                    # above exceed the step.  Wall time they COVER per step (union of their [start, end) intervals, HIP
+                    # events against one base event) and the most that overlapped:
+                    "per_kernel_wall_union_ms_per_step": {k: round(prof.union_ms[i] / steps, 2) for k, i in KIND.items()},
+                    "per_kernel_peak_concurrency": {k: int(prof.peak_concurrency[i]) for k, i in KIND.items()},
                     "scan_wall_ms_per_step_summed_over_chunks": round(prof.scan_wall_ms / steps, 1),
                     "whole_path": whole,
                     "build_id": build_id(),
@@ -407,9 +492,25 @@ def main():
                     "victim_rescans": int(prof.victim_rescans), "spec_rollbacks": int(prof.spec_rollbacks)}
         if world > 1:
             roofline["note"] = "kernel figures are rank 0's share of the chunks"
+        # what bounds the step: the host stage (parser + range coder on `host_threads` threads) or a device stage
+        pl = [v / steps for v in prof.pipeline_s]
+        step_s = dt / steps
+        stages = {"host parser + range coder (%d threads)" % host_threads: pl[0] / max(host_threads, 1),
+                  "rzip scan (last chunk done)": pl[4], "match finder (last block done)": pl[5]}
+        crit = max(stages, key=lambda k: stages[k])
+        critical_path = {"stage": crit, "seconds_per_step": {k: round(v, 2) for k, v in stages.items()},
+                         "step_seconds": round(step_s, 2),
+                         "encoders_busy_s_per_step": round(pl[0], 1), "encoders_idle_s_per_step": round(pl[1], 1),
+                         "finder_workers_busy_s_per_step": round(pl[2], 1), "lists_d2h_s_per_step": round(pl[3], 1),
+                         "last_encode_done_s": round(pl[6], 2),
+                         "note": "a stage's figure is the time it would need alone on its resources; the step cannot be "
+                                 "shorter than the largest"} if world == 1 else None
+        file_leg = None
+        if world == 1 and not args.no_file_leg:
+            file_leg = file_to_file_leg(B, buf, n_bytes, fresh_ctl)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            sample = min(n_bytes, max(1, args.cpu_sample_chunks) * chunk_size)
+            sample = n_bytes if args.cpu_sample_chunks <= 0 else min(n_bytes, args.cpu_sample_chunks * chunk_size)
             cpu = cpu_baseline(buf, n_bytes, sample, ctl_kw, max(1, int(usable + 0.5)), desc)
         verified = None
         if args.verify and out is not None:
@@ -429,7 +530,14 @@ def main():
                        "parallelism": ("%d chunks scanned concurrently on 1 GPU" % n_chunks) if world == 1 else
                                       ("chunk k -> GPU k mod %d, chunk images handed to rank 0 over %s send/recv" % (world, "RCCL" if backend == "nccl" else backend))},
             "roofline": roofline, "cpu_baseline": cpu,
+            "critical_path": critical_path,
+            "value_file_to_file": file_leg,
+            "gpu_state": {"before_timed_region": state_before, "after_timed_region": state_after},
         }
+        if cpu and cpu.get("value"):
+            line["vs_cpu_baseline"] = {"hbm_resident": round(value / cpu["value"], 2),
+                                       "file_to_file": round(file_leg["value"] / cpu["value"], 2) if file_leg and file_leg.get("value") else None,
+                                       "cpu_sample_is_whole_file": cpu.get("whole_file")}
         if verified is not None:
             line["round_trip_ok"] = verified
         print(json.dumps(line), flush=True)

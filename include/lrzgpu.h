@@ -314,6 +314,17 @@ typedef struct lrzgpu_profile {
 	int64_t spec_cancelled_blocks; /* early-released blocks thrown away by those roll-backs   */
 	int64_t victim_rescans;       /* chunks scanned again because the victim_round they started from
 	                                 was not what their predecessor left (src/rzip.c:308)        */
+	/* Launches of one kind run side by side on different streams (a resolver per chunk, a finder per GPU slot), so
+	 * the summed durations above exceed the wall time.  Per kind -- 0 k_tag_scan, 1 k_resolve, 2 k_crc32_tiles,
+	 * 3 k_gather_runs, 4 k_lz4_size, 5 k_bt (+ k_bt_wave), 6 the whole finder, 7 k_long_compare -- the wall time the
+	 * launches cover (union of their [start, end) intervals since lrzgpu_profile_reset) and the most that overlapped. */
+	double union_ms[8];
+	double peak_concurrency[8];
+	/* the whole-file pipeline, summed over the runs since the reset (seconds): 0 host encoders busy (parser + range
+	 * coder, all threads), 1 host encoders waiting for a block, 2 GPU workers in the finder, 3 GPU workers copying
+	 * lists to the host, 4 when the last chunk's scan ended, 5 when the last finder ended, 6 when the last encoder
+	 * ended (4-6: since the start of their run), 7 wall time of the runs */
+	double pipeline_s[8];
 } lrzgpu_profile;
 void lrzgpu_profile_reset(void);
 void lrzgpu_profile_get(lrzgpu_profile *out);

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -390,6 +391,19 @@ extern "C" void lrzgpu_profile_reset(void)
 	ProfileStore &ps = ProfileStore::get();
 	std::lock_guard<std::mutex> lk(ps.mu);
 	memset(&ps.p, 0, sizeof(ps.p));
+	for (auto &v : ps.iv)
+		v.clear();
+	// time zero of the launch intervals: an event on the current device, recorded and completed now
+	if (ps.base) {
+		(void)hipEventDestroy(ps.base);
+		ps.base = nullptr;
+	}
+	if (hipEventCreate(&ps.base) != hipSuccess || hipEventRecord(ps.base, nullptr) != hipSuccess || hipEventSynchronize(ps.base) != hipSuccess) {
+		(void)hipGetLastError();
+		if (ps.base)
+			(void)hipEventDestroy(ps.base);
+		ps.base = nullptr;
+	}
 }
 
 extern "C" void lrzgpu_profile_get(lrzgpu_profile *out)
@@ -397,6 +411,31 @@ extern "C" void lrzgpu_profile_get(lrzgpu_profile *out)
 	ProfileStore &ps = ProfileStore::get();
 	std::lock_guard<std::mutex> lk(ps.mu);
 	*out = ps.p;
+	// per kind: the wall time its launches cover (union of the intervals) and how many ran side by side at most
+	for (int k = 0; k < PK_COUNT; k++) {
+		std::vector<std::pair<float, int>> ev;
+		ev.reserve(ps.iv[k].size() * 2);
+		for (auto &iv : ps.iv[k]) {
+			ev.push_back(std::make_pair(iv.first, 1));
+			ev.push_back(std::make_pair(iv.second, -1));
+		}
+		std::sort(ev.begin(), ev.end(), [](const std::pair<float, int> &a, const std::pair<float, int> &b) {
+			return a.first < b.first || (a.first == b.first && a.second < b.second);
+		});
+		double covered = 0;
+		int depth = 0, peak = 0;
+		float since = 0;
+		for (auto &e : ev) {
+			if (depth > 0)
+				covered += e.first - since;
+			since = e.first;
+			depth += e.second;
+			if (depth > peak)
+				peak = depth;
+		}
+		out->union_ms[k] = covered;
+		out->peak_concurrency[k] = peak;
+	}
 }
 
 // ---- filters on the device: one block resident in HBM, compress direction, in place -------------------

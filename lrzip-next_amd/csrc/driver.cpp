@@ -818,7 +818,7 @@ struct Feeder {
 			{
 				ProfileStore &ps = ProfileStore::get();
 				std::lock_guard<std::mutex> lk(ps.mu);
-				ps.p.lz4_ms += b.timer->ms();
+				ps.p.lz4_ms += b.timer->ms_noted(ps, PK_LZ4);
 				ps.p.lz4_launches++;
 				ps.p.lz4_bytes += b.bytes;
 			}
@@ -1234,7 +1234,7 @@ struct Run {
 			return LRZGPU_E_HIP;
 		ProfileStore &ps = ProfileStore::get();
 		std::lock_guard<std::mutex> lk(ps.mu);
-		ps.p.gather_ms += tg.ms();
+		ps.p.gather_ms += tg.ms_noted(ps, PK_GATHER);
 		ps.p.gather_launches++;
 		ps.p.gather_bytes += S1 - S0;
 		return 0;
@@ -1699,6 +1699,9 @@ int Run::run()
 		ProfileStore &ps = ProfileStore::get();
 		std::lock_guard<std::mutex> lk(ps.mu);
 		ps.p.victim_rescans += n_rescans;
+		const double vals[8] = {P.enc_busy, P.enc_wait, P.mf_busy, P.d2h_busy, t_scan_last - t0, P.t_last_mf - t0, P.t_last_enc - t0, now_s() - t0};
+		for (int k = 0; k < 8; k++)
+			ps.p.pipeline_s[k] += vals[k] > 0 ? vals[k] : 0;
 	}
 	{
 		LzmaParams p;

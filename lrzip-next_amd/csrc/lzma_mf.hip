@@ -275,10 +275,11 @@ struct WaveAlloc {
 	uint32_t free_;
 	uint32_t chunk; // entries per piece: 8192 on real blocks, less where the pool itself is small
 };
-static inline uint32_t pool_chunk(unsigned long long pool_cap)
+// every wave may leave one piece partly unused: all of them together get at most half the pool
+static inline uint32_t pool_chunk(unsigned long long pool_cap, unsigned long long waves)
 {
-	const unsigned long long c = pool_cap / 4096;
-	return (uint32_t)(c < 64 ? 64 : (c > 8192 ? 8192 : c));
+	const unsigned long long c = pool_cap / 2 / (waves ? waves : 1);
+	return (uint32_t)(c < 16 ? 16 : (c > 8192 ? 8192 : c));
 }
 __device__ __forceinline__ unsigned long long wave_take(WaveAlloc &a, uint32_t cnt, unsigned long long *__restrict__ cursor)
 {
@@ -1130,15 +1131,16 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 		tb = w->cub_bytes;
 		HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(w->cub_tmp, tb, w->seg_len, w->seg_len_s, w->seg_start,
 								    w->seg_start_s, (int)nseg, 0, 32, s));
+		const uint32_t chunk = pool_chunk(w->pool_cap, (unsigned long long)nlong + (nseg - nlong + 63) / 64);
 		t_bt = new EventTimer(s);
 		if (nlong)
 			hipLaunchKernelGGL(k_bt_wave, dim3(nlong), dim3(64), 0, s, d_src, (uint32_t)n, w->spos, w->seg_len_s, w->seg_start_s,
 					   (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, w->counts, w->tmp_start, w->pool_tmp, d_cursor,
-					   w->pool_cap, pool_chunk(w->pool_cap), d_err);
+					   w->pool_cap, chunk, d_err);
 		if (nseg > nlong)
 			hipLaunchKernelGGL(k_bt, dim3((nseg - nlong + 63) / 64), dim3(64), 0, s, d_src, (uint32_t)n, w->spos, w->seg_len_s,
 					   w->seg_start_s, d_nseg, nlong, (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, w->counts,
-					   w->tmp_start, w->pool_tmp, d_cursor, w->pool_cap, pool_chunk(w->pool_cap), d_err);
+					   w->tmp_start, w->pool_tmp, d_cursor, w->pool_cap, chunk, d_err);
 		t_bt->stop();
 	}
 	{
@@ -1156,9 +1158,9 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 	{
 		ProfileStore &ps = ProfileStore::get();
 		std::lock_guard<std::mutex> lk(ps.mu);
-		ps.p.mf_total_ms += t_all.ms();
+		ps.p.mf_total_ms += t_all.ms_noted(ps, PK_MF_TOTAL);
 		if (t_bt)
-			ps.p.mf_bt_ms += t_bt->ms();
+			ps.p.mf_bt_ms += t_bt->ms_noted(ps, PK_MF_BT);
 		ps.p.mf_launches++;
 		ps.p.mf_positions += (int64_t)n;
 		ps.p.mf_entries += (int64_t)host_sc[1];

@@ -3,14 +3,23 @@
 #include <hip/hip_runtime.h>
 
 #include <mutex>
+#include <utility>
+#include <vector>
 
 #include "../../include/lrzgpu.h"
 
 namespace lrzgpu {
 
+enum ProfileKind { PK_TAG_SCAN = 0, PK_RESOLVE, PK_CRC, PK_GATHER, PK_LZ4, PK_MF_BT, PK_MF_TOTAL, PK_LONG_COMPARE, PK_COUNT };
+
 struct ProfileStore {
 	std::mutex mu;
 	lrzgpu_profile p{};
+	// when every launch of a kind started and ended, in ms since `base` (recorded by lrzgpu_profile_reset): launches of
+	// one kind run side by side on different streams (a resolver per chunk, a finder per GPU slot), so the SUM of their
+	// durations says nothing about the wall time they cover -- the union of these intervals does
+	hipEvent_t base = nullptr;
+	std::vector<std::pair<float, float>> iv[PK_COUNT];
 	static ProfileStore &get()
 	{
 		static ProfileStore s;
@@ -40,6 +49,17 @@ struct EventTimer {
 		if (a && b && hipEventElapsedTime(&t, a, b) != hipSuccess)
 			t = 0;
 		return t;
+	}
+	// duration, and the launch noted as an interval of `kind` (ProfileStore::mu must be held by the caller)
+	double ms_noted(ProfileStore &ps, int kind)
+	{
+		const double d = ms();
+		float at = 0;
+		if (ps.base && a && hipEventElapsedTime(&at, ps.base, a) == hipSuccess)
+			ps.iv[kind].push_back(std::make_pair(at, at + (float)d));
+		else
+			(void)hipGetLastError();
+		return d;
 	}
 	~EventTimer()
 	{

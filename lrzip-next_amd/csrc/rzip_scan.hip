@@ -1956,7 +1956,7 @@ int crc32_device(ScanWorkspace *w, const uint8_t *d_buf, int64_t n, uint32_t *cr
 	{
 		ProfileStore &ps = ProfileStore::get();
 		std::lock_guard<std::mutex> lk(ps.mu);
-		ps.p.crc_ms += tc.ms();
+		ps.p.crc_ms += tc.ms_noted(ps, PK_CRC);
 		ps.p.crc_launches++;
 		ps.p.crc_bytes += n;
 	}
@@ -2116,10 +2116,10 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 		{
 			ProfileStore &ps = ProfileStore::get();
 			std::lock_guard<std::mutex> lk(ps.mu);
-			ps.p.tag_scan_ms += t1.ms();
+			ps.p.tag_scan_ms += t1.ms_noted(ps, PK_TAG_SCAN);
 			ps.p.tag_scan_launches++;
 			ps.p.tag_scan_positions += seg_hi - seg_lo;
-			ps.p.resolve_ms += t2.ms();
+			ps.p.resolve_ms += t2.ms_noted(ps, PK_RESOLVE);
 			ps.p.resolve_launches++;
 		}
 		if (h.error == 3) {
@@ -2140,7 +2140,7 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 			{
 				ProfileStore &ps = ProfileStore::get();
 				std::lock_guard<std::mutex> lk(ps.mu);
-				ps.p.long_compare_ms += t3.ms();
+				ps.p.long_compare_ms += t3.ms_noted(ps, PK_LONG_COMPARE);
 				ps.p.long_compare_launches++;
 				ps.p.long_compare_bytes += 2 * ((int64_t)best - h.ext_done);
 			}
