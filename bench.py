@@ -60,7 +60,7 @@ class Profile(C.Structure):
                 ("long_compare_launches", C.c_int64), ("long_compare_bytes", C.c_int64), ("spec_rollbacks", C.c_int64),
                 ("spec_cancelled_blocks", C.c_int64), ("victim_rescans", C.c_int64),
                 ("union_ms", C.c_double * 8), ("peak_concurrency", C.c_double * 8),
-                ("pipeline_s", C.c_double * 8)]
+                ("pipeline_s", C.c_double * 8), ("mf_wave_dbg", C.c_int64 * 4)]
 
 
 ALPHABETS = {

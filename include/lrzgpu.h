@@ -325,6 +325,7 @@ typedef struct lrzgpu_profile {
 	 * lists to the host, 4 when the last chunk's scan ended, 5 when the last finder ended, 6 when the last encoder
 	 * ended (4-6: since the start of their run), 7 wall time of the runs */
 	double pipeline_s[8];
+	int64_t mf_wave_dbg[4];       /* k_bt_wave: rounds of all waves, node visits, rounds walks waited for a son, positions */
 } lrzgpu_profile;
 void lrzgpu_profile_reset(void);
 void lrzgpu_profile_get(lrzgpu_profile *out);

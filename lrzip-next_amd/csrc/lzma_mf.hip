@@ -267,6 +267,63 @@ __device__ __forceinline__ void put_mix(uint32_t *o, const uint32_t mix[4], uint
 	}
 }
 
+// Everything about a position that does not depend on the tree: where it is, its first 20 bytes, its h2 / h3
+// candidates and the bytes MixMatches3 looks at there.  Loaded AHEAD of the position's walk (the lane kernel keeps a
+// three-stage pipeline of these, the wave kernel stages 64 at a time in LDS), so that the per-position chain of
+// dependent loads is the tree walk alone.
+struct PosData {
+	uint32_t i;
+	uint32_t w[5];
+	uint32_t c2, c3;
+	uint32_t bytes; // src[c2 - 1] | src[c2 + 1] << 8 | src[c3 - 1] << 16 (0 where there is no candidate)
+};
+__device__ __forceinline__ uint32_t cand_bytes(const uint8_t *__restrict__ src, uint32_t c2, uint32_t c3)
+{
+	uint32_t b = 0;
+	if (c2)
+		b = (uint32_t)src[c2 - 1] | ((uint32_t)src[c2 + 1] << 8);
+	if (c3)
+		b |= (uint32_t)src[c3 - 1] << 16;
+	return b;
+}
+__device__ __forceinline__ void load_pos(PosData &d, const uint8_t *__restrict__ src, uint32_t n, const uint32_t *__restrict__ spos, uint32_t sorted_index,
+					 const uint32_t *__restrict__ prev2, const uint32_t *__restrict__ prev3)
+{
+	d.i = spos[sorted_index];
+	node_prefix(src + d.i, n - d.i, d.w);
+	d.c2 = prev2[d.i];
+	d.c3 = prev3[d.i];
+	d.bytes = cand_bytes(src, d.c2, d.c3);
+}
+// MixMatches3 from preloaded candidates (the position has at least 4 bytes: it is in a bucket)
+__device__ __forceinline__ uint32_t mix_from(const PosData &d, uint32_t pos, uint32_t dict, bool have_tree, uint32_t first_dist1, uint32_t mix[4])
+{
+	uint32_t nmix = 0;
+	const uint32_t min_pos = have_tree ? pos - first_dist1 : (pos > dict ? pos - dict : 1);
+	const uint32_t cur0 = d.w[0] & 0xFF, cur2 = (d.w[0] >> 16) & 0xFF;
+	bool done = false;
+	if (d.c2 >= min_pos && (d.bytes & 0xFF) == cur0) {
+		mix[1] = pos - d.c2 - 1;
+		if (((d.bytes >> 8) & 0xFF) == cur2) {
+			mix[0] = 3;
+			done = true;
+		} else
+			mix[0] = 2;
+		nmix = 2;
+	}
+	if (!done && d.c3 >= min_pos && ((d.bytes >> 16) & 0xFF) == cur0) {
+		if (nmix == 0) {
+			mix[0] = 3;
+			mix[1] = pos - d.c3 - 1;
+		} else {
+			mix[2] = 3;
+			mix[3] = pos - d.c3 - 1;
+		}
+		nmix += 2;
+	}
+	return nmix;
+}
+
 // Output space for the lists of one wavefront: the wave takes the pool in pieces (one returning global atomic per
 // kChunk entries instead of one per position -- a ~1 us round trip each) and hands them out with a prefix sum over the
 // lanes' counts.  Every lane of the wave must call this (cnt = 0 for lanes with nothing to write).
@@ -337,15 +394,44 @@ __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint
 	bool run_ok = false;
 	uint32_t run_s0 = 0, run_s1 = 0;
 	WaveAlloc wa{0, 0, chunk};
+	// the load pipeline: while position j is walked, the bytes MixMatches3 needs of j + 1, the prefix and the h2 / h3
+	// candidates of j + 2 and the place of j + 3 are on their way (*_j = the bucket index a stage holds, ~0 = nothing)
+	PosData d3{}, d2{};
+	uint32_t d3_j = ~0u, d2_j = ~0u, d1_j = ~0u, d1_i = 0;
 
 	for (uint32_t j = 0; __any(j < L); j++) {
 		const bool act = j < L;
 		uint32_t nrec = 0, nmix = 0, i = 0, pos = 0, len_limit = 0;
 		uint32_t mix[4];
 		const uint8_t *cur = src;
+		PosData D{};
 		if (act) {
 			const uint32_t self = k0 + j; // sorted index of this position = its node
-			i = spos[self];
+			if (d3_j == j)
+				D = d3;
+			else
+				load_pos(D, src, n, spos, self, prev2, prev3); // start of the bucket, or behind a run: nothing was on its way
+			// move the pipeline on
+			if (d2_j == j + 1) {
+				d3 = d2;
+				d3.bytes = cand_bytes(src, d2.c2, d2.c3);
+				d3_j = j + 1;
+			} else
+				d3_j = ~0u;
+			if (d1_j == j + 2) {
+				d2.i = d1_i;
+				node_prefix(src + d1_i, n - d1_i, d2.w);
+				d2.c2 = prev2[d1_i];
+				d2.c3 = prev3[d1_i];
+				d2_j = j + 2;
+			} else
+				d2_j = ~0u;
+			if (j + 3 < L) {
+				d1_i = spos[self + 3];
+				d1_j = j + 3;
+			} else
+				d1_j = ~0u;
+			i = D.i;
 			pos = i + 1;
 			cur = src + i;
 			const uint32_t avail = n - i;
@@ -354,7 +440,9 @@ __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint
 			uint32_t delta = pos - prev; // prev == 0 -> delta == pos >= cbs -> empty
 			BtNode me;
 			me.pos = pos;
-			node_prefix(cur, avail, me.w);
+#pragma unroll
+			for (int k = 0; k < 5; k++)
+				me.w[k] = D.w[k];
 			me.son0 = me.son1 = 0;
 
 			if (delta >= cbs) {
@@ -436,7 +524,7 @@ __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint
 				}
 			}
 			prev = pos;
-			nmix = mix_matches(src, cur, i, pos, dict, nrec != 0, nrec ? rec_s[1][lane] : 0, prev2, prev3, mix);
+			nmix = mix_from(D, pos, dict, nrec != 0, nrec ? rec_s[1][lane] : 0, mix);
 		}
 		const uint32_t cnt = nmix + nrec;
 		const unsigned long long st = wave_take(wa, cnt, cursor);
@@ -527,15 +615,18 @@ __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint
 // pending sons; moving into a visited node's son marks that son in the same step that resolves the slot left behind)
 // and the real value when it resolves it.  A walk that loads kPending where it wants to go stalls and looks again in
 // the next round; the oldest unfinished walk never meets a mark (marks only lie in regions no older walk can reach),
-// so the wave always makes progress.  All tree words are read and written with agent-scope atomics (they go to L2:
-// no stale L1 lines between the lanes of the wave) and a fence separates a round's stores from the next round's loads.
+// so the wave always makes progress.  All tree words are read and written with (workgroup-scope) atomics and a fence
+// separates a round's stores from the next round's loads.
 // Runs of one byte value (every position: full-length match with its predecessor at the first step) would serialise
 // the pipeline; when the oldest walk in flight hits one the wave switches to writing such positions 64 at a time.
 constexpr uint32_t kPending = 0xFFFFFFFFu;
-__device__ __forceinline__ uint32_t ld_coh(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint64_t ld_coh64(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_coh(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_coh64(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// A bucket's tree is touched by ONE wavefront while k_bt_wave runs: workgroup scope is all the coherence it needs (one
+// CU, one vector L1; nothing to write back or invalidate).  Agent scope would be 30 times slower here: on this
+// multi-XCD part an agent-scope fence writes the L2 back and invalidates it -- measured 27 us per round.
+__device__ __forceinline__ uint32_t ld_coh(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint64_t ld_coh64(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void st_coh(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void st_coh64(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void store_node_coh(BtNode *np, const BtNode &v)
 {
 	uint64_t *q = reinterpret_cast<uint64_t *>(np);
@@ -555,15 +646,39 @@ __global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src,
 						uint32_t dict, uint32_t fb, uint32_t cut,
 						uint8_t *__restrict__ counts, uint64_t *__restrict__ tmp_start,
 						uint32_t *__restrict__ pool, unsigned long long *__restrict__ cursor,
-						unsigned long long pool_cap, uint32_t chunk, int *__restrict__ err)
+						unsigned long long pool_cap, uint32_t chunk, int *__restrict__ err,
+						unsigned long long *__restrict__ stats)
 {
 	__shared__ uint32_t rec_s[kMaxRec][64];
+	__shared__ uint32_t st_i[64], st_w[5][64], st_c2[64], st_c3[64], st_b[64]; // the staged window of positions
 	const uint32_t lane = threadIdx.x;
 	const uint64_t lt_mask = ((uint64_t)1 << lane) - 1;
 	const uint32_t k0 = seg_start_sorted[blockIdx.x];
 	const uint32_t L = seg_len_sorted[blockIdx.x];
 	const uint32_t cyc_size = dict + 1;
 	uint32_t *const words = reinterpret_cast<uint32_t *>(node); // slot (x, side) = words[8 * x + side]
+	uint32_t stage_base = 0, stage_end = 0, stage_prev = 0; // wave-uniform: the window, and the position before it
+	uint32_t pd_c2 = 0, pd_c3 = 0, pd_bytes = 0;            // the walk's h2 / h3 candidates
+	// stage the 64 positions of the bucket from `from` on (every lane loads one; called by the whole wave)
+	auto restage = [&](uint32_t from) {
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // (the readers of the old window are done)
+		PosData d{};
+		const uint32_t q = from + lane;
+		if (q < L)
+			load_pos(d, src, n, spos, k0 + q, prev2, prev3);
+		st_i[lane] = d.i;
+#pragma unroll
+		for (int k = 0; k < 5; k++)
+			st_w[k][lane] = d.w[k];
+		st_c2[lane] = d.c2;
+		st_c3[lane] = d.c3;
+		st_b[lane] = d.bytes;
+		stage_prev = from ? spos[k0 + from - 1] + 1 : 0;
+		stage_base = from;
+		stage_end = from + 64 < L ? from + 64 : L;
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	};
+	restage(0);
 	WaveAlloc wa{0, 0, chunk};
 	uint32_t next_j = 0; // wave-uniform: the next position of the bucket that has no walk yet
 
@@ -578,58 +693,76 @@ __global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src,
 	uint32_t n_side = 0; // 0 / 1: the son it will descend into; 2: full-length agreement, both sons are taken over
 	bool run_hit = false;
 	uint32_t run_s0 = 0, run_s1 = 0;
+	uint32_t st_rounds = 0, st_steps = 0, st_stalls = 0; // (st_rounds wave-uniform, the others per lane)
 
 	for (;;) {
+		st_rounds++;
 		// ---- start walks on free lanes, in bucket order --------------------------------------------------------
+		// (what a walk needs of its position comes from the staged window: 64 positions loaded at once, below)
 		{
 			const bool idle = state == W_IDLE;
 			const uint64_t m = __ballot(idle);
 			if (m) {
-				const uint32_t j = next_j + (uint32_t)__popcll(m & lt_mask);
-				if (idle) {
-					if (j >= L)
-						state = W_OVER;
-					else {
-						wj = j;
-						const uint32_t self = k0 + j;
-						i = spos[self];
-						pos = i + 1;
-						prev_pos = j ? spos[self - 1] + 1 : 0;
-						const uint32_t avail = n - i;
-						len_limit = avail < fb ? avail : fb;
-						cbs = pos < cyc_size ? pos : cyc_size;
-						node_prefix(src + i, avail, mw);
-						nrec = 0;
-						run_hit = false;
-						BtNode me;
-						me.pos = pos;
+				const uint32_t rank = (uint32_t)__popcll(m & lt_mask);
+				const uint32_t j = next_j + rank;
+				const uint32_t room = stage_end - next_j; // positions of the staged window not handed out yet
+				if (idle && next_j >= L)
+					state = W_OVER;
+				else if (idle && rank < room && j < L) {
+					const uint32_t q = j - stage_base;
+					wj = j;
+					const uint32_t self = k0 + j;
+					i = st_i[q];
 #pragma unroll
-						for (int k = 0; k < 5; k++)
-							me.w[k] = mw[k];
-						if (pos - prev_pos >= cbs) { // (prev_pos == 0: the bucket's first position)
-							me.son0 = me.son1 = 0;
-							state = W_FINISH;
-						} else {
-							me.son0 = me.son1 = kPending;
-							slot0 = 8 * self + 1; // ptr0 = &son1, ptr1 = &son0
-							slot1 = 8 * self;
-							len0 = len1 = 0;
-							max_len = 3;
-							cv = cut;
-							cur_ref = self; // sorted index + 1 of the predecessor
-							state = W_LOAD;
-						}
-						store_node_coh(node + self, me);
+					for (int k = 0; k < 5; k++)
+						mw[k] = st_w[k][q];
+					pd_c2 = st_c2[q];
+					pd_c3 = st_c3[q];
+					pd_bytes = st_b[q];
+					pos = i + 1;
+					prev_pos = q ? st_i[q - 1] + 1 : stage_prev;
+					const uint32_t avail = n - i;
+					len_limit = avail < fb ? avail : fb;
+					cbs = pos < cyc_size ? pos : cyc_size;
+					nrec = 0;
+					run_hit = false;
+					BtNode me;
+					me.pos = pos;
+#pragma unroll
+					for (int k = 0; k < 5; k++)
+						me.w[k] = mw[k];
+					if (pos - prev_pos >= cbs) { // (prev_pos == 0: the bucket's first position)
+						me.son0 = me.son1 = 0;
+						state = W_FINISH;
+					} else {
+						me.son0 = me.son1 = kPending;
+						slot0 = 8 * self + 1; // ptr0 = &son1, ptr1 = &son0
+						slot1 = 8 * self;
+						len0 = len1 = 0;
+						max_len = 3;
+						cv = cut;
+						cur_ref = self; // sorted index + 1 of the predecessor
+						state = W_LOAD;
 					}
+					store_node_coh(node + self, me);
 				}
-				next_j += (uint32_t)__popcll(m);
+				uint32_t started = (uint32_t)__popcll(m);
+				if (started > room)
+					started = room;
+				next_j += started;
 				if (next_j > L)
 					next_j = L;
 			}
+			// the window is used up: stage the next 64 positions of the bucket
+			if (next_j == stage_end && next_j < L)
+				restage(next_j);
 		}
 		if (__ballot(state != W_OVER) == 0)
 			break;
-		__threadfence(); // the stores of this round (new nodes, resolved and marked slots) before the loads of the next
+		st_steps += (state == W_LOAD) ? 1u : 0u;
+		st_stalls += (state == W_SONS) ? 1u : 0u;
+		// the stores of this round (new nodes, resolved and marked slots) complete before the loads of the next
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 
 		// ---- one step of every walk -----------------------------------------------------------------------------
 		if (state == W_LOAD || state == W_SONS) {
@@ -741,8 +874,14 @@ __global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src,
 			const bool fin = state == W_FINISH && (run_from == L || wj <= run_from);
 			uint32_t mix[4];
 			uint32_t nmix = 0;
-			if (fin)
-				nmix = mix_matches(src, src + i, i, pos, dict, nrec != 0, nrec ? rec_s[1][lane] : 0, prev2, prev3, mix);
+			if (fin) {
+				PosData d;
+				d.w[0] = mw[0];
+				d.c2 = pd_c2;
+				d.c3 = pd_c3;
+				d.bytes = pd_bytes;
+				nmix = mix_from(d, pos, dict, nrec != 0, nrec ? rec_s[1][lane] : 0, mix);
+			}
 			const uint32_t cnt = fin ? nmix + nrec : 0;
 			const unsigned long long st = wave_take(wa, cnt, cursor);
 			if (fin) {
@@ -806,7 +945,20 @@ __global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src,
 			if (state != W_OVER || next_j < L)
 				state = W_IDLE;
 			run_hit = false;
+			if (next_j < L)
+				restage(next_j);
 		}
+	}
+	// how the pipeline did (tools/bt_case.py): rounds of this wave, node visits, rounds a walk spent waiting for a son
+	for (int o = 32; o; o >>= 1) {
+		st_steps += __shfl_down(st_steps, o);
+		st_stalls += __shfl_down(st_stalls, o);
+	}
+	if (lane == 0) {
+		atomicAdd(stats + 0, (unsigned long long)st_rounds);
+		atomicAdd(stats + 1, (unsigned long long)st_steps);
+		atomicAdd(stats + 2, (unsigned long long)st_stalls);
+		atomicAdd(stats + 3, (unsigned long long)L);
 	}
 }
 
@@ -1117,7 +1269,7 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 		HIPCHK(hipcub::DeviceSelect::Flagged(w->cub_tmp, tb, hipcub::CountingInputIterator<uint32_t>(0), w->flags,
 						     w->seg_start, d_nseg, (int)n4, s));
 		// buckets of at least this many positions get a wavefront each (k_bt_wave), the rest a lane each (k_bt)
-		uint32_t long_min = 1024;
+		uint32_t long_min = 4096;
 		if (const char *e = getenv("LRZGPU_BT_WAVE_MIN")) { // read per call: tests force 1 (every bucket through the
 			const long v = atol(e);                      // pipelined kernel) and a huge value (none) inside one process
 			long_min = (uint32_t)(v < 1 ? 1 : (v > 0x7FFFFFFF ? 0x7FFFFFFF : v));
@@ -1136,7 +1288,7 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 		if (nlong)
 			hipLaunchKernelGGL(k_bt_wave, dim3(nlong), dim3(64), 0, s, d_src, (uint32_t)n, w->spos, w->seg_len_s, w->seg_start_s,
 					   (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, w->counts, w->tmp_start, w->pool_tmp, d_cursor,
-					   w->pool_cap, chunk, d_err);
+					   w->pool_cap, chunk, d_err, (unsigned long long *)w->scalars + 4);
 		if (nseg > nlong)
 			hipLaunchKernelGGL(k_bt, dim3((nseg - nlong + 63) / 64), dim3(64), 0, s, d_src, (uint32_t)n, w->spos, w->seg_len_s,
 					   w->seg_start_s, d_nseg, nlong, (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, w->counts,
@@ -1152,8 +1304,8 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 		hipLaunchKernelGGL(k_total, dim3(1), dim3(1), 0, s, w->counts, (const unsigned long long *)w->offsets, (uint32_t)n, d_total);
 	}
 	t_all.stop();
-	unsigned long long host_sc[4];
-	HIPCHK(hipMemcpyAsync(host_sc, w->scalars, 32, hipMemcpyDeviceToHost, s));
+	unsigned long long host_sc[8];
+	HIPCHK(hipMemcpyAsync(host_sc, w->scalars, 64, hipMemcpyDeviceToHost, s));
 	HIPCHK(stream_wait(s));
 	{
 		ProfileStore &ps = ProfileStore::get();
@@ -1164,6 +1316,8 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 		ps.p.mf_launches++;
 		ps.p.mf_positions += (int64_t)n;
 		ps.p.mf_entries += (int64_t)host_sc[1];
+		for (int k = 0; k < 4; k++)
+			ps.p.mf_wave_dbg[k] += (int64_t)host_sc[4 + k];
 	}
 	delete t_bt;
 	int err = (int)(host_sc[3] & 0xFFFFFFFFu);

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Match finder alone on one block of the bench text (GPU): k_bt / k_bt_wave timing per cut-over, pipeline statistics."""
+import ctypes as C, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import importlib.util
+spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py")); bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+B = bench.load_bindings(); L = B.lib()
+L.lrzgpu_profile_get.argtypes = [C.POINTER(bench.Profile)]
+mib = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+data = bench.text_like_torch(mib << 20, 1, torch.device("cuda:0")).cpu().numpy().tobytes()
+for wm in sys.argv[2:] or ["1000000000", "1024"]:
+    os.environ["LRZGPU_BT_WAVE_MIN"] = wm
+    for rep in range(2):
+        L.lrzgpu_profile_reset()
+        t0 = time.time()
+        gc, gp = B.lzma_match_lists(data, dict_size=1 << 25, fb=64, cut=48, per_pos=16)
+        dt = time.time() - t0
+        p = bench.Profile(); L.lrzgpu_profile_get(C.byref(p))
+    d = list(p.mf_wave_dbg)
+    print("wave_min %s: k_bt %.1f ms, finder %.1f ms, wall %.2f s; wave kernel: %d positions, rounds %d, visits %d (%.1f/pos), waits %d, visits/round %.2f"
+          % (wm, p.mf_bt_ms, p.mf_total_ms, dt, d[3], d[0], d[1], d[1] / max(d[3], 1), d[2], d[1] / max(d[0], 1)), flush=True)
