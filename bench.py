@@ -178,7 +178,8 @@ def pmc_traffic(kernel, workload_key):
     if d.get("workload_key") != workload_key:
         return None, "PMC summary is for workload %s" % d.get("workload_key")
     ks = d.get("kernels", {})
-    k = ks.get(kernel + "_mw") or ks.get(kernel)  # (the resolver runs as k_resolve_mw<NW> on 2 / 4 wavefronts)
+    # (the resolver runs as k_resolve_mw<NW> on 2 / 4 wavefronts; the BT walk as k_bt + k_bt_wave per block)
+    k = ks.get(kernel + "_mw") or ks.get(kernel + "+" + kernel + "_wave") or ks.get(kernel)
     if not k:
         return None, "kernel not in the PMC summary"
     return int(k["bytes_per_launch"]), d.get("note", "")

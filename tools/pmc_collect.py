@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "gpurun_out", "prof")
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r2"
-BENCH = ["python", os.path.join(ROOT, "bench.py"), "--steps", "1", "--no-cpu-baseline"] + sys.argv[2:]
+BENCH = ["python", os.path.join(ROOT, "bench.py"), "--steps", "1", "--no-cpu-baseline", "--no-file-leg"] + sys.argv[2:]
 STREAMING = {"k_crc32_tiles", "k_long_compare", "k_gather_runs", "k_tag_scan"}
 
 
@@ -78,6 +78,14 @@ def main():
         f = totals[k]["FETCH_SIZE"] * (2 if k in STREAMING else 1)
         kernels[k] = {"launches": launches[k], "bytes_per_launch": (f + totals[k]["WRITE_SIZE"]) * 1024.0 / n,
                       "fetch_correction": 2 if k in STREAMING else 1}
+    # the BT walk is two kernels since round 3 (k_bt_wave: one wavefront per long bucket, k_bt: one lane per short one),
+    # launched together once per block: bench.py's "k_bt" is their sum per finder launch
+    if "k_bt_wave" in kernels and "k_bt" in kernels:
+        n = max(kernels["k_bt"]["launches"], 1)
+        kernels["k_bt+k_bt_wave"] = {"launches": kernels["k_bt"]["launches"],
+                                     "bytes_per_launch": kernels["k_bt"]["bytes_per_launch"] +
+                                     kernels["k_bt_wave"]["bytes_per_launch"] * kernels["k_bt_wave"]["launches"] / n,
+                                     "fetch_correction": 1}
     cfg = line["config"]["workload"]
     wk = re.match(r"(cfg\d)", cfg).group(1)
     a = dict(zip(sys.argv[2::2], sys.argv[3::2]))
