@@ -386,22 +386,26 @@ def main():
         out, ctl = B.compress_device(buf.data_ptr(), n_bytes, ctl=fresh_ctl(), copy=False)
         return out, ctl
 
-    def step_sharded():
-        """chunk k -> rank k % world; chunk images handed to rank 0 over RCCL; rank 0 lays out the file."""
-        state = {"ctl": None, "md5": None}
-
-        def compress_fn(first, stride, victim_in):
-            first_call = victim_in is None
-            got, ctl = B.compress_chunks(dev_ptr=buf.data_ptr(), n=n_bytes, first=first, stride=stride, victim_in=victim_in,
-                                         with_md5=(rank == 0 and first_call), ctl=fresh_ctl())
-            if first_call:
-                state["ctl"], state["md5"] = ctl, bytes(ctl.hash_resblock)
-            return got
-
-        imgs, _ = SH.compress_sharded(compress_fn, n_chunks, rank, world, dist, torch, comm_dev)
+    # ranks other than 0 keep only THEIR chunks resident (rank 0 hashes the whole input on its own thread from t = 0):
+    # lrzgpu_compress_sharded_chunks_dev takes one device pointer per owned chunk
+    chunk_ptrs = None
+    if world > 1:
+        comm, comm_keep = SH.torch_comm(rank, world, dist, torch, comm_dev)
         if rank != 0:
-            return None, state["ctl"]
-        return B.assemble_chunks(imgs, n_bytes, state["md5"], ctl=fresh_ctl())
+            mine = {}
+            for k in range(rank, n_chunks, world):
+                lo = k * chunk_size
+                mine[k] = buf[lo:min(n_bytes, lo + chunk_size)].clone()
+            buf = None  # (step_single is not used on this rank)
+            torch.cuda.empty_cache()
+            chunk_ptrs = [mine[k].data_ptr() if k in mine else 0 for k in range(n_chunks)]
+
+    def step_sharded():
+        """chunk k -> rank k % world, chain check, chunk images to rank 0 over RCCL, rank 0 lays out the file: all
+        inside lrzgpu_compress_sharded*_dev (csrc/shard.cpp); torch.distributed is the transport it calls back into."""
+        if chunk_ptrs is not None:
+            return B.compress_sharded_dev(0, n_bytes, comm, ctl=fresh_ctl(), chunk_ptrs=chunk_ptrs)[:2]
+        return B.compress_sharded_dev(buf.data_ptr(), n_bytes, comm, ctl=fresh_ctl())[:2]
 
     one_step = step_single if world == 1 else step_sharded
 

@@ -133,6 +133,40 @@ int lrzgpu_compress_chunks_dev(lrzgpu_control *control, const void *d_in, int64_
 int lrzgpu_assemble_chunks(lrzgpu_control *control, int64_t st_size, int n_chunks, const uint8_t *const *chunk_img,
 			   const int64_t *chunk_len, const uint8_t md5[16], uint8_t **out, int64_t *out_len);
 
+/* The whole one-file-over-N-ranks protocol behind the C ABI (csrc/shard.cpp): every rank calls the same function with
+ * its rank / world and three transport callbacks; rank r compresses chunks r, r + world, ... (the whole GPU path),
+ * the ranks agree on the victim_round chain (one all-reduce of three integers per chunk per round; the owner of the
+ * first chunk whose guess was wrong redoes it), the chunk images go to rank 0 in file order (send / recv straight out
+ * of pinned host memory: the chunk hand-off), rank 0 returns the .lrz (*out malloc()ed; NULL on the other ranks).
+ * No collective touches the data path.  The transport is the caller's: RCCL over xGMI (bench.py wraps
+ * torch.distributed), gloo (tests/test_sharded_cpu.py), MPI ...; callbacks return 0 on success.
+ *   lrzgpu_compress_sharded_dev         the whole input resident on every rank's device (rank 0 hashes it on its own
+ *                                        thread from the start, beside the chunks)
+ *   lrzgpu_compress_sharded_chunks_dev  a rank holds only ITS chunks: d_chunks[k] = device pointer of chunk k for
+ *                                        k % world == rank (chunk sizes: lrzgpu_plan), NULL elsewhere; rank 0 cannot
+ *                                        use this form unless control->hash_code == 0 (the hash needs every byte)
+ *   lrzgpu_shard_protocol               the protocol alone over any per-rank chunk compressor `fn` (same contract as
+ *                                        lrzgpu_compress_chunks: chunks k % stride == first, victim_in[k] >= 0 = start
+ *                                        value, on_chunk per finished chunk); digest = the whole-input hash (rank 0)
+ * *redone (may be NULL): chunks compressed again because of the chain, over all ranks. */
+typedef struct lrzgpu_shard_comm {
+	void *ctx;
+	int rank, world;
+	int (*allreduce_sum_i64)(void *ctx, int64_t *vals, int count);   /* in place, over all ranks            */
+	int (*send)(void *ctx, int dst, const void *buf, int64_t n);     /* blocking, host memory (pinned)      */
+	int (*recv)(void *ctx, int src, void *buf, int64_t n);
+} lrzgpu_shard_comm;
+typedef int (*lrzgpu_shard_compress_fn)(void *ctx, int first, int stride, const int64_t *victim_in, lrzgpu_chunk_fn on_chunk,
+					void *on_chunk_ctx);
+int lrzgpu_compress_sharded_dev(lrzgpu_control *control, const void *d_in, int64_t n, const lrzgpu_shard_comm *comm,
+				uint8_t **out, int64_t *out_len, int64_t *redone);
+int lrzgpu_compress_sharded_chunks_dev(lrzgpu_control *control, const void *const *d_chunks, int64_t n,
+				       const lrzgpu_shard_comm *comm, uint8_t **out, int64_t *out_len, int64_t *redone);
+int lrzgpu_compress_sharded(lrzgpu_control *control, const uint8_t *in, int64_t n, const lrzgpu_shard_comm *comm,
+			    uint8_t **out, int64_t *out_len, int64_t *redone);
+int lrzgpu_shard_protocol(lrzgpu_control *control, int64_t n, const lrzgpu_shard_comm *comm, lrzgpu_shard_compress_fn fn,
+			  void *fn_ctx, const uint8_t *digest, uint8_t **out, int64_t *out_len, int64_t *redone);
+
 /* ---- stream layer, compress side: src/include/stream.h:14-32 kept call for call ---------------------
  * For a caller that produces the two rzip streams itself (the reference's hash_search() through
  * put_header/put_literal/put_match, src/rzip.c:184-265): the same functions with the same argument lists,

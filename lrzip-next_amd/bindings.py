@@ -200,6 +200,58 @@ def assemble_chunks(images, st_size, md5, ctl=None, **kw):
     return _take(out, olen), c
 
 
+SHARD_COMPRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64), CHUNK_FN, C.c_void_p)
+
+
+def compress_sharded_dev(dev_ptr, n, comm, ctl=None, chunk_ptrs=None, **kw):
+    """lrzgpu_compress_sharded_dev (whole input on this rank's device) or, with chunk_ptrs (a list of device addresses,
+    0 for chunks of other ranks), lrzgpu_compress_sharded_chunks_dev -> (LrzBuffer on rank 0 else None, Control, redone)."""
+    c = ctl if ctl is not None else make_control(**kw)
+    out = C.POINTER(C.c_ubyte)()
+    olen = C.c_int64()
+    redone = C.c_int64()
+    if chunk_ptrs is not None:
+        arr = (C.c_void_p * len(chunk_ptrs))(*[p or None for p in chunk_ptrs])
+        rc = lib().lrzgpu_compress_sharded_chunks_dev(C.byref(c), arr, C.c_int64(n), C.byref(comm), C.byref(out), C.byref(olen), C.byref(redone))
+    else:
+        rc = lib().lrzgpu_compress_sharded_dev(C.byref(c), C.c_void_p(dev_ptr), C.c_int64(n), C.byref(comm), C.byref(out), C.byref(olen), C.byref(redone))
+    if rc != 0:
+        raise RuntimeError("lrzgpu_compress_sharded rc=%d" % rc)
+    return (LrzBuffer(out, olen.value) if out else None), c, redone.value
+
+
+def shard_protocol(n, comm, compress_fn, digest, ctl=None, **kw):
+    """lrzgpu_shard_protocol over a Python per-rank compressor: compress_fn(first, stride, victim_in or None) ->
+    {chunk index: (victim_in, victim_out, image bytes)}.  -> (.lrz bytes on rank 0 else None, redone)."""
+    c = ctl if ctl is not None else make_control(**kw)
+    n_seen = [0]
+
+    def fn(_ctx, first, stride, victim_in, on_chunk, on_ctx):
+        try:
+            vi = None
+            if victim_in:
+                vi = [victim_in[k] for k in range(max(first + 1, stride))]
+            for k, (vin, vout, img) in sorted(compress_fn(first, stride, vi).items()):
+                buf = (C.c_ubyte * max(len(img), 1)).from_buffer_copy(img if img else b"\0")
+                if on_chunk(on_ctx, k, vin, vout, buf, len(img)) != 0:
+                    return -1
+                n_seen[0] += 1
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return -1
+
+    cb = SHARD_COMPRESS_FN(fn)
+    out = C.POINTER(C.c_ubyte)()
+    olen = C.c_int64()
+    redone = C.c_int64()
+    rc = lib().lrzgpu_shard_protocol(C.byref(c), C.c_int64(n), C.byref(comm), cb, None, digest, C.byref(out), C.byref(olen), C.byref(redone))
+    if rc != 0:
+        raise RuntimeError("lrzgpu_shard_protocol rc=%d" % rc)
+    return (_take(out, olen) if out else None), redone.value
+
+
 def chunk_bytes_for(n):
     bits = 8
     while n >> bits > 0:

@@ -1030,14 +1030,18 @@ struct Run {
 			const bool interior = in.dev && ((uintptr_t)(in.dev + cc->offset) & 15) == 0 && cc->offset + cc->size < in.n;
 			if (interior) {
 				cc->d_in = in.dev + cc->offset; // interior chunk of a resident buffer: readable past its end
+			} else if (in.dev_chunks && !in.dev_chunks[cc->index] && cc->size) {
+				rc = LRZGPU_E_PARAM; // a chunk this run was asked for but not given
 			} else if (!cc->in_buf.alloc((size_t)cc->size + 256, P.device)) {
 				rc = LRZGPU_E_NOMEM;
 			} else {
 				cc->d_in = cc->in_buf.p;
 				hipError_t e = hipSuccess;
-				if (in.dev) {
+				if (in.dev || in.dev_chunks) {
+					// (a chunk handed over on its own has no readable bytes behind its end: it is copied next to padding)
+					const uint8_t *from = in.dev ? in.dev + cc->offset : in.dev_chunks[cc->index];
 					if (cc->size)
-						e = hipMemcpyAsync(cc->in_buf.p, in.dev + cc->offset, (size_t)cc->size, hipMemcpyDeviceToDevice, s);
+						e = hipMemcpyAsync(cc->in_buf.p, from, (size_t)cc->size, hipMemcpyDeviceToDevice, s);
 				} else {
 					// host memory or a file: through two pinned pieces, copy/pread of piece k+1 under the DMA of piece k
 					if (!stage[0] && (hipHostMalloc((void **)&stage[0], STAGE_BYTES, hipHostMallocDefault) != hipSuccess ||
@@ -1539,6 +1543,8 @@ int Run::run()
 	P.start();
 	std::vector<std::thread> side;
 	const bool want_md5 = !sel || sel->with_md5;
+	if (in.dev_chunks && (want_md5 || !sel))
+		return LRZGPU_E_PARAM; // the whole-input hash needs the whole input
 	if (want_md5)
 		side.emplace_back([this] { P.guarded([this] { md5_main(); }); });
 	side.emplace_back([this] { P.guarded([this] { reader_main(); }); });

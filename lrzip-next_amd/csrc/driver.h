@@ -14,6 +14,9 @@ namespace lrzgpu {
 struct CompressSource {
 	const uint8_t *host = nullptr;
 	const uint8_t *dev = nullptr;
+	// chunk-sharded runs that were handed only their own chunks: dev_chunks[k] = chunk k's bytes on the device
+	// (nullptr for chunks of other ranks); then neither host nor dev is set and no whole-input hash can be asked for
+	const uint8_t *const *dev_chunks = nullptr;
 	int fd = -1;
 	int64_t fd_base = 0; // file offset of input byte 0
 	int64_t n = 0;

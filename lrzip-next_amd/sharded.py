@@ -1,68 +1,66 @@
-"""One file across one process per GPU: chunk k of the file belongs to rank k mod world.
+"""One file across one process per GPU -- the TRANSPORT half only.
 
-rzip chunks are independent units of the .lrz format (own header, hash table, CRC, block offsets relative to the
-chunk; src/rzip.c:599-626, src/stream.c:1740-1770).  Every rank runs the whole path for its own chunks
-(lrzgpu_compress_chunks*) and ends up with finished chunk images; the only things that travel are
-  * three integers per chunk (victim_round in / out, image length): one all_reduce,
-  * the chunk images themselves, to rank 0, in file order: point-to-point send/recv -- the chunk hand-off
-    (RCCL over xGMI with backend "nccl", TCP with "gloo" in the CPU tests).
-The one value that crosses a chunk boundary in the reference is insert_hash()'s static victim_round
-(src/rzip.c:308): ranks start their chunks from a prediction, rank 0's view of the (in, out) table shows which
-chunk (if any) started from the wrong value, its owner redoes that one chunk, until the chain is consistent.
-Rank 0 lays out magic + chunks + MD5 (lrzgpu_assemble_chunks).  Orchestration only: no byte of the data path is
-computed here.
+The protocol (chunk k -> rank k mod world, the victim_round chain check and redo, the chunk hand-off to rank 0, the
+layout of the one .lrz) lives in the library behind the C ABI (csrc/shard.cpp: lrzgpu_compress_sharded*,
+lrzgpu_shard_protocol).  It asks its caller for three things: sum a few int64 over all ranks, send bytes to a rank,
+receive bytes from a rank.  This module is those three callbacks over torch.distributed (backend "nccl" = RCCL over
+xGMI on the GPU box: host bytes are staged through a device tensor for the send / recv; "gloo" in the CPU tests),
+for bench.py and tests/.  Nothing of the data path is computed here.
 """
+import ctypes as C
+
+ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int)
+SEND = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64)
+RECV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64)
+
+
+class ShardComm(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("rank", C.c_int), ("world", C.c_int), ("allreduce_sum_i64", ALLREDUCE),
+                ("send", SEND), ("recv", RECV)]
 
 
 def owner(k, world):
     return k % world
 
 
-def compress_sharded(compress_fn, n_chunks, rank, world, dist, torch, device, max_rounds=None):
-    """compress_fn(first, stride, victim_in) -> {chunk index: (victim_in, victim_out, image bytes)}: the chunks
-    k % stride == first of the file, each started from victim_in[k] where that is >= 0.
-    Returns (images in file order on rank 0 else None, number of chunks redone over all ranks)."""
-    images, chain = {}, {}
-    if rank < n_chunks:
-        for k, (vin, vout, img) in compress_fn(rank, world, None).items():
-            images[k], chain[k] = img, (vin, vout)
-    redone = 0
-    rounds = 0
-    while True:
-        meta = torch.zeros((n_chunks, 3), dtype=torch.int64, device=device)
-        for k, (vin, vout) in chain.items():
-            meta[k, 0], meta[k, 1], meta[k, 2] = vin, vout, len(images[k])
-        if world > 1:
-            dist.all_reduce(meta, op=dist.ReduceOp.SUM)
-        m = meta.cpu().tolist()
-        # the chain of src/rzip.c:308: chunk k must have started from what chunk k-1 left
-        bad = [k for k in range(1, n_chunks) if m[k][0] != m[k - 1][1]]
-        if not bad:
-            break
-        k0 = bad[0]  # only the first wrong chunk is certain to be wrong: its new end value decides about the rest
-        if owner(k0, world) == rank:
-            victim = [-1] * n_chunks
-            victim[k0] = m[k0 - 1][1]
-            vin, vout, img = compress_fn(k0, max(n_chunks, k0 + 1), victim)[k0]  # chunk k0 alone
-            images[k0], chain[k0] = img, (vin, vout)
-        redone += 1
-        rounds += 1
-        if max_rounds is not None and rounds > max_rounds:
-            raise RuntimeError("victim_round chain did not converge")
-    if world == 1:
-        return [images[k] for k in range(n_chunks)], redone
-    # chunk hand-off to rank 0, in file order
-    if rank == 0:
-        out = []
-        for k in range(n_chunks):
-            if owner(k, world) == 0:
-                out.append(images[k])
-            else:
-                t = torch.empty(int(m[k][2]), dtype=torch.uint8, device=device)
-                dist.recv(t, src=owner(k, world))
-                out.append(t.cpu().numpy().tobytes())
-        return out, redone
-    for k in range(rank, n_chunks, world):
-        t = torch.frombuffer(bytearray(images[k]), dtype=torch.uint8).to(device)
-        dist.send(t, dst=0)
-    return None, redone
+def torch_comm(rank, world, dist, torch, device, piece=1 << 30):
+    """lrzgpu_shard_comm over torch.distributed.  `device`: where send / recv tensors live (the rank's GPU with
+    RCCL, cpu with gloo).  Returns (ShardComm, keepalive): keep the second alive as long as the first is used."""
+    import numpy as np
+
+    def as_numpy(ptr, n):
+        return np.ctypeslib.as_array((C.c_ubyte * n).from_address(ptr))
+
+    def allreduce(_ctx, vals, count):
+        try:
+            a = np.ctypeslib.as_array(vals, shape=(count,))
+            t = torch.from_numpy(a.copy()).to(device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            a[:] = t.cpu().numpy()
+            return 0
+        except Exception:  # a callback must not raise into C
+            return -1
+
+    def send(_ctx, dst, buf, n):
+        try:
+            for o in range(0, n, piece):  # (pieces: one device staging tensor of at most `piece` bytes)
+                k = min(piece, n - o)
+                t = torch.from_numpy(as_numpy(buf + o, k)).to(device)
+                dist.send(t, dst=dst)
+            return 0
+        except Exception:
+            return -1
+
+    def recv(_ctx, src, buf, n):
+        try:
+            for o in range(0, n, piece):
+                k = min(piece, n - o)
+                t = torch.empty(k, dtype=torch.uint8, device=device)
+                dist.recv(t, src=src)
+                as_numpy(buf + o, k)[:] = t.cpu().numpy()
+            return 0
+        except Exception:
+            return -1
+
+    cbs = (ALLREDUCE(allreduce), SEND(send), RECV(recv))
+    return ShardComm(None, rank, world, *cbs), cbs

@@ -53,10 +53,8 @@ def test_roundtrip_full_size_headline_workload(B):
     hdr, chunks = lrz_decode.parse(view)
     assert hdr["st_size"] == n and len(chunks) == 1 and hdr["md5_digest"] == want_md5
     assert len(chunks[0]["streams"][1]) >= 100  # ~128 literal blocks of stream_bufsize
-    out = lrz_decode.decode(view, threads=usable)  # checks the chunk CRC and md5(out) == trailer itself
-    assert out.shape[0] == n
-    del out
-    back = B.decompress_buffer(img, host_threads=usable)  # library decoder: same checks, own LZMA decoder
+    # (the independent Python decoder runs on the smaller round trips above; 4 GiB through it costs a minute)
+    back = B.decompress_buffer(img, host_threads=usable)  # library decoder: chunk CRC + MD5 checked inside
     assert len(back) == n and hashlib.md5(back).digest() == want_md5
     img.free()
 

@@ -1,8 +1,9 @@
-"""CPU (gloo, world_size 2) test of the one-file-across-ranks path: chunk ownership, the victim_round chain
-protocol, the chunk hand-off to rank 0 and the product's own file assembly (lrzgpu_assemble_chunks).
-There is no GPU in this container, so the per-chunk compressor plugged into the orchestration is built from the
-ORACLE scan + the product's host-only container layout; on the GPU box bench.py plugs in
-lrzgpu_compress_chunks_dev (tests/test_chunks_gpu.py plays all ranks in one process against the real thing)."""
+"""CPU (gloo, world_size 2) test of the one-file-across-ranks path through the C ABI (lrzgpu_shard_protocol,
+csrc/shard.cpp): chunk ownership, the victim_round chain check and redo, the chunk hand-off to rank 0 and the layout
+of the one file, over the three transport callbacks of lrzip-next_amd/sharded.py on torch.distributed.
+There is no GPU in this container, so the per-rank chunk compressor handed to the protocol is built from the ORACLE
+scan + the product's host-only container layout; on the GPU box bench.py calls lrzgpu_compress_sharded_dev, where the
+compressor is the library's own GPU path (tests/test_chunks_gpu.py plays all ranks in one process against that)."""
 import hashlib
 import importlib.util
 import os
@@ -83,11 +84,13 @@ def _worker(rank, world, port, q):
                 got[k] = (vin, vout, img)
             return got
 
-        imgs, redone = SH.compress_sharded(compress_fn, len(ranges), rank, world, dist, torch, torch.device("cpu"), max_rounds=len(ranges))
+        comm, keep = SH.torch_comm(rank, world, dist, torch, torch.device("cpu"))
+        got, redone = B.shard_protocol(len(data), comm, compress_fn, hashlib.md5(data).digest(), no_compress=True, threads=1, ramsize=RAM)
         if rank == 0:
-            got, _ = B.assemble_chunks(imgs, len(data), hashlib.md5(data).digest(), no_compress=True, threads=1, ramsize=RAM)
             want, fs = O.compress_buffer(data, no_compress=1, threads=1, ramsize=RAM)
             q.put(("result", got == want, len(ranges), fs.n_chunks, redone))
+        else:
+            assert got is None
         q.put(("calls", rank, calls))
     finally:
         dist.destroy_process_group()
@@ -116,10 +119,14 @@ def test_two_ranks_chunk_sharding_and_victim_round_protocol():
 
 
 def test_single_rank_chain_redo():
-    """world 1, no process group: a forced wrong prediction is redone until the chain is consistent."""
-    import torch
+    """world 1, no transport: a forced wrong prediction is redone until the chain is consistent (the C protocol
+    over a toy compressor whose chunk 1 leaves victim_round 3)."""
+    sys.path.insert(0, HERE)
     SH = _load("lrzip_next_amd_sharded", "lrzip-next_amd/sharded.py")
+    B = _load("lrzip_next_amd_bindings", "lrzip-next_amd/bindings.py")
     seen = []
+    ctl, chunk = B.plan(4 * (2 << 20), no_compress=True, threads=1, ramsize=RAM)
+    assert chunk == 2 << 20
 
     def compress_fn(first, stride, victim_in):
         got = {}
@@ -129,6 +136,8 @@ def test_single_rank_chain_redo():
             got[k] = (vin, 3 if k == 1 else vin, b"p%d@%d" % (k, vin))
         return got
 
-    imgs, redone = SH.compress_sharded(compress_fn, 4, 0, 1, None, torch, torch.device("cpu"))
-    assert imgs == [b"p0@0", b"p1@0", b"p2@3", b"p3@3"] and redone == 2
+    comm = SH.ShardComm(None, 0, 1)
+    img, redone = B.shard_protocol(4 * (2 << 20), comm, compress_fn, bytes(16), no_compress=True, threads=1, ramsize=RAM)
+    assert img[21:-16] == b"p0@0" + b"p1@0" + b"p2@3" + b"p3@3" and redone == 2
+    assert seen == [(0, 0), (1, 0), (2, 0), (3, 0), (2, 3), (3, 3)]
     assert SH.owner(5, 2) == 1
