@@ -126,6 +126,92 @@ def test_chunk_sharded_with_moving_victim_round(B, O):
     assert got == want and redone >= 1
 
 
+def _sharded_c_abi(B, data, world, **kw):
+    """lrzgpu_compress_sharded (csrc/shard.cpp) with every rank a thread of this process and an in-process transport
+    (queues for send / recv, a barrier-protected sum for the all-reduce): the protocol, the library's own GPU
+    compressor per rank and the hand-off run exactly as under torch.distributed, on one GPU."""
+    import queue
+    import threading
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("lrz_sharded_t", os.path.join(root, "lrzip-next_amd", "sharded.py"))
+    SH = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(SH)
+    L = B.lib()
+    L.lrzgpu_compress_sharded.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p, C.POINTER(C.POINTER(C.c_ubyte)),
+                                          C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    chan = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
+    bar = threading.Barrier(world)
+    acc, lock = {}, threading.Lock()
+
+    def make(rank):
+        def allreduce(_c, vals, count):
+            gen = allreduce.gen = getattr(allreduce, "gen", 0) + 1
+            mine = [vals[i] for i in range(count)]
+            with lock:
+                tot = acc.setdefault(gen, [0] * count)
+                for i in range(count):
+                    tot[i] += mine[i]
+            bar.wait()
+            for i in range(count):
+                vals[i] = acc[gen][i]
+            bar.wait()
+            return 0
+
+        def send(_c, dst, buf, n):
+            chan[(rank, dst)].put(C.string_at(buf, n))
+            return 0
+
+        def recv(_c, src, buf, n):
+            b = chan[(src, rank)].get(timeout=600)
+            assert len(b) == n
+            C.memmove(buf, b, n)
+            return 0
+
+        cbs = (SH.ALLREDUCE(allreduce), SH.SEND(send), SH.RECV(recv))
+        return SH.ShardComm(None, rank, world, *cbs), cbs
+
+    res = [None] * world
+
+    def worker(rank):
+        comm, keep = make(rank)
+        c = B.make_control(host_threads=max(2, 8 // world), **kw)
+        out = C.POINTER(C.c_ubyte)()
+        olen, redone = C.c_int64(), C.c_int64()
+        rc = L.lrzgpu_compress_sharded(C.byref(c), data, len(data), C.byref(comm), C.byref(out), C.byref(olen), C.byref(redone))
+        img = C.string_at(out, olen.value) if (rc == 0 and out) else None
+        if out:
+            C.CDLL(None).free(out)
+        res[rank] = (rc, img, redone.value)
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(900)
+    assert all(r is not None and r[0] == 0 for r in res), res
+    assert all(r[1] is None for r in res[1:])
+    return res[0][1], res[0][2]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_c_abi_entry_equals_single_process(B, O, world):
+    kw = dict(level=7, threads=4, processors=8, ramsize=RAM, window=1)
+    data = datagen.cfg3(3 * 104857600 + 12345, 40 * 1048576, seed=5)
+    want, fs = O.compress_buffer(data, compression_level=7, threads=4, processors=8, ramsize=RAM, window=1, workers=16)
+    got, redone = _sharded_c_abi(B, data, world, **kw)
+    assert got == want and redone == 0
+
+
+def test_sharded_c_abi_entry_redoes_wrong_guesses(B, O):
+    kw = dict(level=7, threads=4, processors=8, ramsize=RAM, window=1)
+    data = _moving_victim_data(O)
+    want, _ = O.compress_buffer(data, compression_level=7, threads=4, processors=8, ramsize=RAM, window=1, workers=16)
+    got, redone = _sharded_c_abi(B, data, 3, **kw)
+    assert got == want and redone >= 1
+
+
 def test_fd_path_streams_chunks(B, O, tmp_path):
     """Regular files are read chunk by chunk and written chunk by chunk (src/rzip.c:1057-1107,
     src/stream.c:1772-1821): same bytes as the memory-to-memory call, at an output offset too."""
