@@ -311,6 +311,8 @@ def main():
     ap.add_argument("--cpu-sample-chunks", type=int, default=0,
                     help="rzip chunks of the same buffer the CPU baseline compresses (0 = the WHOLE file, the default)")
     ap.add_argument("--no-file-leg", action="store_true", help="skip the untimed-for-`value` file-to-file step")
+    ap.add_argument("--timeline", default="", help="write every kernel launch of the timed region as kernel,start_ms,end_ms (CSV) "
+                                                   "plus a per-250-ms count of launches in flight per kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--threads", type=int, default=0, help="-p (default: host cores)")
     ap.add_argument("--host-threads", type=int, default=0,
@@ -438,6 +440,27 @@ def main():
     prof = Profile()
     L.lrzgpu_profile_get(C.byref(prof))
     state_after = gpu_state() if rank == 0 else None
+    if rank == 0 and args.timeline:
+        names = ["k_tag_scan", "k_resolve", "k_crc32_tiles", "k_gather_runs", "k_lz4_size", "k_bt", "finder", "k_long_compare"]
+        L.lrzgpu_profile_intervals.argtypes = [C.c_int, C.POINTER(C.c_double), C.c_int]
+        rows = []
+        for kind, nm in enumerate(names):
+            cnt = L.lrzgpu_profile_intervals(kind, None, 0)
+            if cnt > 0:
+                arr = (C.c_double * (2 * cnt))()
+                L.lrzgpu_profile_intervals(kind, arr, cnt)
+                rows += [(nm, arr[2 * i], arr[2 * i + 1]) for i in range(cnt)]
+        rows.sort(key=lambda r: r[1])
+        with open(args.timeline, "w") as f:
+            f.write("kernel,start_ms,end_ms\n")
+            for nm, a, b in rows:
+                f.write("%s,%.3f,%.3f\n" % (nm, a, b))
+            end = max([r[2] for r in rows] + [0.0])
+            f.write("\n# launches in flight at t (ms since the profile reset), sampled every 250 ms\n# t_ms," + ",".join(names) + "\n")
+            t = 0.0
+            while t <= end:
+                f.write("# %.0f," % t + ",".join(str(sum(1 for r in rows if r[0] == nm and r[1] <= t < r[2])) for nm in names) + "\n")
+                t += 250.0
 
     if rank == 0:
         total_mib = args.steps * (n_bytes / 1048576)  # one file per step, whatever the number of GPUs

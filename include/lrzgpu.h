@@ -363,6 +363,9 @@ typedef struct lrzgpu_profile {
 } lrzgpu_profile;
 void lrzgpu_profile_reset(void);
 void lrzgpu_profile_get(lrzgpu_profile *out);
+/* the launch intervals of one kind (the order of union_ms[]): [start, end) pairs in ms since the reset; returns how
+ * many exist and writes at most `cap` pairs (tools/timeline.py draws them) */
+int lrzgpu_profile_intervals(int kind, double *out, int cap);
 
 /* ---- round-trip verifier ----------------------------------------------------------------------
  * The read side of the same subset of the format (lrzip-next 0.14 magic, stored + LZMA blocks, MD5 or

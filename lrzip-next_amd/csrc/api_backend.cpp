@@ -438,6 +438,22 @@ extern "C" void lrzgpu_profile_get(lrzgpu_profile *out)
 	}
 }
 
+// the launch intervals themselves ([start, end) pairs in ms since the reset), for timelines: returns how many pairs
+// exist, writes at most `cap` of them
+extern "C" int lrzgpu_profile_intervals(int kind, double *out, int cap)
+{
+	if (kind < 0 || kind >= PK_COUNT)
+		return LRZGPU_E_PARAM;
+	ProfileStore &ps = ProfileStore::get();
+	std::lock_guard<std::mutex> lk(ps.mu);
+	const int n = (int)ps.iv[kind].size();
+	for (int k = 0; k < n && k < cap; k++) {
+		out[2 * k] = ps.iv[kind][(size_t)k].first;
+		out[2 * k + 1] = ps.iv[kind][(size_t)k].second;
+	}
+	return n;
+}
+
 // ---- filters on the device: one block resident in HBM, compress direction, in place -------------------
 extern "C" int lrzgpu_filter_block_dev(int filter_flag, int delta, void *d_data, int64_t n, int device)
 {
