@@ -78,54 +78,6 @@ def test_victim_round_chain_rescans(B, O):
     assert _profile(B, bench).victim_rescans == 0
 
 
-def _sharded(B, data, world, **kw):
-    """What bench.py --gpus N does, all ranks played by this one process: chunk k -> rank k % world,
-    the victim_round chain checked by the owner of the file, wrong guesses redone, images laid out."""
-    plan = B.make_control(**kw)
-    cs = C.c_int64()
-    assert B.lib().lrzgpu_plan(C.byref(plan), len(data), C.byref(cs)) == 0
-    n_chunks = max(1, -(-len(data) // cs.value)) if cs.value else 1
-    images, chain, md5 = {}, {}, None
-    for r in range(world):
-        got, ctl = B.compress_chunks(data, first=r, stride=world, with_md5=(r == 0), host_threads=8, **kw)
-        if r == 0:
-            md5 = bytes(ctl.hash_resblock)
-        for k, (vin, vout, img) in got.items():
-            assert k % world == r
-            images[k], chain[k] = img, (vin, vout)
-    assert sorted(images) == list(range(n_chunks))
-    redone = 0
-    for k in range(1, n_chunks):
-        if chain[k][0] != chain[k - 1][1]:
-            victim = [-1] * n_chunks
-            victim[k] = chain[k - 1][1]
-            got, _ = B.compress_chunks(data, first=k, stride=max(n_chunks, k + 1), victim_in=victim, host_threads=8, **kw)
-            vin, vout, img = got[k]
-            assert vin == chain[k - 1][1]
-            images[k], chain[k] = img, (vin, vout)
-            redone += 1
-    out, _ = B.assemble_chunks([images[k] for k in range(n_chunks)], len(data), md5, **kw)
-    return out, redone
-
-
-@pytest.mark.parametrize("world", [2, 3])
-def test_chunk_sharded_equals_single_process(B, O, world):
-    kw = dict(level=7, threads=4, processors=8, ramsize=RAM, window=1)
-    data = datagen.cfg3(3 * 104857600 + 12345, 40 * 1048576, seed=5)
-    want, fs = O.compress_buffer(data, compression_level=7, threads=4, processors=8, ramsize=RAM, window=1, workers=16)
-    assert fs.n_chunks == 4
-    got, _ = _sharded(B, data, world, **kw)
-    assert got == want
-
-
-def test_chunk_sharded_with_moving_victim_round(B, O):
-    kw = dict(level=7, threads=4, processors=8, ramsize=RAM, window=1)
-    data = _moving_victim_data(O)
-    want, _ = O.compress_buffer(data, compression_level=7, threads=4, processors=8, ramsize=RAM, window=1, workers=16)
-    got, redone = _sharded(B, data, 3, **kw)
-    assert got == want and redone >= 1
-
-
 def _sharded_c_abi(B, data, world, **kw):
     """lrzgpu_compress_sharded (csrc/shard.cpp) with every rank a thread of this process and an in-process transport
     (queues for send / recv, a barrier-protected sum for the all-reduce): the protocol, the library's own GPU

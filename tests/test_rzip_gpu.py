@@ -31,7 +31,7 @@ def test_tiny_chunks(B, O, kind, n):
 @pytest.mark.parametrize("level", [1, 4, 6, 7, 9])
 @pytest.mark.parametrize("kind", ["text", "random", "few", "phrases", "sparse", "zeros", "longrange"])
 def test_scan_equals_oracle(B, O, kind, level):
-    n = 3 * 1048576 + 777
+    n = (1 if kind in ("phrases", "few") else 3) * 1048576 + 777  # (collapsed tag spaces: serial resolver steps, kept small)
     _check(B, O, datagen.KINDS[kind](n, seed=level + 11), level=level)
 
 

@@ -14,7 +14,7 @@ def _case(seed):
     r = random.Random(seed)
     kind = r.choice(["text", "random", "phrases", "sparse", "longrange", "few", "zeros"])
     n = r.choice([0, 1, 30, 31, 32, 4095, 65537, r.randrange(100000, 3000000), r.randrange(3000000, 12000000)])
-    if kind in ("few", "zeros"):
+    if kind in ("few", "zeros", "phrases"):
         n = min(n, 1500000)  # collapsed tag spaces run in serial resolver steps: keep them small
     kw = dict(level=r.randrange(1, 10), threads=r.choice([1, 2, 3, 4, 8, 16]), processors=r.choice([1, 4, 8, 16]),
               lz4_test=r.random() < 0.8, threshold=r.choice([100, 100, 95, 80, 50]))
