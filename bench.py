@@ -524,15 +524,18 @@ def main():
         pl = [v / steps for v in prof.pipeline_s]
         step_s = dt / steps
         stages = {"host parser + range coder (%d threads)" % host_threads: pl[0] / max(host_threads, 1),
-                  "rzip scan (last chunk done)": pl[4], "match finder (last block done)": pl[5]}
+                  "rzip scan (last chunk done)": pl[4],
+                  "match finder + list copy (%d GPU slots)" % args.gpu_slots: (pl[2] + pl[3]) / max(args.gpu_slots, 1)}
         crit = max(stages, key=lambda k: stages[k])
         critical_path = {"stage": crit, "seconds_per_step": {k: round(v, 2) for k, v in stages.items()},
                          "step_seconds": round(step_s, 2),
                          "encoders_busy_s_per_step": round(pl[0], 1), "encoders_idle_s_per_step": round(pl[1], 1),
                          "finder_workers_busy_s_per_step": round(pl[2], 1), "lists_d2h_s_per_step": round(pl[3], 1),
-                         "last_encode_done_s": round(pl[6], 2),
-                         "note": "a stage's figure is the time it would need alone on its resources; the step cannot be "
-                                 "shorter than the largest"} if world == 1 else None
+                         "last_finder_done_s": round(pl[5], 2), "last_encode_done_s": round(pl[6], 2),
+                         "note": "a stage's figure is the time it needs on its own resources (busy seconds / workers; the scans "
+                                 "run unthrottled from t = 0); the step cannot be shorter than the largest.  The finder "
+                                 "workers are throttled by the encoders (a bounded number of blocks hold lists in host "
+                                 "memory), so their LAST block ends late whatever their speed"} if world == 1 else None
         file_leg = None
         if world == 1 and not args.no_file_leg:
             file_leg = file_to_file_leg(B, buf, n_bytes, fresh_ctl)
