@@ -80,7 +80,7 @@ def test_victim_round_carry(B, O):
         _check(B, O, pat, level=4, victim_round=vr % 3)
 
 
-@pytest.mark.parametrize("mib", [512, 4096])
+@pytest.mark.parametrize("mib", [4096])
 def test_headline_shape(B, O, mib):
     """The bench workload shape (seeded text + identical copy at distance n/2), up to the full 4 GiB of
     BASELINE.json configs[1]: tag masks up to 0x1ff, clusters of ~340 slots, twins under continuous
