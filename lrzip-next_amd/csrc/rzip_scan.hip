@@ -322,6 +322,60 @@ __device__ __forceinline__ bool quick_reject(const uint8_t *buf, i64 p0, i64 op,
 	return ba != bb; // some byte among the 8 before differs: rev < 8
 }
 
+// single_match_len(p0, op) computed by ONE lane, when both extents end inside their bounds (most tag hits that are real
+// matches at all are short ones: a phrase, a line); -1 = an extent reached its bound, take the wave-wide compare.
+// The serial lookup verifies all the hits of a probe window with this in one round of memory latency instead of one
+// wave-wide compare (two to three dependent round trips) per hit.
+__device__ __forceinline__ i64 lane_match_len(const uint8_t *buf, i64 p0, i64 op, i64 end, i64 last_match, i64 *rev)
+{
+	constexpr i64 FWD_BOUND = 256, BACK_BOUND = 128;
+	*rev = 0;
+	if (op >= p0)
+		return 0;
+	i64 total = end - p0;
+	if (total < 0)
+		total = 0;
+	const i64 capf = total < FWD_BOUND ? total : FWD_BOUND;
+	i64 fwd = 0;
+	while (fwd + 8 <= capf) {
+		const u64 x = reinterpret_cast<const U64u *>(buf + p0 + fwd)->v ^ reinterpret_cast<const U64u *>(buf + op + fwd)->v;
+		if (x) {
+			fwd += (__ffsll((long long)x) - 1) >> 3;
+			goto fwd_done;
+		}
+		fwd += 8;
+	}
+	while (fwd < capf && buf[p0 + fwd] == buf[op + fwd])
+		fwd++;
+	if (fwd == capf && capf < total)
+		return -1;
+fwd_done:;
+	const i64 floor_p = last_match > 0 ? last_match : 0;
+	i64 max_back = p0 - floor_p;
+	if (op < max_back)
+		max_back = op;
+	if (max_back < 0)
+		max_back = 0;
+	const i64 capb = max_back < BACK_BOUND ? max_back : BACK_BOUND;
+	i64 back = 0;
+	while (back + 8 <= capb) {
+		const u64 x = reinterpret_cast<const U64u *>(buf + p0 - 8 - back)->v ^ reinterpret_cast<const U64u *>(buf + op - 8 - back)->v;
+		if (x) {
+			back += (i64)(__clzll((long long)x) >> 3); // equal bytes from the top: the ones next to p0
+			goto back_done;
+		}
+		back += 8;
+	}
+	while (back < capb && buf[p0 - 1 - back] == buf[op - 1 - back])
+		back++;
+	if (back == capb && capb < max_back)
+		return -1;
+back_done:;
+	*rev = back;
+	const i64 len = fwd + back;
+	return len < MINIMUM_MATCH ? 0 : len;
+}
+
 struct Resolver {
 	const uint8_t *buf;
 	Slot *tbl;
@@ -539,12 +593,19 @@ struct Resolver {
 			const bool undecided = is_hit && !quick_reject(buf, p, s.offset, end, last_match);
 			u64 hits = __ballot(undecided);
 			tag_misses += __popcll(all_hits) - __popcll(hits);
+			// every undecided lane measures its own candidate (bounded); the loop below only falls back to the
+			// wave-wide compare for the ones that ran into a bound
+			i64 l_rev = 0, l_len = -1;
+			if (undecided)
+				l_len = lane_match_len(buf, p, s.offset, end, last_match, &l_rev);
 			while (hits) {
 				int idx = __ffsll((long long)hits) - 1;
 				hits &= hits - 1;
 				i64 cand_off = (i64)bcast64((u64)s.offset, idx);
-				i64 rev = 0;
-				i64 mlen = match_len(p, cand_off, &rev);
+				i64 rev = (i64)bcast64((u64)l_rev, idx);
+				i64 mlen = (i64)bcast64((u64)l_len, idx);
+				if (mlen < 0)
+					mlen = match_len(p, cand_off, &rev);
 				if (mlen) {
 					if (mlen > best) {
 						best = mlen;

@@ -21,6 +21,9 @@ for kind in ("phrases", "few", "text"):
         t0 = time.time(); B.decompress_buffer(img, host_threads=8); dd = time.time() - t0
         print("%s L%d: compress %.2f s (resolve %.0f ms, k_bt %.0f ms, finder %.0f ms, lz4 %.0f ms; enc busy %.1f s) decode %.2f s; image %d"
               % (kind, level, dt, p.resolve_ms, p.mf_bt_ms, p.mf_total_ms, p.lz4_ms, p.pipeline_s[0], dd, len(img)), flush=True)
+        print("      resolver: lookups %d inserts %d; %s" % (p.resolve_lookups, p.resolve_inserts, dict(zip(
+            ("batches", "committed", "serial_steps", "stop_complex", "stop_match", "stop_conflict", "stop_novictim", "stop_sweptrange"),
+            [int(v) for v in p.resolve_dbg[:8]]))), flush=True)
     for wm in ("1000000000", "4096"):
         os.environ["LRZGPU_BT_WAVE_MIN"] = wm
         L.lrzgpu_profile_reset()
