@@ -311,13 +311,7 @@ struct Pipeline {
 	// the waiting block that comes first in the FILE (chunks are scanned side by side and their blocks arrive
 	// interleaved): chunks then complete one after the other and are laid out / written while later ones are
 	// still being encoded, instead of all at the very end
-	Job *take_first(std::deque<Job *> &q);
-	// When every chunk of the file is in flight at once (no reader waiting for a commit), blocks need not be taken
-	// in file order: full-size literal blocks go first, the short ones (a chunk's last literal block, its token
-	// blocks) last and longest-first.  The encoders start staggered (the first blocks of the scans arrive over a few
-	// seconds) and every full block costs the same, so the threads would also END staggered; the short blocks fill
-	// that in (longest-processing-time-first on the tail).
-	bool short_blocks_last = false;
+	static Job *take_first(std::deque<Job *> &q);
 
 	void fail(int e)
 	{
@@ -706,20 +700,8 @@ struct Pipeline {
 Job *Pipeline::take_first(std::deque<Job *> &q)
 {
 	size_t best = 0;
-	auto is_short = [&](const Job *j) { return short_blocks_last && !(j->ref.streamno == 1 && j->ref.len == sz.stream_bufsize); };
 	for (size_t i = 1; i < q.size(); i++) {
 		const Job *a = q[i], *b = q[best];
-		const bool sa = is_short(a), sb = is_short(b);
-		if (sa != sb) {
-			if (!sa)
-				best = i;
-			continue;
-		}
-		if (sa) { // both short: the longer one first
-			if (a->ref.len > b->ref.len)
-				best = i;
-			continue;
-		}
 		if (a->chunk->index < b->chunk->index || (a->chunk->index == b->chunk->index && a->ref.streamno == b->ref.streamno && a->ref.off < b->ref.off))
 			best = i;
 	}
@@ -1547,8 +1529,6 @@ int Run::run()
 			scan_slots = atoi(e);
 	if ((size_t)scan_slots > mine.size())
 		scan_slots = mine.empty() ? 1 : (int)mine.size();
-	// (with more chunks than that the reader waits for commits, and a commit for the chunk's last -- short -- block)
-	P.short_blocks_last = (int)mine.size() <= scan_slots + 1 && !getenv("LRZGPU_FILE_ORDER");
 	if (ctl->verbose)
 		fprintf(stderr, "lrzgpu: threads %d bufsize %lld dict %u chunk %lld chunks %zu (%zu here) scanners %d encoders %d gpu workers %d\n",
 			P.sz.threads, (long long)P.sz.stream_bufsize, P.sz.dict_size, (long long)P.sz.max_chunk, chunks.size(), mine.size(),
