@@ -1121,6 +1121,7 @@ struct Run {
 				// piece k+1 comes down while piece k is hashed
 				size_t prev = 0;
 				int k = 0;
+				double t_hash = 0, t_wait = 0;
 				for (int64_t o = 0; (o < in.n || prev) && !rc; o += (int64_t)piece, k ^= 1) {
 					size_t len = 0;
 					if (o < in.n) {
@@ -1128,14 +1129,20 @@ struct Run {
 						if (hipMemcpyAsync(stage[k], in.dev + o, len, hipMemcpyDeviceToHost, s) != hipSuccess)
 							rc = LRZGPU_E_HIP;
 					}
+					const double ta = now_s();
 					if (prev)
 						m.update(stage[k ^ 1], prev);
+					const double tb = now_s();
 					if (!rc && stream_wait(s) != hipSuccess)
 						rc = LRZGPU_E_HIP;
+					t_hash += tb - ta;
+					t_wait += now_s() - tb;
 					prev = len;
 					if (P.error())
 						break;
 				}
+				if (tracing())
+					fprintf(stderr, "lrzgpu hash thread: %.2f s hashing, %.2f s waiting for the next piece from the device\n", t_hash, t_wait);
 				for (int q = 0; q < 2; q++)
 					if (stage[q])
 						(void)hipHostFree(stage[q]);

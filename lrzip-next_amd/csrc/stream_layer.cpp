@@ -1,7 +1,10 @@
 // stream_layer.cpp -- see stream_layer.h.  Host-only logic, no device code.
 #include "stream_layer.h"
 
+#include <atomic>
 #include <cstring>
+#include <thread>
+#include <utility>
 
 namespace lrzgpu {
 
@@ -261,6 +264,8 @@ void write_chunk_raw(uint8_t *o, int cb, bool eof, int64_t chunk_size, const std
 		put_val(base, (size_t)cur_pos + 1, 0, cb * 3);
 		cur_pos += 1 + cb * 3;
 	}
+	std::vector<std::pair<size_t, const DoneBlock *>> big; // payloads worth a thread of their own
+	size_t big_bytes = 0;
 	for (const DoneBlock &b : blocks) { // src/stream.c:1772-1821
 		put_val(base, (size_t)last_head[b.streamno], cur_pos, cb);
 		last_head[b.streamno] = cur_pos + 1 + cb * 2;
@@ -269,10 +274,34 @@ void write_chunk_raw(uint8_t *o, int cb, bool eof, int64_t chunk_size, const std
 		put_val(base, (size_t)cur_pos + 1 + cb, b.s_len, cb);
 		put_val(base, (size_t)cur_pos + 1 + 2 * cb, 0, cb);
 		cur_pos += 1 + cb * 3;
-		if (!b.payload.empty())
+		if (b.payload.size() >= ((size_t)8 << 20)) {
+			big.push_back(std::make_pair((size_t)cur_pos, &b));
+			big_bytes += b.payload.size();
+		} else if (!b.payload.empty())
 			memcpy(base + cur_pos, b.payload.data(), b.payload.size());
 		cur_pos += (int64_t)b.payload.size();
 	}
+	// a chunk of stored blocks is gigabytes of payload: one core moves ~4 GB/s, a few threads the rest of what the
+	// memory system gives (the committer is alone at this point of a chunk: the last chunk's layout is a serial tail)
+	const unsigned nt = big_bytes >= ((size_t)256 << 20) ? 8u : 1u;
+	std::atomic<size_t> next{0};
+	auto work = [&] {
+		for (;;) {
+			const size_t k = next.fetch_add(1);
+			if (k >= big.size())
+				return;
+			memcpy(base + big[k].first, big[k].second->payload.data(), big[k].second->payload.size());
+		}
+	};
+	std::vector<std::thread> th;
+	try {
+		for (unsigned t = 1; t < nt; t++)
+			th.emplace_back(work);
+	} catch (...) { // no thread to be had: the caller's does it all
+	}
+	work();
+	for (auto &t : th)
+		t.join();
 }
 
 void write_chunk(std::vector<uint8_t> *outp, int cb, bool eof, int64_t chunk_size, const std::vector<DoneBlock> &blocks)

@@ -83,7 +83,7 @@ def test_cfg5_full_32gib_random(B):
     import time
     t0 = time.time()
     out, ctl = B.compress_device(buf.data_ptr(), n, level=7, threads=os.cpu_count(), processors=os.cpu_count(), ramsize=ram, window=328,
-                                 copy=False)
+                                 host_threads=16, gpu_slots=8, copy=False)
     dt = time.time() - t0
     _note("cfg5: 32 GiB random (torch.randint on the GPU, seed 5), -L7 -w 328, one chunk, input in HBM: %.1f s = %.1f MB/s, image %d bytes "
           "(every literal block stored through the lz4 gate), cold pools" % (dt, (n >> 20) / dt, len(out)))
