@@ -422,6 +422,8 @@ def main():
 
     state_before = gpu_state() if rank == 0 else None
     L.lrzgpu_profile_reset()
+    L.lrzgpu_profile_cpu.argtypes = [C.POINTER(C.c_double), C.c_int]
+    L.lrzgpu_profile_cpu(None, 1)
     fence()
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
@@ -439,6 +441,8 @@ def main():
 
     prof = Profile()
     L.lrzgpu_profile_get(C.byref(prof))
+    role_cpu = (C.c_double * 8)()
+    L.lrzgpu_profile_cpu(role_cpu, 0)
     state_after = gpu_state() if rank == 0 else None
     if rank == 0 and args.timeline:
         names = ["k_tag_scan", "k_resolve", "k_crc32_tiles", "k_gather_runs", "k_lz4_size", "k_bt", "finder", "k_long_compare"]
@@ -558,6 +562,9 @@ def main():
                        "stream_bufsize": int(ctl.stream_bufsize), "dict_size": int(ctl.dictSize_used),
                        "output_bytes": len(out), "host_threads": host_threads, "host_cpus_usable": round(usable, 1),
                        "host_cpu_seconds_rank0": round(cpu_s, 1),
+                       "host_cpu_seconds_per_step_by_thread_role": dict(
+                           [(nm, round(role_cpu[i] / steps, 1)) for i, nm in enumerate(("encoders (parser + range coder)", "gpu workers", "scanners", "whole-input hash", "reader"))] +
+                           [("everything else (committer, Python, HIP runtime threads)", round((cpu_s - sum(role_cpu)) / steps, 1))]),
                        "parallelism": ("%d chunks scanned concurrently on 1 GPU" % n_chunks) if world == 1 else
                                       ("chunk k -> GPU k mod %d, chunk images handed to rank 0 over %s send/recv" % (world, "RCCL" if backend == "nccl" else backend))},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -92,6 +92,10 @@ int64_t lrzgpu_match_len(const uint8_t *buf, int64_t p0, int64_t op, int64_t end
  * lrzgpu_trim() (lrzgpu.h) returns parked buffers and workspaces; the streams the library parks instead of destroying
  * stay open.  lrzgpu_shutdown() = lrzgpu_trim() + those streams closed: once, before exit(). */
 void lrzgpu_shutdown(void);
+/* CPU seconds the threads of the whole-file pipeline have burnt, by role, since the last call with reset != 0:
+ * 0 host encoders (LZMA parser + range coder, or zstd), 1 GPU workers (block copies, finder launches, list copies),
+ * 2 scanners (kernel launches, token streams), 3 the whole-input hash, 4 the reader.  (Measurement only.) */
+void lrzgpu_profile_cpu(double out[8], int reset);
 
 #ifdef __cplusplus
 }

@@ -73,6 +73,15 @@
 
 using namespace lrzgpu;
 
+// CPU seconds burnt by the threads of the whole-file pipeline, by role, since the last lrzgpu_profile_reset()
+static std::mutex g_role_mu;
+static double g_role_cpu[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static void role_cpu_add(int role, double s)
+{
+	std::lock_guard<std::mutex> lk(g_role_mu);
+	g_role_cpu[role & 7] += s;
+}
+
 namespace lrzgpu {
 int selected_hash_code();
 int selected_filter(int *delta);
@@ -138,6 +147,19 @@ int control_filter(const lrzgpu_control *c, int *flag, int *delta)
 	return check_filter(*flag, *delta);
 }
 } // namespace lrzgpu
+
+// (lrzgpu_hash.h) CPU seconds of the pipeline's threads by role: 0 encoders (parser + range coder / zstd), 1 GPU workers
+// (block copies, finder launches, list copies), 2 scanners, 3 the whole-input hash, 4 the reader; reset != 0 clears
+extern "C" void lrzgpu_profile_cpu(double out[8], int reset)
+{
+	std::lock_guard<std::mutex> lk(g_role_mu);
+	for (int k = 0; k < 8; k++) {
+		if (out)
+			out[k] = g_role_cpu[k];
+		if (reset)
+			g_role_cpu[k] = 0;
+	}
+}
 
 extern "C" void lrzgpu_trim(void)
 {
@@ -238,6 +260,7 @@ struct ZstdLib {
 
 struct Job;
 static std::vector<int> encoder_cpu_order();
+
 
 struct ChunkCtx {
 	int index = 0;
@@ -637,8 +660,9 @@ struct Pipeline {
 		}
 	}
 
-	// a thread body: nothing may escape it (std::terminate), failures become the pipeline's error
-	template <typename F> void guarded(F &&f)
+	// a thread body: nothing may escape it (std::terminate), failures become the pipeline's error; the CPU time the
+	// thread burnt is booked to its role (0 encoders, 1 GPU workers, 2 scanners, 3 hash, 4 reader)
+	template <typename F> void guarded(F &&f, int role = -1)
 	{
 		try {
 			f();
@@ -647,18 +671,21 @@ struct Pipeline {
 		} catch (...) {
 			fail(LRZGPU_E_INTERNAL);
 		}
+		struct timespec ts;
+		if (role >= 0 && clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts) == 0)
+			role_cpu_add(role, ts.tv_sec + ts.tv_nsec * 1e-9);
 	}
 
 	void start()
 	{
 		for (int i = 0; i < n_gpu_workers; i++)
-			threads.emplace_back([this] { guarded([this] { gpu_worker_main(); }); });
+			threads.emplace_back([this] { guarded([this] { gpu_worker_main(); }, 1); });
 		std::vector<int> pin;
 		if (const char *e = getenv("LRZGPU_PIN_ENCODERS"))
 			if (*e == '1')
 				pin = encoder_cpu_order();
 		for (int i = 0; i < n_encoders; i++) {
-			threads.emplace_back([this] { guarded([this] { encoder_main(); }); });
+			threads.emplace_back([this] { guarded([this] { encoder_main(); }, 0); });
 			if (!pin.empty()) {
 				cpu_set_t one;
 				CPU_ZERO(&one);
@@ -1553,10 +1580,10 @@ int Run::run()
 	if (in.dev_chunks && (want_md5 || !sel))
 		return LRZGPU_E_PARAM; // the whole-input hash needs the whole input
 	if (want_md5)
-		side.emplace_back([this] { P.guarded([this] { md5_main(); }); });
-	side.emplace_back([this] { P.guarded([this] { reader_main(); }); });
+		side.emplace_back([this] { P.guarded([this] { md5_main(); }, 3); });
+	side.emplace_back([this] { P.guarded([this] { reader_main(); }, 4); });
 	for (int k = 0; k < scan_slots; k++)
-		side.emplace_back([this] { P.guarded([this] { scanner_main(); }); });
+		side.emplace_back([this] { P.guarded([this] { scanner_main(); }, 2); });
 
 	// ---- committer: chunks in file order ------------------------------------------------------------
 	int ret = 0;
