@@ -819,7 +819,7 @@ struct Feeder {
 		b.timer = new EventTimer(ls);
 		int lr = lz4_sizes_device(b.d_jobs, (int)lj.size(), b.d_res, ls);
 		b.timer->stop();
-		if (lr != 0 || hipEventCreateWithFlags(&b.ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess || hipEventRecord(b.ev, ls) != hipSuccess) {
+		if (lr != 0 || hipEventCreateWithFlags(&b.ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(b.ev, ls) != hipSuccess) {
 			delete b.timer;
 			return LRZGPU_E_HIP;
 		}
@@ -832,7 +832,7 @@ struct Feeder {
 	{
 		for (size_t k = 0; k < batches.size();) {
 			Lz4Batch &b = batches[k];
-			hipError_t q = wait ? hipEventSynchronize(b.ev) : hipEventQuery(b.ev);
+			hipError_t q = wait ? event_wait(b.ev) : hipEventQuery(b.ev);
 			if (q == hipErrorNotReady) {
 				k++;
 				continue;
@@ -840,7 +840,7 @@ struct Feeder {
 			if (q != hipSuccess)
 				return LRZGPU_E_HIP;
 			std::vector<int> res(b.jobs.size());
-			if (hipMemcpyAsync(res.data(), b.d_res, res.size() * sizeof(int), hipMemcpyDeviceToHost, ms) != hipSuccess || stream_wait(ms) != hipSuccess)
+			if (d2h_pageable(res.data(), b.d_res, res.size() * sizeof(int), ms) != hipSuccess)
 				return LRZGPU_E_HIP;
 			{
 				ProfileStore &ps = ProfileStore::get();
@@ -876,7 +876,7 @@ struct Feeder {
 	{
 		for (Lz4Batch &b : batches) {
 			if (b.ev) {
-				(void)hipEventSynchronize(b.ev);
+				(void)event_wait(b.ev);
 				(void)hipEventDestroy(b.ev);
 			}
 			delete b.timer;
@@ -1076,13 +1076,13 @@ struct Run {
 						rc = LRZGPU_E_NOMEM;
 					hipEvent_t done[2] = {nullptr, nullptr};
 					for (int k = 0; k < 2 && !rc; k++)
-						if (hipEventCreateWithFlags(&done[k], hipEventBlockingSync | hipEventDisableTiming) != hipSuccess)
+						if (hipEventCreateWithFlags(&done[k], hipEventDisableTiming) != hipSuccess)
 							rc = LRZGPU_E_HIP;
 					int k = 0;
 					bool used[2] = {false, false};
 					for (int64_t o = 0; o < cc->size && !rc; o += (int64_t)STAGE_BYTES, k ^= 1) {
 						const size_t len = (size_t)(cc->size - o < (int64_t)STAGE_BYTES ? cc->size - o : (int64_t)STAGE_BYTES);
-						if (used[k] && hipEventSynchronize(done[k]) != hipSuccess) {
+						if (used[k] && event_wait(done[k]) != hipSuccess) {
 							rc = LRZGPU_E_HIP;
 							break;
 						}
@@ -1100,7 +1100,7 @@ struct Run {
 					for (int q = 0; q < 2; q++)
 						if (done[q]) {
 							if (used[q])
-								(void)hipEventSynchronize(done[q]);
+								(void)event_wait(done[q]);
 							(void)hipEventDestroy(done[q]);
 						}
 				}
@@ -1314,8 +1314,7 @@ struct Run {
 					rp = final_recs->data() + seen;
 				else {
 					rec_buf.resize((size_t)(nrec - seen));
-					if (hipMemcpyAsync(rec_buf.data(), S.sw->records + seen, (size_t)(nrec - seen) * sizeof(MatchRec), hipMemcpyDeviceToHost, F.ms) != hipSuccess ||
-					    stream_wait(F.ms) != hipSuccess)
+					if (d2h_pageable(rec_buf.data(), S.sw->records + seen, (size_t)(nrec - seen) * sizeof(MatchRec), F.ms) != hipSuccess)
 						return LRZGPU_E_HIP;
 					rp = rec_buf.data();
 				}

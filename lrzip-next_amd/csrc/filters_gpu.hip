@@ -487,7 +487,7 @@ int filter_block_device(int flag, int delta, uint8_t *d, size_t n, uint8_t *scra
 			return -3;
 		hipLaunchKernelGGL(k_count_candidates, dim3(grid_for(n_items)), dim3(256), 0, s, (const uint8_t *)d, (uint32_t)n_items, x86 ? 0 : 1, d_total);
 		unsigned long long total = 0;
-		if (hipMemcpyAsync(&total, d_total, sizeof(total), hipMemcpyDeviceToHost, s) != hipSuccess || stream_wait(s) != hipSuccess)
+		if (d2h_pageable(&total, d_total, sizeof(total), s) != hipSuccess)
 			return -3;
 		if (total == 0)
 			return 0;

@@ -1276,8 +1276,7 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 		}
 		hipLaunchKernelGGL(k_seg_len, dim3(g), dim3(256), 0, s, w->seg_start, d_nseg, n4, w->seg_len, long_min, d_nseg + 1);
 		uint32_t nseg_long[2] = {0, 0};
-		HIPCHK(hipMemcpyAsync(nseg_long, d_nseg, 8, hipMemcpyDeviceToHost, s));
-		HIPCHK(stream_wait(s));
+		HIPCHK(d2h_pageable(nseg_long, d_nseg, 8, s)); // (sleeps while the sorts run)
 		const uint32_t nseg = nseg_long[0], nlong = nseg_long[1] > nseg_long[0] ? nseg_long[0] : nseg_long[1];
 		// longest buckets first
 		tb = w->cub_bytes;
@@ -1305,8 +1304,7 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 	}
 	t_all.stop();
 	unsigned long long host_sc[8];
-	HIPCHK(hipMemcpyAsync(host_sc, w->scalars, 64, hipMemcpyDeviceToHost, s));
-	HIPCHK(stream_wait(s));
+	HIPCHK(d2h_pageable(host_sc, w->scalars, 64, s)); // (sleeps while the walks and the gather run)
 	{
 		ProfileStore &ps = ProfileStore::get();
 		std::lock_guard<std::mutex> lk(ps.mu);

@@ -2012,8 +2012,7 @@ int crc32_device(ScanWorkspace *w, const uint8_t *d_buf, int64_t n, uint32_t *cr
 	hipLaunchKernelGGL(k_crc32_tiles, dim3((unsigned)tiles), dim3(256), 0, s, d_buf, (i64)n, d_ops, w->crc_partial);
 	tc.stop();
 	std::vector<uint32_t> part(tiles);
-	HIPCHK(hipMemcpyAsync(part.data(), w->crc_partial, tiles * 4, hipMemcpyDeviceToHost, s));
-	HIPCHK(stream_wait(s));
+	HIPCHK(d2h_pageable(part.data(), w->crc_partial, tiles * 4, s));
 	{
 		ProfileStore &ps = ProfileStore::get();
 		std::lock_guard<std::mutex> lk(ps.mu);
@@ -2167,8 +2166,7 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 					   (uint32_t)w->comp_cap, w->rank_bytes, w->fp_bytes);
 		}
 		t2.stop();
-		HIPCHK(hipMemcpyAsync(&h, w->state, sizeof(h), hipMemcpyDeviceToHost, s));
-		HIPCHK(stream_wait(s));
+		HIPCHK(d2h_pageable(&h, w->state, sizeof(h), s)); // (sleeps while the resolver runs)
 		if (getenv("LRZGPU_TRACE"))
 			fprintf(stderr, "lrzgpu scan: seg [%lld,%lld) tiles %d  k1 %.2f ms  k2 %.2f ms  p_skip %lld  mask %llx  lookups %lld recs %lld  batches %lld committed %lld serial %lld complex %lld conflict %lld\n",
 				(long long)seg_lo, (long long)seg_hi, ntiles, t1.ms(), t2.ms(), (long long)h.p_skip,
@@ -2193,8 +2191,7 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 			hipLaunchKernelGGL(k_long_compare, dim3(2048), dim3(256), 0, s, d_chunk, (i64)h.ext_p, (i64)h.ext_op, (i64)h.ext_done,
 					   (i64)limit, w->long_best);
 			t3.stop();
-			HIPCHK(hipMemcpyAsync(&best, w->long_best, 8, hipMemcpyDeviceToHost, s));
-			HIPCHK(stream_wait(s));
+			HIPCHK(d2h_pageable(&best, w->long_best, 8, s));
 			h.hint_p = h.ext_p;
 			h.hint_op = h.ext_op;
 			h.hint_len = (int64_t)best;
@@ -2232,12 +2229,11 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 	if (chunk_size > 0 && end > 0) {
 		// state already in h from the last segment
 	} else {
-		HIPCHK(hipMemcpyAsync(&h, w->state, sizeof(h), hipMemcpyDeviceToHost, s));
-		HIPCHK(stream_wait(s));
+		HIPCHK(d2h_pageable(&h, w->state, sizeof(h), s));
 	}
 	res->records.resize((size_t)h.n_records);
 	if (h.n_records)
-		HIPCHK(hipMemcpyAsync(res->records.data(), w->records, (size_t)h.n_records * sizeof(MatchRec), hipMemcpyDeviceToHost, s));
+		HIPCHK(d2h_pageable(res->records.data(), w->records, (size_t)h.n_records * sizeof(MatchRec), s));
 	uint32_t crc = 0;
 	if (crc32_device(w, d_chunk, chunk_size, &crc, s) != 0)
 		return -6;
