@@ -30,7 +30,7 @@ struct MwUniform { // published by wave 0 before the first barrier of a round
 	i64 scan_end;
 };
 
-template <int NW>
+template <int NW, int MAXH, int MAXE>
 __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restrict__ buf, Slot *__restrict__ tbl, ScanState *__restrict__ st, i64 seg_lo,
 							int ntiles, const uint32_t *__restrict__ cand_rel, const u64 *__restrict__ cand_tag,
 							const uint32_t *__restrict__ tile_count, MatchRec *__restrict__ records, int batch_mode,
@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 							uint8_t *__restrict__ fp_bytes)
 {
 	constexpr int W = 64 * NW;
-	constexpr int RINGN = 4 * W;
+	constexpr int RINGN = NW >= 8 ? 2 * W : 4 * W;
 	constexpr int PWB = 16; // suspects per wave that get the exact test
 	constexpr int CFB = CF_BITS + (NW >= 4 ? 1 : 0); // four times the writes per round: twice the counters
 	constexpr int CFW = (1 << CFB) / 2;
@@ -49,8 +49,8 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 	__shared__ i64 stk_off[64];
 	__shared__ i64 stk_h[64];
 	// phase A scratch of each wave (tag hits of the lookup walk); between rounds the staging area of the window
-	__shared__ __attribute__((aligned(16))) i64 hit_all[NW][MAX_HITS * 64];
-	__shared__ uint32_t eqs_lds[MAX_EQS * W];
+	__shared__ __attribute__((aligned(16))) i64 hit_all[NW][MAXH * 64];
+	__shared__ uint32_t eqs_lds[MAXE * W];
 	__shared__ uint32_t cf_bits[CFW];
 	__shared__ uint32_t vict[W];
 	__shared__ MwUniform U;
@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 	__shared__ uint32_t fl_k[NW][PWB], fl_lo[NW][PWB], fl_hi[NW][PWB];
 	__shared__ int fl_res[NW][NW][PWB];
 	__shared__ i64 x_miss;
-	static_assert(sizeof(i64) * MAX_HITS * 64 * NW >= (size_t)W * 128, "staging area");
+	static_assert(sizeof(i64) * MAXH * 64 * NW >= (size_t)W * 128, "staging area");
 
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, gi = threadIdx.x;
 	const bool master = wave == 0;
@@ -447,7 +447,7 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 		{
 			const bool need_sim = alive && !w_simd;
 			if (__ballot(need_sim)) {
-				simulate_lanes(R, tbl, buf, tbl_size, better, lane, alive, need_sim, w_tag, w_pos, w_ticket, hit_lds, eqs_lds, W, L, [](int) {});
+				simulate_lanes<MAXH, MAXE>(R, tbl, buf, tbl_size, better, lane, alive, need_sim, w_tag, w_pos, w_ticket, hit_lds, eqs_lds, W, L, [](int) {});
 				if (need_sim)
 					w_simd = true;
 			}

@@ -59,6 +59,9 @@ constexpr long long LONG_EXTENT = 4 << 20; // forward extents longer than this g
 constexpr int A1_MAX_STEPS = 8192; // slots a speculative walk may cover (longer clusters: serial path)
 constexpr int MAX_EQS = 32;  // round-robin eviction handled in the batch up to this max_chain_len
 constexpr int MAX_HITS = 24; // tag hits one speculative lookup may verify (more -> serial path)
+// the 8-wavefront resolver trades both for window: 160 KB of LDS hold 512 candidates with these (levels <= 7 only)
+constexpr int MAX_EQS_W8 = 16;
+constexpr int MAX_HITS_W8 = 16;
 constexpr int CF_BITS = 13; // conflict filter: 16-bit write counters per hashed 8-slot granule (<= 320 writes per round)
 constexpr int CF_WORDS = (1 << CF_BITS) / 2;
 
@@ -814,7 +817,7 @@ fwd_done:
 // tag hits, (A3) the displacement chain of the insert, one level at a time.  Called by the resolver
 // wave for its window and by the pre-simulation waves for the candidates still in the queue; R is
 // only read (masks, table pointers, last_match); hit_lds / eqs_lds are the caller's own LDS scratch.
-template <class LapF>
+template <int MAXH, int MAXE, class LapF>
 __device__ __forceinline__ void simulate_lanes(const Resolver &R, const Slot *__restrict__ tbl, const uint8_t *__restrict__ buf, const i64 tbl_size,
 					       const u64 better, const int lane, const bool alive, const bool need_sim, const u64 w_tag,
 					       const i64 w_pos, const int w_ticket, i64 *hit_lds, uint32_t *eqs_lds, const int eqs_stride, LaneSim &L, LapF lap)
@@ -903,14 +906,14 @@ __device__ __forceinline__ void simulate_lanes(const Resolver &R, const Slot *__
 									eqb &= eqb - 1;
 									if (tbl[idx + q].t != T)
 										continue; // fingerprint false positive
-									if (neq < MAX_EQS)
+									if (neq < MAXE)
 										eqs_lds[neq * eqs_stride + w_ticket] = (uint32_t)(idx + q);
 									if (++neq >= R.max_chain) {
-										if (R.max_chain <= MAX_EQS && !tw)
+										if (R.max_chain <= MAXE && !tw)
 											kind = 3; // round-robin eviction among these equal tags
 										else if (seek_pred) {
 											tw = seek_pred = false;
-											if (R.max_chain <= MAX_EQS)
+											if (R.max_chain <= MAXE)
 												kind = 3;
 											else
 												L.complex_ = true;
@@ -949,7 +952,7 @@ __device__ __forceinline__ void simulate_lanes(const Resolver &R, const Slot *__
 									L.tw_over = true;
 									break;
 								}
-								if (neq < MAX_EQS)
+								if (neq < MAXE)
 									eqs_lds[neq * eqs_stride + w_ticket] = (uint32_t)(idx + s1);
 								if (++neq >= R.max_chain) {
 									L.complex_ = true;
@@ -966,7 +969,7 @@ __device__ __forceinline__ void simulate_lanes(const Resolver &R, const Slot *__
 							const Slot sl = tbl[idx + q];
 							if (sl.t != T)
 								continue; // fingerprint false positive
-							if (nhit < MAX_HITS)
+							if (nhit < MAXH)
 								hit_lds[nhit * 64 + lane] = sl.offset;
 							else
 								L.complex_ = true;
@@ -994,10 +997,10 @@ __device__ __forceinline__ void simulate_lanes(const Resolver &R, const Slot *__
 			// undecided ones get the exact compare
 			uint32_t und = 0; // bit k: hit k needs the exact compare
 			if (need_sim && !L.complex_) {
-				for (int k = 0; k < nhit && k < MAX_HITS; k++)
+				for (int k = 0; k < nhit && k < MAXH; k++)
 					if (!quick_reject(buf, P, hit_lds[k * 64 + lane], R.end, R.last_match))
 						und |= 1u << k;
-				L.misses = (nhit < MAX_HITS ? nhit : MAX_HITS) - __popc(und);
+				L.misses = (nhit < MAXH ? nhit : MAXH) - __popc(und);
 			}
 			while (__ballot(und != 0)) {
 				if (und) {
@@ -1459,7 +1462,7 @@ __global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf,
 		// tag hits, (A3) the displacement chain of the insert, one level at a time.
 		const bool need_sim = alive && !w_simd;
 		if (__ballot(need_sim)) {
-			simulate_lanes(R, tbl, buf, tbl_size, better, lane, alive, need_sim, w_tag, w_pos, w_ticket, hit_lds, eqs_lds, 64, L, lap);
+			simulate_lanes<MAX_HITS, MAX_EQS>(R, tbl, buf, tbl_size, better, lane, alive, need_sim, w_tag, w_pos, w_ticket, hit_lds, eqs_lds, 64, L, lap);
 			if (need_sim)
 				w_simd = true;
 			lap(15);
@@ -2055,11 +2058,11 @@ int scan_workspace_create(ScanWorkspace **out, int rzip_level, int64_t max_chunk
 		const char *pr = getenv("LRZGPU_RESOLVE_PROF"); // bit 1: per-phase cycle counters in the profile
 		if (pr && *pr == '1')
 			w->batch_mode |= 2;
-		// bits 4..6: wavefronts of the resolver workgroup (1 = k_resolve, 2 / 4 = k_resolve_mw)
+		// bits 4..7: wavefronts of the resolver workgroup (1 = k_resolve, 2 / 4 / 8 = k_resolve_mw)
 		int nw = 4;
 		if (const char *e = getenv("LRZGPU_RESOLVE_WAVES"))
 			nw = atoi(e);
-		nw = nw >= 4 ? 4 : nw >= 2 ? 2 : 1;
+		nw = nw >= 8 ? 8 : nw >= 4 ? 4 : nw >= 2 ? 2 : 1;
 		if ((w->batch_mode & 1) && nw > 1)
 			w->batch_mode |= nw << 4;
 	}
@@ -2158,9 +2161,14 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 		t1.stop();
 		EventTimer t2(s);
 		{
-			const int nw = (w->batch_mode >> 4) & 7;
-			auto kern = nw == 4 ? k_resolve_mw<4> : nw == 2 ? k_resolve_mw<2> : k_resolve;
-			hipLaunchKernelGGL(kern, dim3(1), dim3(nw == 4 ? 256 : nw == 2 ? 128 : 64), 0, s, d_chunk, (Slot *)w->table, w->state, (i64)seg_lo,
+			int nw = (w->batch_mode >> 4) & 15;
+			if (nw == 8 && chain > (unsigned)MAX_EQS_W8)
+				nw = 4; // (levels 8 and 9: the round-robin eviction needs the longer lists)
+			auto kern = nw == 8   ? k_resolve_mw<8, MAX_HITS_W8, MAX_EQS_W8>
+				    : nw == 4 ? k_resolve_mw<4, MAX_HITS, MAX_EQS>
+				    : nw == 2 ? k_resolve_mw<2, MAX_HITS, MAX_EQS>
+					      : k_resolve;
+			hipLaunchKernelGGL(kern, dim3(1), dim3(nw > 1 ? 64 * nw : 64), 0, s, d_chunk, (Slot *)w->table, w->state, (i64)seg_lo,
 					   ntiles, (const uint32_t *)w->cand_rel, (const u64 *)w->cand_tag, (const uint32_t *)w->tile_count, w->records,
 					   w->batch_mode, (const uint32_t *)w->tile_base, (const uint32_t *)w->comp_rel, (const u64 *)w->comp_tag,
 					   (uint32_t)w->comp_cap, w->rank_bytes, w->fp_bytes);

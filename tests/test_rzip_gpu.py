@@ -99,7 +99,7 @@ def test_headline_shape(B, O, mib):
     assert st.match_bytes > (n // 2) - (8 << 20) and st.minimum_tag_mask >= 0x3f
 
 
-@pytest.mark.parametrize("waves", [1, 2])
+@pytest.mark.parametrize("waves", [1, 2, 8])
 def test_resolver_wavefront_counts(B, O, monkeypatch, waves):
     """The resolver runs on 4 wavefronts by default (k_resolve_mw<4>, a window of 256 candidates); the same round
     on 2 wavefronts and the single-wavefront k_resolve must produce the same bytes and the same statistics.
