@@ -165,7 +165,7 @@ def test_sharded_c_abi_entry_redoes_wrong_guesses(B, O):
 def test_fd_path_streams_chunks(B, O, tmp_path):
     """Regular files are read chunk by chunk and written chunk by chunk (src/rzip.c:1057-1107,
     src/stream.c:1772-1821): same bytes as the memory-to-memory call, at an output offset too."""
-    data = datagen.cfg3(2 * 104857600 + 999, 30 * 1048576, seed=9)
+    data = datagen.cfg3(104857600 + 45 * 1048576 + 999, 30 * 1048576, seed=9)
     want, _ = O.compress_buffer(data, compression_level=7, threads=4, processors=8, ramsize=RAM, window=1, workers=16)
     src = tmp_path / "in.bin"
     src.write_bytes(data)

@@ -38,11 +38,11 @@ def test_cfg1_text_rzip_only_whole_file(B, O):
 def test_cfg4_source_tree_tar_zstd15(B, O):
     """cfg 4 at reduced size: tar of copies of one source tree, --zstd --zstd-level 15 (=> rzip level 6), several
     chunks; zstd blocks through the host libzstd like the reference."""
-    data = datagen.source_tree_tar(16, 20 << 20, seed=7)  # ~ 330 MiB, tree distance 20 MiB
-    assert len(data) > 3 * 104857600
+    data = datagen.source_tree_tar(12, 20 << 20, seed=7)  # ~ 250 MiB, tree distance 20 MiB
+    assert len(data) > 2 * 104857600
     kw = dict(level=7, threads=8, processors=16, ramsize=RAM, window=1, zstd=True, zstd_level=15)
     want, fs = O.compress_buffer(data, compression_level=7, threads=8, processors=16, ramsize=RAM, window=1, zstd=1, zstd_level=15, workers=16)
-    assert fs.n_chunks >= 4
+    assert fs.n_chunks >= 3
     got, ctl = B.compress_buffer(data, host_threads=16, **kw)
     assert got == want
     assert got[17] == (6 << 4) + 4 and got[18] == 15 and got[19] >> 4 == 6  # strategy 6 | zstd, level 15, rzip level 6
@@ -50,10 +50,10 @@ def test_cfg4_source_tree_tar_zstd15(B, O):
 
 
 def test_cfg5_random_lz4_early_out(B, O):
-    """cfg 5 at 1 GiB: incompressible input, every literal block must come out stored (CTYPE 3) through the lz4
+    """cfg 5 at 512 MiB (32 GiB below): incompressible input, every literal block must come out stored (CTYPE 3) through the lz4
     gate; -L7, one chunk."""
     import numpy as np
-    data = np.random.default_rng(5).integers(0, 256, size=1 << 30, dtype=np.uint8).tobytes()
+    data = np.random.default_rng(5).integers(0, 256, size=1 << 29, dtype=np.uint8).tobytes()
     kw = dict(level=7, threads=16, processors=16, ramsize=24 << 30)
     want, fs = O.compress_buffer(data, compression_level=7, threads=16, processors=16, ramsize=24 << 30, workers=16)
     got, ctl = B.compress_buffer(data, host_threads=16, **kw)

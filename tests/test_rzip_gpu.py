@@ -107,7 +107,7 @@ def test_resolver_wavefront_counts(B, O, monkeypatch, waves):
     B.lib().lrzgpu_trim()
     monkeypatch.setenv("LRZGPU_RESOLVE_WAVES", str(waves))
     try:
-        _check(B, O, datagen.text_like(20 * 1048576 + 3, seed=61), level=7)      # table fill, first clean, sweeps, twins
+        _check(B, O, datagen.text_like(14 * 1048576 + 3, seed=61), level=7)      # table fill, first clean, sweeps, twins
         _check(B, O, datagen.long_range(6 * 1048576, seed=62, base_frac=0.5, mutate_every=50021), level=7)  # matches, lazy matching
         _check(B, O, datagen.KINDS["few"](2 * 1048576 + 11, seed=63), level=4)      # collapsed tag space: serial mode, evictions
         pat = (b"0123456789abcdefghijklmnopqrstu" * 40 + b"XYZ") * 1500

@@ -28,7 +28,7 @@ def _chunks(B, O, data, window, level=7):
 
 
 @pytest.mark.parametrize("kind,n,window", [("longrange", 6 * 1048576 + 77, 0), ("text", 3 * 1048576, 0), ("random", 2 * 1048576, 0),
-                                           ("cfg3", 2 * 104857600 + 4321, 1), ("tiny", 100, 0), ("empty", 0, 0)])
+                                           ("cfg3", 104857600 + 40 * 1048576 + 4321, 1), ("tiny", 100, 0), ("empty", 0, 0)])
 def test_stream_api_writes_the_same_file(B, O, tmp_path, kind, n, window):
     if kind == "cfg3":
         data = datagen.cfg3(n, 30 * 1048576, seed=4)
