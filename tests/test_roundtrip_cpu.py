@@ -60,6 +60,17 @@ def test_library_decoder_edge_cases(B, O):
         bad[flip] ^= 0x21
         with pytest.raises(RuntimeError):
             B.decompress_buffer(bytes(bad))
+    # stored blocks: nothing but the chunk CRC and the MD5 notices a changed literal -- both are checked by the thread
+    # that follows the rebuild (images of 1 MiB and more), and a clean image still decodes after a bad one
+    data = datagen.text_like(3 * 524288 + 5, seed=8)
+    img, _ = O.compress_buffer(data, compression_level=7, threads=2, processors=2, ramsize=RAM, no_compress=True)
+    for flip in (len(img) // 2, len(img) - 3):
+        bad = bytearray(img)
+        bad[flip] ^= 0x01
+        with pytest.raises(RuntimeError):
+            B.decompress_buffer(bytes(bad))
+    assert B.decompress_buffer(img) == data
+    assert B.decompress_buffer(img, host_threads=1) == data  # (checks inline)
 
 
 def test_file_info_and_decompress_file(B, O, tmp_path):
