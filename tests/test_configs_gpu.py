@@ -66,6 +66,8 @@ def test_cfg5_full_32gib_random(B):
     import torch
     n = 32 << 30
     # seeded 64-bit PRNG on the GPU: splitmix64 of a counter (three multiply-xorshift rounds, elementwise), 1 GiB a time
+    import time
+    t_gen = time.time()
     buf = torch.empty(n + 256, dtype=torch.uint8, device="cuda")
     step = 1 << 30
     m30, m27, m31 = (1 << 34) - 1, (1 << 37) - 1, (1 << 33) - 1
@@ -80,13 +82,13 @@ def test_cfg5_full_32gib_random(B):
     buf[n:] = 0
     torch.cuda.synchronize()
     ram = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
-    import time
+    t_gen = time.time() - t_gen
     t0 = time.time()
     out, ctl = B.compress_device(buf.data_ptr(), n, level=7, threads=os.cpu_count(), processors=os.cpu_count(), ramsize=ram, window=328,
                                  host_threads=16, gpu_slots=8, copy=False)
     dt = time.time() - t0
     _note("cfg5: 32 GiB random (torch.randint on the GPU, seed 5), -L7 -w 328, one chunk, input in HBM: %.1f s = %.1f MB/s, image %d bytes "
-          "(every literal block stored through the lz4 gate), cold pools" % (dt, (n >> 20) / dt, len(out)))
+          "(every literal block stored through the lz4 gate), cold pools; generating the input took %.1f s" % (dt, (n >> 20) / dt, len(out), t_gen))
     assert len(out) > n  # incompressible: stored blocks + headers
     # Incompressible input: no match, every literal block stored -- the image IS the input cut into stored blocks.
     # Walk the container (every header of the chain), check that, and compare block payloads with the source where
