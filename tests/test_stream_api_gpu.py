@@ -31,7 +31,7 @@ def _chunks(B, O, data, window, level=7):
                                            ("cfg3", 104857600 + 40 * 1048576 + 4321, 1), ("tiny", 100, 0), ("empty", 0, 0)])
 def test_stream_api_writes_the_same_file(B, O, tmp_path, kind, n, window):
     if kind == "cfg3":
-        data = datagen.cfg3(n, 30 * 1048576, seed=4)
+        data = datagen.cfg3(n, 15 * 1048576, seed=4)
     elif kind in ("tiny", "empty"):
         data = datagen.text_like(n, seed=2)
     else:
