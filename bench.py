@@ -301,8 +301,8 @@ def cpu_baseline(buf, n_bytes, sample_bytes, ctl_kw, cores, desc):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=["cfg3", "cfg2"], default=os.environ.get("LRZGPU_BENCH_WORKLOAD", "cfg3"))
     ap.add_argument("--mib", type=int, default=int(os.environ.get("LRZGPU_BENCH_MIB", "0")),
                     help="file size in MiB (default: 16384 for cfg3, 4096 for cfg2)")
