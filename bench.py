@@ -139,13 +139,20 @@ def make_cfg3(n_bytes, base_bytes, seed, device, alphabet="alnum", mutate_every=
     return buf
 
 
-def build_id():
-    """Identifies the DEVICE code a PMC summary was measured for: every .hip translation unit of csrc/ and the
-    local headers they include, transitively (HBM bytes per launch of a kernel are a property of the kernel and of
-    the workload key stored next to it; host-only sources -- parser, hashes, read side -- do not enter)."""
+# the translation unit of csrc/ each profiled kernel is compiled from
+KERNEL_UNIT = {"k_resolve": "rzip_scan.hip", "k_tag_scan": "rzip_scan.hip", "k_long_compare": "rzip_scan.hip",
+               "k_gather_runs": "rzip_scan.hip", "k_crc32_tiles": "rzip_scan.hip", "k_bt": "lzma_mf.hip",
+               "k_lz4_size": "lz4_gate.hip"}
+
+
+def build_id(unit=None):
+    """Identifies the DEVICE code a PMC summary was measured for: every .hip translation unit of csrc/ (or, with
+    `unit`, that one alone) and the local headers they include, transitively (HBM bytes per launch of a kernel are a
+    property of the kernel's translation unit and of the workload key stored next to it; host-only sources -- parser,
+    hashes, read side -- do not enter)."""
     import re
     src = os.path.join(ROOT, "lrzip-next_amd", "csrc")
-    todo = sorted(glob.glob(os.path.join(src, "*.hip")))
+    todo = [os.path.join(src, unit)] if unit else sorted(glob.glob(os.path.join(src, "*.hip")))
     seen = []
     while todo:
         p = todo.pop(0)
@@ -165,6 +172,11 @@ def build_id():
     return h.hexdigest()[:16]
 
 
+def unit_build_ids():
+    src = os.path.join(ROOT, "lrzip-next_amd", "csrc")
+    return {os.path.basename(p): build_id(os.path.basename(p)) for p in sorted(glob.glob(os.path.join(src, "*.hip")))}
+
+
 def pmc_traffic(kernel, workload_key):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary -- only if it was collected
     for exactly this build and workload (tools/pmc_collect.py writes the summary); else None."""
@@ -173,8 +185,13 @@ def pmc_traffic(kernel, workload_key):
         d = json.load(open(path))
     except (OSError, ValueError):
         return None, "no PMC summary committed (tools/pmc_collect.py)"
+    same_unit = ""
     if d.get("build_id") != build_id():
-        return None, "PMC summary is for build %s, this is build %s: not reported" % (d.get("build_id"), build_id())
+        # another build: the figure still stands if the translation unit this kernel comes from is byte-identical
+        unit = KERNEL_UNIT.get(kernel)
+        if not unit or d.get("unit_build_ids", {}).get(unit) != build_id(unit):
+            return None, "PMC summary is for build %s, this is build %s: not reported" % (d.get("build_id"), build_id())
+        same_unit = "; measured on build %s, this is build %s with %s and its headers unchanged" % (d.get("build_id"), build_id(), unit)
     if d.get("workload_key") != workload_key:
         return None, "PMC summary is for workload %s" % d.get("workload_key")
     ks = d.get("kernels", {})
@@ -182,7 +199,7 @@ def pmc_traffic(kernel, workload_key):
     k = ks.get(kernel + "_mw") or ks.get(kernel + "+" + kernel + "_wave") or ks.get(kernel)
     if not k:
         return None, "kernel not in the PMC summary"
-    return int(k["bytes_per_launch"]), d.get("note", "")
+    return int(k["bytes_per_launch"]), d.get("note", "") + same_unit
 
 
 def usable_cpus():

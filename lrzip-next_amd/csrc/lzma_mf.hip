@@ -105,21 +105,30 @@ __global__ void __launch_bounds__(256) k_flag_heads(const uint32_t *__restrict__
 		flags[k] = (k == 0 || skey[k] != skey[k - 1]) ? 1 : 0;
 }
 
-// bucket lengths; *n_long = how many of them have at least `long_min` positions (those go to k_bt_wave)
+// bucket lengths; n_ge[k] = how many of them have at least tiers.min_len[k] positions (the buckets are sorted by length
+// afterwards, so these counts are the launch boundaries: k_bt_wave from memory, k_bt_wave from LDS by capacity, k_bt)
+constexpr int kBtTiers = 6;
+struct BtTiers {
+	uint32_t min_len[kBtTiers];
+};
 __global__ void __launch_bounds__(256) k_seg_len(const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ nseg_p,
-						 uint32_t n4, uint32_t *__restrict__ seg_len, uint32_t long_min, uint32_t *__restrict__ n_long)
+						 uint32_t n4, uint32_t *__restrict__ seg_len, BtTiers tiers, uint32_t *__restrict__ n_ge)
 {
 	uint32_t nseg = *nseg_p;
 	uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
 	uint32_t stride = gridDim.x * blockDim.x;
-	uint32_t mine = 0;
+	uint32_t mine[kBtTiers] = {0, 0, 0, 0, 0, 0};
 	for (; s < nseg; s += stride) {
 		const uint32_t len = (s + 1 < nseg ? seg_start[s + 1] : n4) - seg_start[s];
 		seg_len[s] = len;
-		mine += len >= long_min ? 1u : 0u;
+#pragma unroll
+		for (int k = 0; k < kBtTiers; k++)
+			mine[k] += len >= tiers.min_len[k] ? 1u : 0u;
 	}
-	if (mine)
-		atomicAdd(n_long, mine);
+#pragma unroll
+	for (int k = 0; k < kBtTiers; k++)
+		if (mine[k])
+			atomicAdd(n_ge + k, mine[k]);
 }
 
 constexpr int kMaxRec = 128; // u32 entries per position: 2 * (2 hash pairs + cut (<= 48)) -> 100
@@ -638,7 +647,12 @@ __device__ __forceinline__ void store_node_coh(BtNode *np, const BtNode &v)
 
 enum : uint32_t { W_IDLE = 0, W_LOAD = 1, W_SONS = 2, W_FINISH = 3, W_OVER = 4 };
 
-__global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src, uint32_t n,
+// CAP == 0: the tree nodes live in memory (`node`).  CAP > 0: the bucket has at most CAP positions and its nodes live
+// in LDS for the whole launch -- a tree only links positions of one bucket and nothing reads it once the bucket's last
+// position has been walked, so the nodes never reach memory at all: what is left of the kernel's traffic is the bucket's
+// positions and bytes in, its lists out, and a round is an LDS round trip instead of an L2 one.
+template <uint32_t CAP>
+__global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src, uint32_t n, uint32_t seg_base,
 						const uint32_t *__restrict__ spos,
 						const uint32_t *__restrict__ seg_len_sorted, const uint32_t *__restrict__ seg_start_sorted,
 						BtNode *node,
@@ -650,18 +664,40 @@ __global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src,
 						unsigned long long *__restrict__ stats)
 {
 	__shared__ uint32_t rec_s[kMaxRec][64];
+	__shared__ __attribute__((aligned(32))) uint32_t node_l[CAP ? CAP * 8 : 8];
 	__shared__ uint32_t st_i[64], st_w[5][64], st_c2[64], st_c3[64], st_b[64]; // the staged window of positions
+	// Orders a round's tree stores before the next round's loads.  Tree in memory: a workgroup-scope fence (waits for
+	// every outstanding store of the wave).  Tree in LDS: the LDS operations of ONE wavefront execute in program order,
+	// so the compiler must not move them and that is all -- above all the round does not wait for the global stores of
+	// the lists a finished walk has just written (1.5-2 us each: first build of the LDS kernel, 2.3 us per round).
+	auto tree_fence = [&]() {
+		if constexpr (CAP != 0)
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+		else
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	};
 	const uint32_t lane = threadIdx.x;
 	const uint64_t lt_mask = ((uint64_t)1 << lane) - 1;
-	const uint32_t k0 = seg_start_sorted[blockIdx.x];
-	const uint32_t L = seg_len_sorted[blockIdx.x];
+	const uint32_t k0 = seg_start_sorted[seg_base + blockIdx.x];
+	const uint32_t L = seg_len_sorted[seg_base + blockIdx.x];
+	if (CAP && L > CAP) { // (the host sorts buckets into launches by length: cannot happen)
+		*err = 3;
+		return;
+	}
 	const uint32_t cyc_size = dict + 1;
-	uint32_t *const words = reinterpret_cast<uint32_t *>(node); // slot (x, side) = words[8 * x + side]
+	// slot (x, side) = word 8 * x + side of the node array, x = sorted index
+	auto word_at = [&](uint32_t idx) -> uint32_t * {
+		if constexpr (CAP != 0)
+			return node_l + (idx - 8 * k0);
+		else
+			return reinterpret_cast<uint32_t *>(node) + idx;
+	};
+	auto node_at = [&](uint32_t x) -> BtNode * { return reinterpret_cast<BtNode *>(word_at(8 * x)); };
 	uint32_t stage_base = 0, stage_end = 0, stage_prev = 0; // wave-uniform: the window, and the position before it
 	uint32_t pd_c2 = 0, pd_c3 = 0, pd_bytes = 0;            // the walk's h2 / h3 candidates
 	// stage the 64 positions of the bucket from `from` on (every lane loads one; called by the whole wave)
 	auto restage = [&](uint32_t from) {
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // (the readers of the old window are done)
+		tree_fence(); // (the readers of the old window are done)
 		PosData d{};
 		const uint32_t q = from + lane;
 		if (q < L)
@@ -676,7 +712,7 @@ __global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src,
 		stage_prev = from ? spos[k0 + from - 1] + 1 : 0;
 		stage_base = from;
 		stage_end = from + 64 < L ? from + 64 : L;
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		tree_fence();
 	};
 	restage(0);
 	WaveAlloc wa{0, 0, chunk};
@@ -744,7 +780,7 @@ __global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src,
 						cur_ref = self; // sorted index + 1 of the predecessor
 						state = W_LOAD;
 					}
-					store_node_coh(node + self, me);
+					store_node_coh(node_at(self), me);
 				}
 				uint32_t started = (uint32_t)__popcll(m);
 				if (started > room)
@@ -762,12 +798,12 @@ __global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src,
 		st_steps += (state == W_LOAD) ? 1u : 0u;
 		st_stalls += (state == W_SONS) ? 1u : 0u;
 		// the stores of this round (new nodes, resolved and marked slots) complete before the loads of the next
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		tree_fence();
 
 		// ---- one step of every walk -----------------------------------------------------------------------------
 		if (state == W_LOAD || state == W_SONS) {
 			const uint32_t x = cur_ref - 1;
-			const uint64_t *q = reinterpret_cast<const uint64_t *>(node + x);
+			const uint64_t *q = reinterpret_cast<const uint64_t *>(node_at(x));
 			const uint64_t sons = ld_coh64(q);
 			uint32_t s0 = (uint32_t)sons, s1 = (uint32_t)(sons >> 32);
 			bool go = true;
@@ -777,8 +813,8 @@ __global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src,
 				const uint32_t nw[5] = {(uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32), (uint32_t)c, (uint32_t)(c >> 32)};
 				const uint32_t delta = pos - npos;
 				if (delta >= cbs) {
-					st_coh(words + slot0, 0);
-					st_coh(words + slot1, 0);
+					st_coh(word_at(slot0), 0);
+					st_coh(word_at(slot1), 0);
 					state = W_FINISH;
 					go = false;
 				} else {
@@ -813,8 +849,8 @@ __global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src,
 			if (go) {
 				if (n_side == 2) {
 					if (s0 != kPending && s1 != kPending) {
-						st_coh(words + slot1, s0);
-						st_coh(words + slot0, s1);
+						st_coh(word_at(slot1), s0);
+						st_coh(word_at(slot0), s1);
 						run_s0 = s0;
 						run_s1 = s1;
 						state = W_FINISH;
@@ -825,25 +861,25 @@ __global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src,
 					if (next != kPending) {
 						const uint32_t taken = 8 * x + n_side; // &x.son1 (smaller) / &x.son0
 						if (n_side) {
-							st_coh(words + slot1, cur_ref);
+							st_coh(word_at(slot1), cur_ref);
 							slot1 = taken;
 							len1 = n_len;
 						} else {
-							st_coh(words + slot0, cur_ref);
+							st_coh(word_at(slot0), cur_ref);
 							slot0 = taken;
 							len0 = n_len;
 						}
 						if (next >= cur_ref) { // corrupt tree (cannot happen): stop like the reference
 							*err = 2;
-							st_coh(words + slot0, 0);
-							st_coh(words + slot1, 0);
+							st_coh(word_at(slot0), 0);
+							st_coh(word_at(slot1), 0);
 							state = W_FINISH;
 						} else if (--cv == 0 || next == 0) {
-							st_coh(words + slot0, 0);
-							st_coh(words + slot1, 0);
+							st_coh(word_at(slot0), 0);
+							st_coh(word_at(slot1), 0);
 							state = W_FINISH;
 						} else {
-							st_coh(words + taken, kPending); // ours until this walk writes its next subtree root there
+							st_coh(word_at(taken), kPending); // ours until this walk writes its next subtree root there
 							cur_ref = next;
 							state = W_LOAD;
 						}
@@ -926,7 +962,7 @@ __global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src,
 #pragma unroll
 					for (int k = 0; k < 5; k++)
 						rn.w[k] = b * 0x01010101u; // fb >= 20 bytes of the run lie ahead of every one of them
-					store_node_coh(node + k0 + idx, rn);
+					store_node_coh(node_at(k0 + idx), rn);
 					counts[iq] = 2;
 					tmp_start[iq] = st;
 					if (st + 2 > pool_cap)
@@ -1151,7 +1187,7 @@ int mf_workspace_create(MfWorkspace **out, size_t max_n, double pool_per_pos)
 	HIPCHK(hipMalloc(&w->offsets, n * 8));
 	HIPCHK(hipMalloc(&w->pool_tmp, w->pool_cap * 4));
 	HIPCHK(hipMalloc(&w->pool_out, w->pool_cap * 4));
-	HIPCHK(hipMalloc(&w->scalars, 64));
+	HIPCHK(hipMalloc(&w->scalars, 128));
 	// temp storage: the largest request among the cub calls used below
 	size_t need = 0, t = 0;
 	(void)hipcub::DeviceRadixSort::SortPairs(nullptr, t, w->key_a, w->key_b, w->val_a, w->val_b, (int)max_n, 0, 32);
@@ -1210,7 +1246,8 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 	int *d_err = (int *)((unsigned long long *)w->scalars + 3);           // [3]
 	EventTimer t_all(s);
 	EventTimer *t_bt = nullptr;
-	HIPCHK(hipMemsetAsync(w->scalars, 0, 64, s));
+	HIPCHK(hipMemsetAsync(w->scalars, 0, 128, s));
+	uint32_t *d_nge = (uint32_t *)((unsigned long long *)w->scalars + 8); // [8..10]: kBtTiers bucket counts
 	*total_entries = 0;
 	if (n == 0)
 		return 0;
@@ -1268,29 +1305,81 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 		tb = w->cub_bytes;
 		HIPCHK(hipcub::DeviceSelect::Flagged(w->cub_tmp, tb, hipcub::CountingInputIterator<uint32_t>(0), w->flags,
 						     w->seg_start, d_nseg, (int)n4, s));
-		// buckets of at least this many positions get a wavefront each (k_bt_wave), the rest a lane each (k_bt)
+		// buckets of at least this many positions get a wavefront each and keep their tree in memory (k_bt_wave<0>)
 		uint32_t long_min = 4096;
 		if (const char *e = getenv("LRZGPU_BT_WAVE_MIN")) { // read per call: tests force 1 (every bucket through the
 			const long v = atol(e);                      // pipelined kernel) and a huge value (none) inside one process
 			long_min = (uint32_t)(v < 1 ? 1 : (v > 0x7FFFFFFF ? 0x7FFFFFFF : v));
 		}
-		hipLaunchKernelGGL(k_seg_len, dim3(g), dim3(256), 0, s, w->seg_start, d_nseg, n4, w->seg_len, long_min, d_nseg + 1);
-		uint32_t nseg_long[2] = {0, 0};
-		HIPCHK(d2h_pageable(nseg_long, d_nseg, 8, s)); // (sleeps while the sorts run)
-		const uint32_t nseg = nseg_long[0], nlong = nseg_long[1] > nseg_long[0] ? nseg_long[0] : nseg_long[1];
+		// shorter ones down to this many positions get a wavefront each and keep their tree in LDS (k_bt_wave<CAP>, the
+		// launch by the capacity that holds them); the rest a lane each (k_bt).  Unset / 0: no LDS launches.
+		uint32_t lds_min = 0;
+		if (const char *e = getenv("LRZGPU_BT_LDS_MIN")) {
+			const long v = atol(e);
+			lds_min = (uint32_t)(v < 0 ? 0 : (v > 0x7FFFFFFF ? 0x7FFFFFFF : v));
+		}
+		static const uint32_t kLdsCap[kBtTiers - 1] = {3840, 2048, 1024, 512, 256};
+		if (lds_min && lds_min <= kLdsCap[0] && long_min > kLdsCap[0] + 1)
+			long_min = kLdsCap[0] + 1; // (what no LDS launch can hold goes to the kernel that works from memory)
+		// launch k (k >= 1) takes the buckets of tiers.min_len[k] .. tiers.min_len[k - 1] - 1 positions
+		BtTiers tiers;
+		int lds_cap[kBtTiers] = {0, 0, 0, 0, 0, 0};
+		int ntier = 1;
+		tiers.min_len[0] = long_min;
+		if (lds_min && lds_min < long_min)
+			for (int c = 0; c < kBtTiers - 1; c++) {
+				const uint32_t top = tiers.min_len[ntier - 1] - 1; // longest bucket still without a launch
+				if (top > kLdsCap[c] || top < lds_min)
+					continue; // (capacity too small for it / nothing left to take)
+				const uint32_t below = c + 1 < kBtTiers - 1 ? kLdsCap[c + 1] + 1 : 1;
+				if (c + 1 < kBtTiers - 1 && top <= kLdsCap[c + 1])
+					continue; // the next smaller capacity holds them all
+				lds_cap[ntier] = (int)kLdsCap[c];
+				tiers.min_len[ntier] = below > lds_min ? below : lds_min;
+				ntier++;
+				if (tiers.min_len[ntier - 1] == lds_min)
+					break;
+			}
+		for (int k = ntier; k < kBtTiers; k++)
+			tiers.min_len[k] = 0xFFFFFFFFu;
+		hipLaunchKernelGGL(k_seg_len, dim3(g), dim3(256), 0, s, w->seg_start, d_nseg, n4, w->seg_len, tiers, d_nge);
+		uint32_t sc[22] = {0};
+		HIPCHK(d2h_pageable(sc, d_nseg, 88, s)); // nseg at [0], the tier counts at [12..]  (sleeps while the sorts run)
+		const uint32_t nseg = sc[0];
+		uint32_t bound[kBtTiers];
+		for (int k = 0; k < ntier; k++) {
+			bound[k] = sc[12 + k] > nseg ? nseg : sc[12 + k];
+			if (k && bound[k] < bound[k - 1])
+				bound[k] = bound[k - 1];
+		}
+		const uint32_t nlong = bound[0], nwave = bound[ntier - 1];
 		// longest buckets first
 		tb = w->cub_bytes;
 		HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(w->cub_tmp, tb, w->seg_len, w->seg_len_s, w->seg_start,
 								    w->seg_start_s, (int)nseg, 0, 32, s));
-		const uint32_t chunk = pool_chunk(w->pool_cap, (unsigned long long)nlong + (nseg - nlong + 63) / 64);
+		const uint32_t chunk = pool_chunk(w->pool_cap, (unsigned long long)nwave + (nseg - nwave + 63) / 64);
 		t_bt = new EventTimer(s);
+#define LRZGPU_BT_WAVE_ARGS(base)                                                                                                \
+	d_src, (uint32_t)n, (uint32_t)(base), w->spos, w->seg_len_s, w->seg_start_s, (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, \
+		w->counts, w->tmp_start, w->pool_tmp, d_cursor, w->pool_cap, chunk, d_err, (unsigned long long *)w->scalars + 4
 		if (nlong)
-			hipLaunchKernelGGL(k_bt_wave, dim3(nlong), dim3(64), 0, s, d_src, (uint32_t)n, w->spos, w->seg_len_s, w->seg_start_s,
-					   (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, w->counts, w->tmp_start, w->pool_tmp, d_cursor,
-					   w->pool_cap, chunk, d_err, (unsigned long long *)w->scalars + 4);
-		if (nseg > nlong)
-			hipLaunchKernelGGL(k_bt, dim3((nseg - nlong + 63) / 64), dim3(64), 0, s, d_src, (uint32_t)n, w->spos, w->seg_len_s,
-					   w->seg_start_s, d_nseg, nlong, (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, w->counts,
+			hipLaunchKernelGGL(k_bt_wave<0>, dim3(nlong), dim3(64), 0, s, LRZGPU_BT_WAVE_ARGS(0));
+		for (int k = 1; k < ntier; k++) {
+			const uint32_t cnt = bound[k] - bound[k - 1];
+			if (!cnt)
+				continue;
+			switch (lds_cap[k]) {
+			case 3840: hipLaunchKernelGGL(k_bt_wave<3840>, dim3(cnt), dim3(64), 0, s, LRZGPU_BT_WAVE_ARGS(bound[k - 1])); break;
+			case 2048: hipLaunchKernelGGL(k_bt_wave<2048>, dim3(cnt), dim3(64), 0, s, LRZGPU_BT_WAVE_ARGS(bound[k - 1])); break;
+			case 1024: hipLaunchKernelGGL(k_bt_wave<1024>, dim3(cnt), dim3(64), 0, s, LRZGPU_BT_WAVE_ARGS(bound[k - 1])); break;
+			case 512: hipLaunchKernelGGL(k_bt_wave<512>, dim3(cnt), dim3(64), 0, s, LRZGPU_BT_WAVE_ARGS(bound[k - 1])); break;
+			default: hipLaunchKernelGGL(k_bt_wave<256>, dim3(cnt), dim3(64), 0, s, LRZGPU_BT_WAVE_ARGS(bound[k - 1])); break;
+			}
+		}
+#undef LRZGPU_BT_WAVE_ARGS
+		if (nseg > nwave)
+			hipLaunchKernelGGL(k_bt, dim3((nseg - nwave + 63) / 64), dim3(64), 0, s, d_src, (uint32_t)n, w->spos, w->seg_len_s,
+					   w->seg_start_s, d_nseg, nwave, (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, w->counts,
 					   w->tmp_start, w->pool_tmp, d_cursor, w->pool_cap, chunk, d_err);
 		t_bt->stop();
 	}

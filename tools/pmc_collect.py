@@ -91,7 +91,7 @@ def main():
     a = dict(zip(sys.argv[2::2], sys.argv[3::2]))
     mib = int(a.get("--mib", 16384 if wk == "cfg3" else 4096))
     window = int(a.get("--window", 21 if wk == "cfg3" else 0))
-    json.dump({"build_id": bench.build_id(), "workload_key": "%s-%dMiB-w%d-%s" % (wk, mib, window, a.get("--alphabet", "alnum")),
+    json.dump({"build_id": bench.build_id(), "unit_build_ids": bench.unit_build_ids(), "workload_key": "%s-%dMiB-w%d-%s" % (wk, mib, window, a.get("--alphabet", "alnum")),
                "kernels": kernels,
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KB x 1024 per launch; fetch x 2 for the wide "
                        "streaming kernels (gfx950 counts 64 B per 128 B request), raw for the narrow random-access ones (uncalibrated: "
