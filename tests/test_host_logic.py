@@ -201,3 +201,43 @@ print("ok")
     env = dict(os.environ, LRZGPU_NO_AVX512="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+def test_bench_pmc_traffic_is_tied_to_the_kernels_translation_unit(monkeypatch, tmp_path):
+    """bench.py reports roofline.traffic from the committed PMC summary only for the device code it was measured on:
+    the same build, or another build whose translation unit of THAT kernel (and its headers) is byte-identical."""
+    import importlib.util, json, shutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ids = bench.unit_build_ids()
+    assert set(bench.KERNEL_UNIT.values()) <= set(ids) and all(len(v) == 16 for v in ids.values())
+    # a scratch tree: the device sources + a summary written for them
+    src = os.path.join(root, "lrzip-next_amd", "csrc")
+    dst = tmp_path / "lrzip-next_amd" / "csrc"
+    dst.mkdir(parents=True)
+    for f in os.listdir(src):
+        if f.endswith((".hip", ".h")):
+            shutil.copy(os.path.join(src, f), dst / f)
+    (tmp_path / "include").mkdir()
+    for f in os.listdir(os.path.join(root, "include")):
+        shutil.copy(os.path.join(root, "include", f), tmp_path / "include" / f)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.build_id() and bench.unit_build_ids() == ids
+    (tmp_path / "profiles").mkdir()
+    summary = {"build_id": bench.build_id(), "unit_build_ids": bench.unit_build_ids(), "workload_key": "w",
+               "kernels": {"k_resolve_mw": {"bytes_per_launch": 123.0}, "k_bt": {"bytes_per_launch": 456.0}}, "note": "n"}
+    (tmp_path / "profiles" / "pmc_summary.json").write_text(json.dumps(summary))
+    assert bench.pmc_traffic("k_resolve", "w") == (123, "n")
+    assert bench.pmc_traffic("k_resolve", "other")[0] is None
+    # the finder's unit changes: the resolver's figure stands (and says so), the finder's does not
+    with open(dst / "lzma_mf.hip", "a") as f:
+        f.write("// changed\n")
+    got, note = bench.pmc_traffic("k_resolve", "w")
+    assert got == 123 and "rzip_scan.hip and its headers unchanged" in note
+    assert bench.pmc_traffic("k_bt", "w")[0] is None
+    # a header the resolver includes changes: nothing stands
+    with open(dst / "rzip_resolve_mw.h", "a") as f:
+        f.write("// changed\n")
+    assert bench.pmc_traffic("k_resolve", "w")[0] is None
