@@ -1377,8 +1377,15 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 			}
 		}
 #undef LRZGPU_BT_WAVE_ARGS
+		// (experiment: LRZGPU_BT_PAD_LDS = bytes of unused dynamic LDS per k_bt wavefront, i.e. fewer of them per CU --
+		//  fewer buckets in flight, a smaller set of tree tops competing for the L2)
+		unsigned bt_pad = 0;
+		if (const char *e = getenv("LRZGPU_BT_PAD_LDS")) {
+			const long v = atol(e);
+			bt_pad = (unsigned)(v < 0 ? 0 : (v > 30720 ? 30720 : v));
+		}
 		if (nseg > nwave)
-			hipLaunchKernelGGL(k_bt, dim3((nseg - nwave + 63) / 64), dim3(64), 0, s, d_src, (uint32_t)n, w->spos, w->seg_len_s,
+			hipLaunchKernelGGL(k_bt, dim3((nseg - nwave + 63) / 64), dim3(64), bt_pad, s, d_src, (uint32_t)n, w->spos, w->seg_len_s,
 					   w->seg_start_s, d_nseg, nwave, (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, w->counts,
 					   w->tmp_start, w->pool_tmp, d_cursor, w->pool_cap, chunk, d_err);
 		t_bt->stop();
