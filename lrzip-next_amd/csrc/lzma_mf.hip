@@ -33,6 +33,7 @@
 
 #include "common.h"
 #include "lzma_mf.h"
+#include "pools.h"
 #include "profile.h"
 
 namespace lrzgpu {
@@ -1246,6 +1247,8 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 	int *d_err = (int *)((unsigned long long *)w->scalars + 3);           // [3]
 	EventTimer t_all(s);
 	EventTimer *t_bt = nullptr;
+	hipStream_t s2 = nullptr; // second stream of the LRZGPU_BT_OVERLAP experiment
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	HIPCHK(hipMemsetAsync(w->scalars, 0, 128, s));
 	uint32_t *d_nge = (uint32_t *)((unsigned long long *)w->scalars + 8); // [8..10]: kBtTiers bucket counts
 	*total_entries = 0;
@@ -1359,21 +1362,33 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 								    w->seg_start_s, (int)nseg, 0, 32, s));
 		const uint32_t chunk = pool_chunk(w->pool_cap, (unsigned long long)nwave + (nseg - nwave + 63) / 64);
 		t_bt = new EventTimer(s);
+		// (experiment: LRZGPU_BT_OVERLAP=1 puts the wave-per-bucket launches on a second stream beside k_bt: they
+		//  work on different buckets and share only the pool cursor, an atomic)
+		hipStream_t sw = s;
+		if (getenv("LRZGPU_BT_OVERLAP") && nwave && nseg > nwave) {
+			s2 = pooled_stream();
+			if (s2 && hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) == hipSuccess &&
+			    hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) == hipSuccess) {
+				HIPCHK(hipEventRecord(ev_fork, s));
+				HIPCHK(hipStreamWaitEvent(s2, ev_fork, 0));
+				sw = s2;
+			}
+		}
 #define LRZGPU_BT_WAVE_ARGS(base)                                                                                                \
 	d_src, (uint32_t)n, (uint32_t)(base), w->spos, w->seg_len_s, w->seg_start_s, (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, \
 		w->counts, w->tmp_start, w->pool_tmp, d_cursor, w->pool_cap, chunk, d_err, (unsigned long long *)w->scalars + 4
 		if (nlong)
-			hipLaunchKernelGGL(k_bt_wave<0>, dim3(nlong), dim3(64), 0, s, LRZGPU_BT_WAVE_ARGS(0));
+			hipLaunchKernelGGL(k_bt_wave<0>, dim3(nlong), dim3(64), 0, sw, LRZGPU_BT_WAVE_ARGS(0));
 		for (int k = 1; k < ntier; k++) {
 			const uint32_t cnt = bound[k] - bound[k - 1];
 			if (!cnt)
 				continue;
 			switch (lds_cap[k]) {
-			case 3840: hipLaunchKernelGGL(k_bt_wave<3840>, dim3(cnt), dim3(64), 0, s, LRZGPU_BT_WAVE_ARGS(bound[k - 1])); break;
-			case 2048: hipLaunchKernelGGL(k_bt_wave<2048>, dim3(cnt), dim3(64), 0, s, LRZGPU_BT_WAVE_ARGS(bound[k - 1])); break;
-			case 1024: hipLaunchKernelGGL(k_bt_wave<1024>, dim3(cnt), dim3(64), 0, s, LRZGPU_BT_WAVE_ARGS(bound[k - 1])); break;
-			case 512: hipLaunchKernelGGL(k_bt_wave<512>, dim3(cnt), dim3(64), 0, s, LRZGPU_BT_WAVE_ARGS(bound[k - 1])); break;
-			default: hipLaunchKernelGGL(k_bt_wave<256>, dim3(cnt), dim3(64), 0, s, LRZGPU_BT_WAVE_ARGS(bound[k - 1])); break;
+			case 3840: hipLaunchKernelGGL(k_bt_wave<3840>, dim3(cnt), dim3(64), 0, sw, LRZGPU_BT_WAVE_ARGS(bound[k - 1])); break;
+			case 2048: hipLaunchKernelGGL(k_bt_wave<2048>, dim3(cnt), dim3(64), 0, sw, LRZGPU_BT_WAVE_ARGS(bound[k - 1])); break;
+			case 1024: hipLaunchKernelGGL(k_bt_wave<1024>, dim3(cnt), dim3(64), 0, sw, LRZGPU_BT_WAVE_ARGS(bound[k - 1])); break;
+			case 512: hipLaunchKernelGGL(k_bt_wave<512>, dim3(cnt), dim3(64), 0, sw, LRZGPU_BT_WAVE_ARGS(bound[k - 1])); break;
+			default: hipLaunchKernelGGL(k_bt_wave<256>, dim3(cnt), dim3(64), 0, sw, LRZGPU_BT_WAVE_ARGS(bound[k - 1])); break;
 			}
 		}
 #undef LRZGPU_BT_WAVE_ARGS
@@ -1388,6 +1403,10 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 			hipLaunchKernelGGL(k_bt, dim3((nseg - nwave + 63) / 64), dim3(64), bt_pad, s, d_src, (uint32_t)n, w->spos, w->seg_len_s,
 					   w->seg_start_s, d_nseg, nwave, (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, w->counts,
 					   w->tmp_start, w->pool_tmp, d_cursor, w->pool_cap, chunk, d_err);
+		if (sw != s) { // join: everything behind this point on `s` follows both
+			HIPCHK(hipEventRecord(ev_join, s2));
+			HIPCHK(hipStreamWaitEvent(s, ev_join, 0));
+		}
 		t_bt->stop();
 	}
 	{
@@ -1414,6 +1433,12 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 			ps.p.mf_wave_dbg[k] += (int64_t)host_sc[4 + k];
 	}
 	delete t_bt;
+	if (ev_fork)
+		(void)hipEventDestroy(ev_fork);
+	if (ev_join)
+		(void)hipEventDestroy(ev_join);
+	if (s2)
+		StreamPool::get().give(s2); // idle: `s` waited for its last launch and has been drained above
 	int err = (int)(host_sc[3] & 0xFFFFFFFFu);
 	if (err == 1)
 		return -4; // pool too small
