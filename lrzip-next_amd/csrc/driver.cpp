@@ -214,12 +214,39 @@ static bool tracing_events()
 				(j)->ref.streamno, (long long)(j)->ref.off, (long long)(j)->ref.len);                                 \
 	} while (0)
 
+// Experiment (LRZGPU_SCAN_EXCLUSIVE_CUS=n, 1..16; unset = off): every scanner owns n CUs that nothing else may use --
+// its scan stream is masked to them (make_scan_stream) and every other stream of the pipeline to the rest of the chip.
+// The resolver is one latency-bound workgroup; measured with the finder's wave-per-bucket launches spread over the
+// chip, whatever shares its CU costs it (470 -> 741 ms per launch).
+static int scan_exclusive_cus()
+{
+	static const int n = [] {
+		const char *e = getenv("LRZGPU_SCAN_EXCLUSIVE_CUS");
+		const int v = e ? atoi(e) : 0;
+		return v < 0 ? 0 : (v > 16 ? 16 : v);
+	}();
+	return n;
+}
 static hipError_t make_stream(hipStream_t *s, bool high_priority = false)
 {
-	const int dev = current_device_or0(), kind = high_priority ? 1 : 0;
+	const int dev = current_device_or0();
+	const int excl = high_priority ? 0 : scan_exclusive_cus();
+	const int kind = high_priority ? 1 : (excl ? 64 : 0);
 	if ((*s = StreamPool::get().take(dev, kind)) != nullptr)
 		return hipSuccess;
 	hipError_t e = hipErrorUnknown;
+	if (excl) {
+		hipDeviceProp_t prop;
+		if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 8 * excl + 32) {
+			const int ncu = prop.multiProcessorCount > 256 ? 256 : prop.multiProcessorCount;
+			uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+			for (int c = 8 * excl; c < ncu; c++)
+				mask[c >> 5] |= 1u << (c & 31);
+			e = hipExtStreamCreateWithCUMask(s, (uint32_t)((ncu + 31) / 32), mask);
+			if (e != hipSuccess)
+				(void)hipGetLastError();
+		}
+	}
 	if (high_priority) {
 		// a scan stream must never queue behind a multi-second gate/finder kernel: streams share a
 		// small pool of hardware queues (GPU_MAX_HW_QUEUES), priority streams get their own
@@ -1214,16 +1241,18 @@ struct Run {
 	{
 		static const bool off = getenv("LRZGPU_NO_SCAN_CU_MASK") != nullptr;
 		hipDeviceProp_t prop;
-		if (scan_slots > 1 && !off && hipGetDeviceProperties(&prop, P.device) == hipSuccess && prop.multiProcessorCount >= 64) {
+		if ((scan_slots > 1 || scan_exclusive_cus()) && !off && hipGetDeviceProperties(&prop, P.device) == hipSuccess && prop.multiProcessorCount >= 64) {
 			const int ncu = prop.multiProcessorCount > 256 ? 256 : prop.multiProcessorCount;
 			const int k = scanner_ids.fetch_add(1) % 8;
-			if ((*s = StreamPool::get().take(P.device, 16 + k)) != nullptr)
+			const int excl = scan_exclusive_cus(); // experiment: CUs k, k + 8, ... below 8 * excl, and nobody else's
+			const int kind = (excl ? 48 : 16) + k;
+			if ((*s = StreamPool::get().take(P.device, kind)) != nullptr)
 				return hipSuccess;
 			uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-			for (int c = k; c < ncu; c += 8)
+			for (int c = k; c < (excl ? 8 * excl : ncu); c += 8)
 				mask[c >> 5] |= 1u << (c & 31);
 			if (hipExtStreamCreateWithCUMask(s, (uint32_t)((ncu + 31) / 32), mask) == hipSuccess) {
-				StreamPool::get().created(*s, P.device, 16 + k);
+				StreamPool::get().created(*s, P.device, kind);
 				return hipSuccess;
 			}
 			(void)hipGetLastError();
