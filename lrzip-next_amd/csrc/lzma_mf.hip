@@ -32,6 +32,7 @@
 #include <cstring>
 
 #include "common.h"
+#include "bt_tiers.h"
 #include "lzma_mf.h"
 #include "pools.h"
 #include "profile.h"
@@ -108,10 +109,6 @@ __global__ void __launch_bounds__(256) k_flag_heads(const uint32_t *__restrict__
 
 // bucket lengths; n_ge[k] = how many of them have at least tiers.min_len[k] positions (the buckets are sorted by length
 // afterwards, so these counts are the launch boundaries: k_bt_wave from memory, k_bt_wave from LDS by capacity, k_bt)
-constexpr int kBtTiers = 6;
-struct BtTiers {
-	uint32_t min_len[kBtTiers];
-};
 __global__ void __launch_bounds__(256) k_seg_len(const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ nseg_p,
 						 uint32_t n4, uint32_t *__restrict__ seg_len, BtTiers tiers, uint32_t *__restrict__ n_ge)
 {
@@ -1321,30 +1318,11 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 			const long v = atol(e);
 			lds_min = (uint32_t)(v < 0 ? 0 : (v > 0x7FFFFFFF ? 0x7FFFFFFF : v));
 		}
-		static const uint32_t kLdsCap[kBtTiers - 1] = {3840, 2048, 1024, 512, 256};
-		if (lds_min && lds_min <= kLdsCap[0] && long_min > kLdsCap[0] + 1)
-			long_min = kLdsCap[0] + 1; // (what no LDS launch can hold goes to the kernel that works from memory)
-		// launch k (k >= 1) takes the buckets of tiers.min_len[k] .. tiers.min_len[k - 1] - 1 positions
-		BtTiers tiers;
-		int lds_cap[kBtTiers] = {0, 0, 0, 0, 0, 0};
-		int ntier = 1;
-		tiers.min_len[0] = long_min;
-		if (lds_min && lds_min < long_min)
-			for (int c = 0; c < kBtTiers - 1; c++) {
-				const uint32_t top = tiers.min_len[ntier - 1] - 1; // longest bucket still without a launch
-				if (top > kLdsCap[c] || top < lds_min)
-					continue; // (capacity too small for it / nothing left to take)
-				const uint32_t below = c + 1 < kBtTiers - 1 ? kLdsCap[c + 1] + 1 : 1;
-				if (c + 1 < kBtTiers - 1 && top <= kLdsCap[c + 1])
-					continue; // the next smaller capacity holds them all
-				lds_cap[ntier] = (int)kLdsCap[c];
-				tiers.min_len[ntier] = below > lds_min ? below : lds_min;
-				ntier++;
-				if (tiers.min_len[ntier - 1] == lds_min)
-					break;
-			}
-		for (int k = ntier; k < kBtTiers; k++)
-			tiers.min_len[k] = 0xFFFFFFFFu;
+		// launch k (k >= 1) takes the buckets of tiers.min_len[k] .. tiers.min_len[k - 1] - 1 positions (bt_tiers.h)
+		const BtLaunchPlan plan = bt_plan_launches(long_min, lds_min);
+		const BtTiers &tiers = plan.tiers;
+		const uint32_t *lds_cap = plan.lds_cap;
+		const int ntier = plan.n;
 		hipLaunchKernelGGL(k_seg_len, dim3(g), dim3(256), 0, s, w->seg_start, d_nseg, n4, w->seg_len, tiers, d_nge);
 		uint32_t sc[22] = {0};
 		HIPCHK(d2h_pageable(sc, d_nseg, 88, s)); // nseg at [0], the tier counts at [12..]  (sleeps while the sorts run)
