@@ -1244,8 +1244,25 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 	int *d_err = (int *)((unsigned long long *)w->scalars + 3);           // [3]
 	EventTimer t_all(s);
 	EventTimer *t_bt = nullptr;
-	hipStream_t s2 = nullptr; // second stream of the LRZGPU_BT_OVERLAP experiment
-	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	// second stream of the LRZGPU_BT_OVERLAP experiment; goes back to the pool idle on every way out
+	struct Fork {
+		hipStream_t s2 = nullptr;
+		hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+		bool drained = false; // the caller's stream waited for s2's last launch and was itself synchronised
+		~Fork()
+		{
+			if (s2 && !drained)
+				(void)hipStreamSynchronize(s2);
+			if (ev_fork)
+				(void)hipEventDestroy(ev_fork);
+			if (ev_join)
+				(void)hipEventDestroy(ev_join);
+			if (s2)
+				StreamPool::get().give(s2);
+		}
+	} fork;
+	hipStream_t &s2 = fork.s2;
+	hipEvent_t &ev_fork = fork.ev_fork, &ev_join = fork.ev_join;
 	HIPCHK(hipMemsetAsync(w->scalars, 0, 128, s));
 	uint32_t *d_nge = (uint32_t *)((unsigned long long *)w->scalars + 8); // [8..10]: kBtTiers bucket counts
 	*total_entries = 0;
@@ -1411,12 +1428,7 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 			ps.p.mf_wave_dbg[k] += (int64_t)host_sc[4 + k];
 	}
 	delete t_bt;
-	if (ev_fork)
-		(void)hipEventDestroy(ev_fork);
-	if (ev_join)
-		(void)hipEventDestroy(ev_join);
-	if (s2)
-		StreamPool::get().give(s2); // idle: `s` waited for its last launch and has been drained above
+	fork.drained = true; // `s` waited for s2's last launch (the join) and has been drained by the copy above
 	int err = (int)(host_sc[3] & 0xFFFFFFFFu);
 	if (err == 1)
 		return -4; // pool too small
