@@ -311,6 +311,14 @@ int lrzgpu_lzma_encode_with_lists_fmt(unsigned char *dest, size_t *destLen, cons
 				      const uint8_t *counts, const uint32_t *pairs, int list_format, int level,
 				      unsigned dictSize, int lc, int lp, int pb, int fb);
 
+/* The same on lists that arrive in two stages -- the early start of a block whose tail is still being scanned
+ * (csrc/lzma_enc.h StagedLists is the in-library interface).  This entry is its host-only
+ * harness: the encoder runs on a private copy of src[] whose bytes from early_positions on are overwritten and on
+ * lists cut off there until it asks for the rest; the stream must equal lrzgpu_lzma_encode_with_lists_fmt()'s. */
+int lrzgpu_lzma_encode_with_lists_staged(unsigned char *dest, size_t *destLen, const unsigned char *src, size_t srcLen,
+					 const uint8_t *counts, const uint32_t *pairs, size_t early_positions, int list_format,
+					 int level, unsigned dictSize, int lc, int lp, int pb, int fb);
+
 /* ---- host-only pieces of the stream layer (usable without a device) ----------------------------
  * lrzgpu_plan: the sizing open_stream_out()/rzip_fd() derive before the first chunk
  * (src/stream.c:1169-1331, src/rzip.c:999-1020); fills stream_bufsize, dictSize_used, threads_used.

@@ -361,6 +361,29 @@ def lzma_encode_with_lists(data: bytes, counts, pairs, level=7, dict_size=1 << 2
     return rc, dst.raw[:dlen.value]
 
 
+def lzma_encode_with_lists_staged(data: bytes, counts, pairs, early_positions, level=7, dict_size=1 << 25, fb=64, lc=3, lp=0, pb=2,
+                                  cap=None, list_format=0):
+    """lrzgpu_lzma_encode_with_lists_staged: the parser started on the lists of the first early_positions positions."""
+    import numpy as np
+    n = len(data)
+    if cap is None:
+        cap = n + n // 3 + 4096
+    dst = C.create_string_buffer(cap)
+    dlen = C.c_size_t(cap)
+    counts = np.ascontiguousarray(counts, dtype=np.uint8)
+    pairs = np.ascontiguousarray(pairs, dtype=np.uint32)
+    if counts.size == 0:
+        counts = np.zeros(1, dtype=np.uint8)
+    if pairs.size == 0:
+        pairs = np.zeros(1, dtype=np.uint32)
+    f = lib().lrzgpu_lzma_encode_with_lists_staged
+    f.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                  C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int]
+    f.restype = C.c_int
+    rc = f(dst, C.byref(dlen), data, n, counts.ctypes.data, pairs.ctypes.data, early_positions, list_format, level, dict_size, lc, lp, pb, fb)
+    return rc, dst.raw[:dlen.value]
+
+
 def lzma_compress(data: bytes, level=7, dict_size=1 << 25, fb=64, lc=3, lp=0, pb=2, threads=2, cap=None):
     n = len(data)
     if cap is None:

@@ -273,6 +273,82 @@ extern "C" int lrzgpu_lzma_mf_next_block(lrzgpu_mf *m, uint32_t *d, size_t cap_u
 
 extern "C" void lrzgpu_lzma_mf_close(lrzgpu_mf *m) { delete m; }
 
+// The parser on lists that arrive in two stages (lzma_enc.h StagedLists; DESIGN.md section 9 "early start").  This
+// host-only entry is the harness of that path: it runs the encoder on a PRIVATE copy of the block whose bytes from
+// early_positions on are 0xA5 and on early lists cut off at early_positions until the parser asks for the rest --
+// an encoder that looked beyond what the early stage covers would not produce the whole-block stream.
+namespace {
+struct StagedHarness {
+	std::vector<uint8_t> block;
+	const unsigned char *src;
+	size_t n, early;
+	MatchLists full;
+	int calls = 0;
+	static const MatchLists *rest(void *ctx)
+	{
+		StagedHarness *h = (StagedHarness *)ctx;
+		h->calls++;
+		if (h->early < h->n)
+			memcpy(h->block.data() + h->early, h->src + h->early, h->n - h->early);
+		return &h->full;
+	}
+};
+} // namespace
+
+extern "C" int lrzgpu_lzma_encode_with_lists_staged(unsigned char *dest, size_t *destLen, const unsigned char *src, size_t srcLen,
+						    const uint8_t *counts, const uint32_t *pairs, size_t early_positions, int list_format,
+						    int level, unsigned dictSize, int lc, int lp, int pb, int fb)
+{
+	if (list_format < 0 || list_format > 2 || !dest || !destLen || (!src && srcLen) || !counts || !pairs)
+		return LZ_ERROR_PARAM;
+	if (list_format == 2 && (dictSize > (1u << 25) || fb > 65))
+		return LZ_ERROR_PARAM;
+	LzmaParams p;
+	p.level = level;
+	p.dict_size = dictSize;
+	p.lc = lc;
+	p.lp = lp;
+	p.pb = pb;
+	p.fb = fb;
+	p.fast = level >= 0 && level < 5;
+	try {
+		StagedHarness h;
+		h.src = src;
+		h.n = srcLen;
+		h.early = early_positions < srcLen ? early_positions : srcLen;
+		h.block.assign(src, src + h.early);
+		h.block.resize(srcLen + 16, 0xA5);
+		h.full.counts = counts;
+		h.full.pairs = pairs;
+		h.full.tail_flags = list_format != 0;
+		h.full.packed = list_format == 2;
+		// the early stage's own arrays: the lists of the first `early` positions, nothing behind them
+		std::vector<uint8_t> ec(counts, counts + h.early);
+		uint64_t entries = 0;
+		for (size_t i = 0; i < h.early; i++)
+			entries += counts[i];
+		const size_t words = (size_t)(list_format == 2 ? entries / 2 : entries);
+		std::vector<uint32_t> ep(pairs, pairs + words);
+		ec.resize(srcLen + 16, 0xFE); // (what a run-away reader would take for long lists)
+		ep.resize(words + 4096, 0x7FFFFFFFu);
+		StagedLists sl;
+		sl.early = h.full;
+		sl.early.counts = ec.data();
+		sl.early.pairs = ep.data();
+		sl.early_positions = h.early;
+		sl.rest = &StagedHarness::rest;
+		sl.ctx = &h;
+		size_t out_len = 0;
+		const int r = lzma_encode_block_staged(p, h.block.data(), srcLen, sl, dest, *destLen, &out_len);
+		*destLen = out_len;
+		if (r == LZ_OK && h.early < srcLen && h.calls != 1)
+			return LZ_ERROR_PARAM; // the rest must have been asked for, once
+		return r;
+	} catch (...) {
+		return LZ_ERROR_MEM;
+	}
+}
+
 extern "C" int lrzgpu_lzma_encode_with_lists_fmt(unsigned char *dest, size_t *destLen, const unsigned char *src, size_t srcLen,
 						 const uint8_t *counts, const uint32_t *pairs, int list_format, int level, unsigned dictSize,
 						 int lc, int lp, int pb, int fb)

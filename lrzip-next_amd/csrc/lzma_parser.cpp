@@ -937,7 +937,106 @@ template <int FORMAT> struct BlockEncoder {
 			}
 		rc.finish();
 	}
+
+	// ---- early start: the same loop over lists that arrive in two stages (lzma_enc.h StagedLists) -----------------
+	// run() stays as it is (and keeps its profile); this copy asks for the rest of the lists before a search could
+	// reach a position the early lists do not cover.  A search takes at most kWindow positions, a step skips at most
+	// kLenMax more, and a comparison reads at most kLenMax bytes beyond the position it starts at.
+	static constexpr size_t kStageReach = kWindow + 2 * kLenMax + 64;
+	size_t stage_limit = 0; // positions below it have lists (and bytes); 0 = everything is there
+	const MatchLists *(*stage_rest)(void *) = nullptr;
+	void *stage_ctx = nullptr;
+	bool stage_failed = false;
+	void switch_to_the_rest()
+	{
+		const MatchLists *ml = stage_rest(stage_ctx);
+		stage_limit = 0;
+		if (!ml || ml->packed != (FORMAT == 2) || ml->tail_flags != (FORMAT != 0)) {
+			stage_failed = true;
+			return;
+		}
+		if (held.w) // a list kept for the next search is a view into the old buffer: same offset in the new one
+			held.w = ml->pairs + (held.w - words);
+		counts = ml->counts;
+		words = ml->pairs;
+	}
+	void run_staged()
+	{
+		if (n == 0) {
+			rc.finish();
+			return;
+		}
+		if (stage_limit && kStageReach >= stage_limit)
+			switch_to_the_rest();
+		if (stage_failed)
+			return;
+		(void)take();
+		rc.encode(&model.is_match[0][0], 0);
+		rc.encode_tree<8>(model.literal.data(), data[0]);
+		ahead--;
+		uint32_t pos = 1;
+		if (fetch_pos < n)
+			for (;;) {
+				Step s;
+				if (q_head != q_tail)
+					s = queue[q_head++];
+				else {
+					if (stage_limit && fetch_pos + kStageReach >= stage_limit) {
+						switch_to_the_rest();
+						if (stage_failed)
+							return;
+					}
+					if (greedy)
+						plan_greedy(&s);
+					else
+						plan(pos, &s);
+				}
+				code_step(pos, s);
+				pos += s.len;
+				ahead -= s.len;
+				if (ahead == 0) {
+					if (!greedy && matches_since_refresh >= kRefreshEvery)
+						refresh_all();
+					if (!greedy && rep_lens_until_refresh <= 0) {
+						rep_lens_until_refresh = (int)kRefreshEvery;
+						prices.rep_len.refresh(model.rep_len, prices.bit, 1u << model.pb, nice_len);
+					}
+					if (fetch_pos == n || rc.overflow)
+						break;
+				}
+			}
+		rc.finish();
+	}
 };
+
+template <int FORMAT>
+int encode_staged_with(const LzmaParams &prm, const uint8_t *src, size_t n, const StagedLists &sl, uint8_t *dest, size_t dest_cap, size_t *dest_len)
+{
+	std::unique_ptr<BlockEncoder<FORMAT>> e(new (std::nothrow) BlockEncoder<FORMAT>());
+	if (!e)
+		return LZ_ERROR_MEM;
+	e->data = src;
+	e->n = n;
+	e->counts = sl.early.counts;
+	e->words = sl.early.pairs;
+	e->stage_limit = sl.early_positions < n ? sl.early_positions : 0;
+	e->stage_rest = sl.rest;
+	e->stage_ctx = sl.ctx;
+	if (e->stage_limit == 0 && sl.early_positions < n)
+		e->stage_limit = 1; // (no early positions at all: ask for the rest at once)
+	e->rc.out = dest;
+	e->rc.cap = dest_cap;
+	e->setup(prm);
+	e->run_staged();
+	if (e->stage_failed)
+		return LZ_ERROR_PARAM;
+	if (e->rc.overflow) {
+		*dest_len = dest_cap;
+		return LZ_ERROR_OUTPUT_EOF;
+	}
+	*dest_len = e->rc.len;
+	return LZ_OK;
+}
 
 template <int FORMAT>
 int encode_with(const LzmaParams &prm, const uint8_t *src, size_t n, const MatchLists &ml, uint8_t *dest, size_t dest_cap, size_t *dest_len)
@@ -986,6 +1085,14 @@ int encode_block(const LzmaParams &prm, const uint8_t *src, size_t n, const Matc
 		return encode_with<1>(prm, src, n, ml, dest, dest_cap, dest_len);
 	return encode_with<0>(prm, src, n, ml, dest, dest_cap, dest_len);
 }
+int encode_block_staged(const LzmaParams &prm, const uint8_t *src, size_t n, const StagedLists &sl, uint8_t *dest, size_t dest_cap, size_t *dest_len)
+{
+	if (sl.early.packed)
+		return encode_staged_with<2>(prm, src, n, sl, dest, dest_cap, dest_len);
+	if (sl.early.tail_flags)
+		return encode_staged_with<1>(prm, src, n, sl, dest, dest_cap, dest_len);
+	return encode_staged_with<0>(prm, src, n, sl, dest, dest_cap, dest_len);
+}
 
 } // namespace LZMA_ISA_NS
 } // namespace lrzgpu
@@ -994,6 +1101,7 @@ int encode_block(const LzmaParams &prm, const uint8_t *src, size_t n, const Matc
 namespace lrzgpu {
 namespace isa_v4 {
 int encode_block(const LzmaParams &prm, const uint8_t *src, size_t n, const MatchLists &ml, uint8_t *dest, size_t dest_cap, size_t *dest_len);
+int encode_block_staged(const LzmaParams &prm, const uint8_t *src, size_t n, const StagedLists &sl, uint8_t *dest, size_t dest_cap, size_t *dest_len);
 }
 
 // hash masks the reference derives for a block (LzFind.c:347-373, 432-442): smallest 2^k - 1 covering
@@ -1056,6 +1164,18 @@ int lzma_encode_block(const LzmaParams &prm, const uint8_t *src, size_t n, const
 	static const bool v4 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512bw") &&
 			       __builtin_cpu_supports("avx512dq") && !getenv("LRZGPU_NO_AVX512");
 	return v4 ? isa_v4::encode_block(prm, src, n, ml, dest, dest_cap, dest_len) : isa_v3::encode_block(prm, src, n, ml, dest, dest_cap, dest_len);
+}
+
+int lzma_encode_block_staged(const LzmaParams &prm, const uint8_t *src, size_t n, const StagedLists &sl, uint8_t *dest, size_t dest_cap,
+			     size_t *dest_len)
+{
+	if (prm.lc > 8 || prm.lp > 4 || prm.pb > 4 || prm.lc < 0 || prm.lp < 0 || prm.pb < 0 || (prm.level < 5) != prm.fast || n >= 0xFFFFFFFFu ||
+	    !sl.rest)
+		return LZ_ERROR_PARAM;
+	static const bool v4 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512bw") &&
+			       __builtin_cpu_supports("avx512dq") && !getenv("LRZGPU_NO_AVX512");
+	return v4 ? isa_v4::encode_block_staged(prm, src, n, sl, dest, dest_cap, dest_len)
+		  : isa_v3::encode_block_staged(prm, src, n, sl, dest, dest_cap, dest_len);
 }
 
 } // namespace lrzgpu

@@ -299,3 +299,29 @@ int main()
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout
     assert int(out.stdout.split()[1]) > 100000
+
+
+@pytest.mark.parametrize("level,kind", [(7, "text"), (7, "longrange"), (7, "zeros"), (7, "few"), (5, "phrases"), (3, "text")])
+def test_parser_started_on_a_prefix_of_the_lists(B, O, level, kind):
+    """Early start of a block: the parser begins on the lists of the first positions and asks for
+    the rest when its search could reach beyond them.  The harness behind lrzgpu_lzma_encode_with_lists_staged hides
+    everything from early_positions on (bytes overwritten, lists cut off) until then; the stream must be the
+    reference's LzmaCompress bytes whatever the switch position -- inside a literal run, inside a long match, inside
+    the first search window, at the very start or beyond the end."""
+    import numpy as np
+    n = 300000 if kind != "zeros" else 90000
+    data = datagen.KINDS[kind](n, seed=23)
+    fb = 32 if level < 7 else 64
+    dict_size = {3: 1 << 20, 5: 1 << 24, 7: 1 << 25}[level]
+    if level >= 5:
+        offs, pairs = O.mf_bt4(data, dict_size=dict_size, fb=fb, cut=16 + fb // 2)
+    else:
+        offs, pairs = O.mf_hc5(data, dict_size=dict_size, fb=fb, cut=(16 + fb // 2) // 2)
+    counts = np.diff(offs).astype(np.uint8)
+    rc, want, _ = O.lzma_compress_ref(data, level=level, dict_size=dict_size)
+    assert rc == 0
+    for fmt in ((0, 2) if level >= 5 else (0,)):
+        lists = B.format_lists(data, counts, pairs, fmt)
+        for early in (0, 1, 1000, 2658, 2659, 5000, 77777, n // 2 + 3, n - 3000, n - 1, n, n + 10):
+            rc, got = B.lzma_encode_with_lists_staged(data, counts, lists, early, level=level, dict_size=dict_size, fb=fb, list_format=fmt)
+            assert rc == 0 and got == want, (fmt, early)

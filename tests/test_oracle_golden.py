@@ -151,3 +151,24 @@ def test_lz4_early_verdict_bound(O):
         else:
             assert got == exact, (kind, n, bound, exact, got)
     assert early > 100
+
+
+@pytest.mark.parametrize("kind", ["text", "few", "phrases", "zeros"])
+def test_bt4_lists_are_prefix_computable(O, kind):
+    """What the early start of a block rests on: the BT4 lists of the positions below
+    P - fb depend only on bytes [0, P) -- a bucket's walk visits earlier positions only and compares at most fb bytes.
+    Checked with the restated reference finder: the lists of a prefix equal the lists of the whole block up to there
+    (same dictionary, no larger than the prefix, so that both runs derive the same hash mask)."""
+    import numpy as np
+    import datagen
+    n, fb, dict_size = 1500000, 64, 1 << 19
+    data = datagen.KINDS[kind](n, seed=77)
+    full_offs, full_pairs = O.mf_bt4(data, dict_size=dict_size, fb=fb, cut=16 + fb // 2)
+    for P in (600000, 1048576 + 13):
+        offs, pairs = O.mf_bt4(data[:P], dict_size=dict_size, fb=fb, cut=16 + fb // 2)
+        safe = P - fb  # positions whose fb bytes of look-ahead lie inside the prefix
+        assert np.array_equal(offs[:safe + 1], full_offs[:safe + 1])
+        assert np.array_equal(pairs[:int(offs[safe])], full_pairs[:int(full_offs[safe])])
+        # and the clipping is real: the prefix run's last positions see a shorter look-ahead
+        if kind == "zeros":
+            assert not np.array_equal(pairs[int(offs[P - 8]):int(offs[P - 7])], full_pairs[int(full_offs[P - 8]):int(full_offs[P - 7])])
