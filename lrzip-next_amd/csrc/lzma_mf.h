@@ -32,7 +32,11 @@ int mf_workspace_create(MfWorkspace **out, size_t max_n, double pool_per_pos);
 void mf_workspace_destroy(MfWorkspace *w);
 // mode: 0 plain (len, dist-1) couples; 1 the same with the tail flag in bit 31 of len; 2 one u32 per pair
 // (flag << 31 | (len - 2) << 25 | dist-1, total_entries/2 words; needs dict <= 32 MiB and fb <= 65) -- see k_gather
+// block_n (0 = n): d_src[0..n) is a PREFIX of a block of block_n bytes (the early start of DESIGN.md section 9): the hash
+// mask is derived from the block's size, so the buckets -- and with them every list below n - fb - 4 -- are the ones the
+// whole block will have (tests/test_oracle_golden.py: test_bt4_lists_are_prefix_computable); the lists of the last
+// fb + 4 positions of the prefix are clipped by its end and must not be used.
 int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict, uint32_t fb, uint32_t cut,
-		  hipStream_t s, unsigned long long *total_entries, int mode = 0, bool hc5 = false);
+		  hipStream_t s, unsigned long long *total_entries, int mode = 0, bool hc5 = false, size_t block_n = 0);
 
 } // namespace lrzgpu

@@ -1230,8 +1230,9 @@ static inline int grid_for(size_t n, int block) // ~8 blocks per CU, grid-stride
 // Runs the finder on d_src[0..n) (device). Results stay on the device in w->counts / w->pool_out;
 // *total_entries receives the number of u32 entries.
 int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict, uint32_t fb, uint32_t cut,
-		  hipStream_t s, unsigned long long *total_entries, int mode, bool hc5)
+		  hipStream_t s, unsigned long long *total_entries, int mode, bool hc5, size_t block_n)
 {
+	const size_t mask_n = block_n > n ? block_n : n; // the size the reference's finder would be created for
 	if (mode < 0 || mode > 2 || (mode == 2 && (dict > (1u << 25) || fb > 65)))
 		return -3;
 	if (n > w->max_n || n >= 0xFFFFFFF0ull)
@@ -1274,7 +1275,7 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 			return -3;
 		if (n >= 5) {
 			const uint32_t n5 = (uint32_t)(n - 4);
-			const uint32_t mask = lzma_hash_mask5(dict, n);
+			const uint32_t mask = lzma_hash_mask5(dict, mask_n);
 			const int bits = 32 - __builtin_clz(mask);
 			size_t tb;
 			const int g = grid_for(n5, 256);
@@ -1298,7 +1299,7 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 		}
 	} else if (n >= 4) {
 		const uint32_t n4 = (uint32_t)(n - 3);
-		const uint32_t mask = lzma_hash_mask(dict, n);
+		const uint32_t mask = lzma_hash_mask(dict, mask_n);
 		const int big = mask >= 0xFFFFFF;
 		int bits = 32 - __builtin_clz(mask);
 		size_t tb;
