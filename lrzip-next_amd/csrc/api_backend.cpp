@@ -297,7 +297,8 @@ struct StagedHarness {
 
 extern "C" int lrzgpu_lzma_encode_with_lists_staged(unsigned char *dest, size_t *destLen, const unsigned char *src, size_t srcLen,
 						    const uint8_t *counts, const uint32_t *pairs, size_t early_positions, int list_format,
-						    int level, unsigned dictSize, int lc, int lp, int pb, int fb)
+						    int level, unsigned dictSize, int lc, int lp, int pb, int fb,
+						    const uint8_t *early_counts, const uint32_t *early_pairs)
 {
 	if (list_format < 0 || list_format > 2 || !dest || !destLen || (!src && srcLen) || !counts || !pairs)
 		return LZ_ERROR_PARAM;
@@ -322,13 +323,16 @@ extern "C" int lrzgpu_lzma_encode_with_lists_staged(unsigned char *dest, size_t 
 		h.full.pairs = pairs;
 		h.full.tail_flags = list_format != 0;
 		h.full.packed = list_format == 2;
-		// the early stage's own arrays: the lists of the first `early` positions, nothing behind them
-		std::vector<uint8_t> ec(counts, counts + h.early);
+		// the early stage's own arrays: the lists of the first `early` positions -- the caller's (a finder run on a
+		// prefix of the block) or the whole block's --, nothing behind them
+		const uint8_t *c0 = early_counts ? early_counts : counts;
+		const uint32_t *p0 = early_pairs ? early_pairs : pairs;
+		std::vector<uint8_t> ec(c0, c0 + h.early);
 		uint64_t entries = 0;
 		for (size_t i = 0; i < h.early; i++)
-			entries += counts[i];
+			entries += c0[i];
 		const size_t words = (size_t)(list_format == 2 ? entries / 2 : entries);
-		std::vector<uint32_t> ep(pairs, pairs + words);
+		std::vector<uint32_t> ep(p0, p0 + words);
 		ec.resize(srcLen + 16, 0xFE); // (what a run-away reader would take for long lists)
 		ep.resize(words + 4096, 0x7FFFFFFFu);
 		StagedLists sl;

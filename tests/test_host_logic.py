@@ -325,3 +325,28 @@ def test_parser_started_on_a_prefix_of_the_lists(B, O, level, kind):
         for early in (0, 1, 1000, 2658, 2659, 5000, 77777, n // 2 + 3, n - 3000, n - 1, n, n + 10):
             rc, got = B.lzma_encode_with_lists_staged(data, counts, lists, early, level=level, dict_size=dict_size, fb=fb, list_format=fmt)
             assert rc == 0 and got == want, (fmt, early)
+
+
+@pytest.mark.parametrize("kind", ["text", "few", "phrases"])
+def test_parser_started_on_the_lists_of_a_prefix_run(B, O, kind):
+    """The early start end to end on the host: the early lists come from a finder that saw only a PREFIX of the block
+    (the restated reference finder on data[:P], tail flags computed on that prefix too), are used below P - fb - 4, and
+    the whole block's lists take over from there.  Reference LzmaCompress bytes.  (The dictionary is no larger than
+    the prefix so that the oracle finder derives the block's hash mask for it; the GPU finder takes the block size as
+    a parameter.)"""
+    import numpy as np
+    n, fb, dict_size, level = 1200000, 64, 1 << 19, 7
+    data = datagen.KINDS[kind](n, seed=29)
+    offs, pairs = O.mf_bt4(data, dict_size=dict_size, fb=fb, cut=16 + fb // 2)
+    counts = np.diff(offs).astype(np.uint8)
+    rc, want, _ = O.lzma_compress_ref(data, level=level, dict_size=dict_size)
+    assert rc == 0
+    for P in (700000, 1048576 + 5):
+        poffs, ppairs = O.mf_bt4(data[:P], dict_size=dict_size, fb=fb, cut=16 + fb // 2)
+        pcounts = np.diff(poffs).astype(np.uint8)
+        for fmt in (0, 2):
+            lists = B.format_lists(data, counts, pairs, fmt)
+            plists = B.format_lists(data[:P], pcounts, ppairs, fmt)
+            rc, got = B.lzma_encode_with_lists_staged(data, counts, lists, P - fb - 4, level=level, dict_size=dict_size, fb=fb,
+                                                      list_format=fmt, early_counts=pcounts, early_pairs=plists)
+            assert rc == 0 and got == want, (P, fmt)
