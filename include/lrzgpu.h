@@ -279,6 +279,11 @@ int lrzgpu_LzmaCompress(unsigned char *dest, size_t *destLen, const unsigned cha
  * position i; pairs = (len, dist-1) couples of position 0, 1, ... ; returns total entries or <0. */
 int64_t lrzgpu_lzma_match_lists(const uint8_t *src, size_t n, uint32_t dictSize, unsigned fb, unsigned cutValue,
 				uint8_t *counts, uint32_t *pairs, size_t pairs_cap, int device);
+/* The BT4 finder on a PREFIX src[0..n) of a block of block_n bytes (the early start of a block): the
+ * hash mask is the block's, so the lists of the positions below n - fb - 4 are the whole block's; the last fb + 4
+ * positions' lists are clipped by the end of the prefix and must not be used. */
+int64_t lrzgpu_lzma_match_lists_prefix(const uint8_t *src, size_t n, size_t block_n, uint32_t dictSize, unsigned fb,
+				       unsigned cutValue, uint8_t *counts, uint32_t *pairs, size_t pairs_cap, int device);
 /* Same for the hash-chain finder of levels 1..4: the lists Hc5_MatchFinder_GetMatches
  * (src/lzma/C/LzFind.c:1431-1502) returns position by position. */
 int64_t lrzgpu_lzma_match_lists_hc5(const uint8_t *src, size_t n, uint32_t dictSize, unsigned fb, unsigned cutValue,

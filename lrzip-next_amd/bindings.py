@@ -292,6 +292,22 @@ def lzma_match_lists(data: bytes, dict_size=1 << 25, fb=64, cut=48, device=0, pe
     return counts[:n], pairs[:total]
 
 
+def lzma_match_lists_prefix(data: bytes, block_n, dict_size=1 << 25, fb=64, cut=48, device=0, per_pos=16):
+    """lrzgpu_lzma_match_lists_prefix: the BT4 finder on a prefix of a block of block_n bytes (hash mask of the block)."""
+    import numpy as np
+    n = len(data)
+    counts = np.zeros(max(n, 1), dtype=np.uint8)
+    cap = n * per_pos + 4096
+    pairs = np.zeros(cap, dtype=np.uint32)
+    f = lib().lrzgpu_lzma_match_lists_prefix
+    f.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    f.restype = C.c_int64
+    total = f(data, n, block_n, dict_size, fb, cut, counts.ctypes.data, pairs.ctypes.data, cap, device)
+    if total < 0:
+        raise RuntimeError("lrzgpu_lzma_match_lists_prefix rc=%d" % total)
+    return counts[:n], pairs[:total]
+
+
 def lzma_match_lists_hc5(data: bytes, dict_size=1 << 22, fb=32, cut=16, device=0, per_pos=40):
     import numpy as np
     n = len(data)

@@ -157,7 +157,7 @@ static int lz4_size_host(const uint8_t *src, int src_size, int dst_capacity, int
 // ---- LZMA: src/lzma/include/LzmaLib.h:95-112 --------------------------------------------------
 
 static int64_t match_lists_impl(const uint8_t *src, size_t n, uint32_t dictSize, unsigned fb, unsigned cutValue,
-				uint8_t *counts, uint32_t *pairs, size_t pairs_cap, int device, bool hc5)
+				uint8_t *counts, uint32_t *pairs, size_t pairs_cap, int device, bool hc5, size_t block_n = 0)
 {
 	int rc = select_device(device);
 	if (rc)
@@ -175,7 +175,7 @@ static int64_t match_lists_impl(const uint8_t *src, size_t n, uint32_t dictSize,
 		ret = LRZGPU_E_NOMEM;
 	else if (n == 0 || hipMemcpy(tb.block.p, src, n, hipMemcpyHostToDevice) == hipSuccess) {
 		const uint8_t *d_src = tb.block.p;
-		int r = mf_run_device(w, d_src, n, dictSize, fb, cutValue, 0, &total, 0, hc5);
+		int r = mf_run_device(w, d_src, n, dictSize, fb, cutValue, 0, &total, 0, hc5, block_n);
 		if (r == 0) {
 			if (total > pairs_cap)
 				ret = LRZGPU_E_NOMEM;
@@ -193,6 +193,14 @@ extern "C" int64_t lrzgpu_lzma_match_lists(const uint8_t *src, size_t n, uint32_
 					   uint8_t *counts, uint32_t *pairs, size_t pairs_cap, int device)
 {
 	return match_lists_impl(src, n, dictSize, fb, cutValue, counts, pairs, pairs_cap, device, false);
+}
+
+extern "C" int64_t lrzgpu_lzma_match_lists_prefix(const uint8_t *src, size_t n, size_t block_n, uint32_t dictSize, unsigned fb,
+						  unsigned cutValue, uint8_t *counts, uint32_t *pairs, size_t pairs_cap, int device)
+{
+	if (block_n < n)
+		return LRZGPU_E_PARAM;
+	return match_lists_impl(src, n, dictSize, fb, cutValue, counts, pairs, pairs_cap, device, false, block_n);
 }
 
 extern "C" int64_t lrzgpu_lzma_match_lists_hc5(const uint8_t *src, size_t n, uint32_t dictSize, unsigned fb, unsigned cutValue,
