@@ -316,16 +316,17 @@ int lrzgpu_lzma_encode_with_lists_fmt(unsigned char *dest, size_t *destLen, cons
 				      const uint8_t *counts, const uint32_t *pairs, int list_format, int level,
 				      unsigned dictSize, int lc, int lp, int pb, int fb);
 
-/* The same on lists that arrive in two stages -- the early start of a block whose tail is still being scanned
- * (csrc/lzma_enc.h StagedLists is the in-library interface).  This entry is its host-only
- * harness: the encoder runs on a private copy of src[] whose bytes from early_positions on are overwritten and on
- * lists cut off there until it asks for the rest; the stream must equal lrzgpu_lzma_encode_with_lists_fmt()'s.
+/* The same on lists that arrive in stages -- the early start of a block whose tail is still being scanned
+ * (csrc/lzma_enc.h StagedLists is the in-library interface, the whole-file driver its user).
+ * This entry is its host-only harness: the encoder runs on a private copy of src[] whose bytes from the current limit
+ * on are overwritten and on lists cut off there; each time it asks for more, stage_step further positions are
+ * revealed (0 = everything that is left, in one piece); the stream must equal lrzgpu_lzma_encode_with_lists_fmt()'s.
  * early_counts / early_pairs (may be NULL: the whole block's lists are used) = the lists of the first
  * early_positions positions as a finder run on a prefix of the block produced them. */
 int lrzgpu_lzma_encode_with_lists_staged(unsigned char *dest, size_t *destLen, const unsigned char *src, size_t srcLen,
 					 const uint8_t *counts, const uint32_t *pairs, size_t early_positions, int list_format,
 					 int level, unsigned dictSize, int lc, int lp, int pb, int fb,
-					 const uint8_t *early_counts, const uint32_t *early_pairs);
+					 const uint8_t *early_counts, const uint32_t *early_pairs, size_t stage_step);
 
 /* ---- host-only pieces of the stream layer (usable without a device) ----------------------------
  * lrzgpu_plan: the sizing open_stream_out()/rzip_fd() derive before the first chunk

@@ -378,8 +378,9 @@ def lzma_encode_with_lists(data: bytes, counts, pairs, level=7, dict_size=1 << 2
 
 
 def lzma_encode_with_lists_staged(data: bytes, counts, pairs, early_positions, level=7, dict_size=1 << 25, fb=64, lc=3, lp=0, pb=2,
-                                  cap=None, list_format=0, early_counts=None, early_pairs=None):
-    """lrzgpu_lzma_encode_with_lists_staged: the parser started on the lists of the first early_positions positions."""
+                                  cap=None, list_format=0, early_counts=None, early_pairs=None, stage_step=0):
+    """lrzgpu_lzma_encode_with_lists_staged: the parser started on the lists of the first early_positions positions,
+    handed stage_step more every time it asks (0 = the rest in one piece)."""
     import numpy as np
     n = len(data)
     if cap is None:
@@ -394,7 +395,7 @@ def lzma_encode_with_lists_staged(data: bytes, counts, pairs, early_positions, l
         pairs = np.zeros(1, dtype=np.uint32)
     f = lib().lrzgpu_lzma_encode_with_lists_staged
     f.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
-                  C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+                  C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
     f.restype = C.c_int
     ec = ep = None
     if early_counts is not None:
@@ -404,7 +405,7 @@ def lzma_encode_with_lists_staged(data: bytes, counts, pairs, early_positions, l
             ep = np.zeros(1, dtype=np.uint32)
         assert ec.size >= min(early_positions, n)
     rc = f(dst, C.byref(dlen), data, n, counts.ctypes.data, pairs.ctypes.data, early_positions, list_format, level, dict_size, lc, lp, pb, fb,
-           ec.ctypes.data if ec is not None else None, ep.ctypes.data if ep is not None else None)
+           ec.ctypes.data if ec is not None else None, ep.ctypes.data if ep is not None else None, stage_step)
     return rc, dst.raw[:dlen.value]
 
 

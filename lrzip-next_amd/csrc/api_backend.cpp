@@ -281,24 +281,40 @@ extern "C" int lrzgpu_lzma_mf_next_block(lrzgpu_mf *m, uint32_t *d, size_t cap_u
 
 extern "C" void lrzgpu_lzma_mf_close(lrzgpu_mf *m) { delete m; }
 
-// The parser on lists that arrive in two stages (lzma_enc.h StagedLists; DESIGN.md section 9 "early start").  This
+// The parser on lists that arrive in stages (lzma_enc.h StagedLists; DESIGN.md section 5 "early start").  This
 // host-only entry is the harness of that path: it runs the encoder on a PRIVATE copy of the block whose bytes from
-// early_positions on are 0xA5 and on early lists cut off at early_positions until the parser asks for the rest --
-// an encoder that looked beyond what the early stage covers would not produce the whole-block stream.
+// the current limit on are 0xA5 and on lists cut off at that limit; every time the parser asks for more, stage_step
+// further positions (0 = all that is left) are revealed in place -- an encoder that looked beyond what a stage
+// covers would not produce the whole-block stream.
 namespace {
 struct StagedHarness {
 	std::vector<uint8_t> block;
+	std::vector<uint8_t> ec;
+	std::vector<uint32_t> ep;
 	const unsigned char *src;
-	size_t n, early;
-	MatchLists full;
+	const uint8_t *counts;
+	const uint32_t *pairs;
+	size_t n, limit, step, words_done;
+	int fmt;
+	MatchLists ml;
 	int calls = 0;
-	static const MatchLists *rest(void *ctx)
+	static const MatchLists *rest(void *ctx, size_t *valid)
 	{
 		StagedHarness *h = (StagedHarness *)ctx;
 		h->calls++;
-		if (h->early < h->n)
-			memcpy(h->block.data() + h->early, h->src + h->early, h->n - h->early);
-		return &h->full;
+		const size_t next = (h->step == 0 || h->limit + h->step > h->n) ? h->n : h->limit + h->step;
+		memcpy(h->block.data() + h->limit, h->src + h->limit, next - h->limit);
+		uint64_t before = 0, entries = 0;
+		for (size_t i = 0; i < h->limit; i++)
+			before += h->counts[i];
+		for (size_t i = h->limit; i < next; i++)
+			entries += h->counts[i];
+		const size_t w0 = (size_t)(h->fmt == 2 ? before / 2 : before), w = (size_t)(h->fmt == 2 ? entries / 2 : entries);
+		memcpy(h->ec.data() + h->limit, h->counts + h->limit, next - h->limit);
+		memcpy(h->ep.data() + w0, h->pairs + w0, w * 4);
+		h->limit = next;
+		*valid = next;
+		return &h->ml;
 	}
 };
 } // namespace
@@ -306,7 +322,7 @@ struct StagedHarness {
 extern "C" int lrzgpu_lzma_encode_with_lists_staged(unsigned char *dest, size_t *destLen, const unsigned char *src, size_t srcLen,
 						    const uint8_t *counts, const uint32_t *pairs, size_t early_positions, int list_format,
 						    int level, unsigned dictSize, int lc, int lp, int pb, int fb,
-						    const uint8_t *early_counts, const uint32_t *early_pairs)
+						    const uint8_t *early_counts, const uint32_t *early_pairs, size_t stage_step)
 {
 	if (list_format < 0 || list_format > 2 || !dest || !destLen || (!src && srcLen) || !counts || !pairs)
 		return LZ_ERROR_PARAM;
@@ -323,38 +339,43 @@ extern "C" int lrzgpu_lzma_encode_with_lists_staged(unsigned char *dest, size_t 
 	try {
 		StagedHarness h;
 		h.src = src;
+		h.counts = counts;
+		h.pairs = pairs;
 		h.n = srcLen;
-		h.early = early_positions < srcLen ? early_positions : srcLen;
-		h.block.assign(src, src + h.early);
+		h.step = stage_step;
+		h.fmt = list_format;
+		h.limit = early_positions < srcLen ? early_positions : srcLen;
+		h.block.assign(src, src + h.limit);
 		h.block.resize(srcLen + 16, 0xA5);
-		h.full.counts = counts;
-		h.full.pairs = pairs;
-		h.full.tail_flags = list_format != 0;
-		h.full.packed = list_format == 2;
 		// the early stage's own arrays: the lists of the first `early` positions -- the caller's (a finder run on a
 		// prefix of the block) or the whole block's --, nothing behind them
 		const uint8_t *c0 = early_counts ? early_counts : counts;
 		const uint32_t *p0 = early_pairs ? early_pairs : pairs;
-		std::vector<uint8_t> ec(c0, c0 + h.early);
-		uint64_t entries = 0;
-		for (size_t i = 0; i < h.early; i++)
+		uint64_t entries = 0, all = 0;
+		for (size_t i = 0; i < h.limit; i++)
 			entries += c0[i];
+		for (size_t i = 0; i < srcLen; i++)
+			all += counts[i];
 		const size_t words = (size_t)(list_format == 2 ? entries / 2 : entries);
-		std::vector<uint32_t> ep(p0, p0 + words);
-		ec.resize(srcLen + 16, 0xFE); // (what a run-away reader would take for long lists)
-		ep.resize(words + 4096, 0x7FFFFFFFu);
+		h.ec.assign(c0, c0 + h.limit);
+		h.ep.assign(p0, p0 + words);
+		h.ec.resize(srcLen + 16, 0xFE); // (what a run-away reader would take for long lists)
+		h.ep.resize((size_t)(list_format == 2 ? all / 2 : all) + 4096, 0x7FFFFFFFu);
+		h.ml.counts = h.ec.data();
+		h.ml.pairs = h.ep.data();
+		h.ml.tail_flags = list_format != 0;
+		h.ml.packed = list_format == 2;
 		StagedLists sl;
-		sl.early = h.full;
-		sl.early.counts = ec.data();
-		sl.early.pairs = ep.data();
-		sl.early_positions = h.early;
+		sl.early = h.ml;
+		sl.early_positions = h.limit;
 		sl.rest = &StagedHarness::rest;
 		sl.ctx = &h;
 		size_t out_len = 0;
+		const size_t first = h.limit;
 		const int r = lzma_encode_block_staged(p, h.block.data(), srcLen, sl, dest, *destLen, &out_len);
 		*destLen = out_len;
-		if (r == LZ_OK && h.early < srcLen && h.calls != 1)
-			return LZ_ERROR_PARAM; // the rest must have been asked for, once
+		if (r == LZ_OK && first < srcLen && (h.limit != srcLen || (stage_step == 0 && h.calls != 1)))
+			return LZ_ERROR_PARAM; // the rest must have been asked for (once, when it comes in one piece)
 		return r;
 	} catch (...) {
 		return LZ_ERROR_MEM;

@@ -43,16 +43,18 @@ enum : int { LZ_OK = 0, LZ_ERROR_MEM = 2, LZ_ERROR_PARAM = 5, LZ_ERROR_OUTPUT_EO
 int lzma_encode_block(const LzmaParams &prm, const uint8_t *src, size_t n, const MatchLists &ml,
 		      uint8_t *dest, size_t dest_cap, size_t *dest_len);
 
-// Early start of a block: the parser begins on the lists of the block's first positions while the
-// rest of the block is still being scanned.  `early` is valid for positions < early_positions (the finder ran on a
-// prefix: lists below its end - fb equal the whole block's), src[] for bytes < early_positions; `rest(ctx)` is called
-// once, from the encoding thread, when the parse comes within reach of that limit (one search window + two maximal
-// match lengths): it waits for the whole block and returns its lists (same format, positions from 0; src[] complete).
-// Same bytes out as lzma_encode_block() on the whole block's lists.
+// Early start of a block: the parser begins on the lists of the block's first positions while
+// the rest of the block is still being scanned, and is handed more in stages.  `early` is valid for positions <
+// early_positions (the finder ran on a prefix: lists below its end - fb - 4 equal the whole block's), src[] for bytes
+// below the prefix's end.  `rest(ctx, &valid)` is called from the encoding thread whenever the parse comes within reach of
+// the current limit (one search window + two maximal match lengths): it blocks until the producer has more and returns
+// the lists (same format, positions from 0; the same arrays extended, or new ones) with *valid = the new limit, the
+// block's length once everything is there; nullptr withdraws the block (LZ_ERROR_PARAM is returned, nothing of dest is
+// meaningful).  Same bytes out as lzma_encode_block() on the whole block's lists.
 struct StagedLists {
 	MatchLists early;
 	size_t early_positions = 0;
-	const MatchLists *(*rest)(void *ctx) = nullptr;
+	const MatchLists *(*rest)(void *ctx, size_t *valid_positions) = nullptr;
 	void *ctx = nullptr;
 };
 int lzma_encode_block_staged(const LzmaParams &prm, const uint8_t *src, size_t n, const StagedLists &sl,

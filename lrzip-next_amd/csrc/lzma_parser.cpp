@@ -896,12 +896,44 @@ template <int FORMAT> struct BlockEncoder {
 		prices.rep_len.refresh(model.rep_len, prices.bit, 1u << model.pb, nice_len);
 	}
 
+	// ---- lists that arrive in stages (lzma_enc.h StagedLists; the early start of a block) --------
+	// The parse may begin while the finder has covered only a prefix of the block: positions below stage_limit have
+	// lists (and the block's bytes are there up to the limit).  A search takes at most kWindow positions, a step skips
+	// at most kLenMax more, and a comparison reads at most kLenMax bytes beyond the position it starts at: before a
+	// search could come within kStageReach of the limit the producer is asked for more (it blocks until it has more).
+	static constexpr size_t kStageReach = kWindow + 2 * kLenMax + 64;
+	size_t stage_limit = 0; // 0 = everything is there
+	size_t stage_have = 0;  // what the producer said last
+	const MatchLists *(*stage_rest)(void *, size_t *) = nullptr;
+	void *stage_ctx = nullptr;
+	bool stage_failed = false;
+	void more_lists()
+	{
+		while (stage_limit && fetch_pos + kStageReach >= stage_limit) {
+			size_t valid = 0;
+			const MatchLists *ml = stage_rest ? stage_rest(stage_ctx, &valid) : nullptr;
+			if (!ml || ml->packed != (FORMAT == 2) || ml->tail_flags != (FORMAT != 0) || (valid < n && valid <= stage_have)) {
+				stage_failed = true; // the block was withdrawn (or the producer made no progress)
+				return;
+			}
+			if (held.w) // a list kept for the next search is a view into the old arrays: same offset in the new ones
+				held.w = ml->pairs + (held.w - words);
+			counts = ml->counts;
+			words = ml->pairs;
+			stage_have = valid;
+			stage_limit = valid < n ? (valid ? valid : 1) : 0;
+		}
+	}
+
 	void run()
 	{
 		if (n == 0) {
 			rc.finish();
 			return;
 		}
+		more_lists();
+		if (stage_failed)
+			return;
 		// the first byte has no context and no history: always a plain literal
 		(void)take();
 		rc.encode(&model.is_match[0][0], 0);
@@ -913,11 +945,18 @@ template <int FORMAT> struct BlockEncoder {
 				Step s;
 				if (q_head != q_tail)
 					s = queue[q_head++];
-				else if (greedy)
-					plan_greedy(&s);
 				else {
-					LAP(8);
-					plan(pos, &s);
+					if (__builtin_expect(stage_limit != 0, 0)) {
+						more_lists();
+						if (stage_failed)
+							return;
+					}
+					if (greedy)
+						plan_greedy(&s);
+					else {
+						LAP(8);
+						plan(pos, &s);
+					}
 				}
 				code_step(pos, s);
 				pos += s.len;
@@ -937,76 +976,6 @@ template <int FORMAT> struct BlockEncoder {
 			}
 		rc.finish();
 	}
-
-	// ---- early start: the same loop over lists that arrive in two stages (lzma_enc.h StagedLists) -----------------
-	// run() stays as it is (and keeps its profile); this copy asks for the rest of the lists before a search could
-	// reach a position the early lists do not cover.  A search takes at most kWindow positions, a step skips at most
-	// kLenMax more, and a comparison reads at most kLenMax bytes beyond the position it starts at.
-	static constexpr size_t kStageReach = kWindow + 2 * kLenMax + 64;
-	size_t stage_limit = 0; // positions below it have lists (and bytes); 0 = everything is there
-	const MatchLists *(*stage_rest)(void *) = nullptr;
-	void *stage_ctx = nullptr;
-	bool stage_failed = false;
-	void switch_to_the_rest()
-	{
-		const MatchLists *ml = stage_rest(stage_ctx);
-		stage_limit = 0;
-		if (!ml || ml->packed != (FORMAT == 2) || ml->tail_flags != (FORMAT != 0)) {
-			stage_failed = true;
-			return;
-		}
-		if (held.w) // a list kept for the next search is a view into the old buffer: same offset in the new one
-			held.w = ml->pairs + (held.w - words);
-		counts = ml->counts;
-		words = ml->pairs;
-	}
-	void run_staged()
-	{
-		if (n == 0) {
-			rc.finish();
-			return;
-		}
-		if (stage_limit && kStageReach >= stage_limit)
-			switch_to_the_rest();
-		if (stage_failed)
-			return;
-		(void)take();
-		rc.encode(&model.is_match[0][0], 0);
-		rc.encode_tree<8>(model.literal.data(), data[0]);
-		ahead--;
-		uint32_t pos = 1;
-		if (fetch_pos < n)
-			for (;;) {
-				Step s;
-				if (q_head != q_tail)
-					s = queue[q_head++];
-				else {
-					if (stage_limit && fetch_pos + kStageReach >= stage_limit) {
-						switch_to_the_rest();
-						if (stage_failed)
-							return;
-					}
-					if (greedy)
-						plan_greedy(&s);
-					else
-						plan(pos, &s);
-				}
-				code_step(pos, s);
-				pos += s.len;
-				ahead -= s.len;
-				if (ahead == 0) {
-					if (!greedy && matches_since_refresh >= kRefreshEvery)
-						refresh_all();
-					if (!greedy && rep_lens_until_refresh <= 0) {
-						rep_lens_until_refresh = (int)kRefreshEvery;
-						prices.rep_len.refresh(model.rep_len, prices.bit, 1u << model.pb, nice_len);
-					}
-					if (fetch_pos == n || rc.overflow)
-						break;
-				}
-			}
-		rc.finish();
-	}
 };
 
 template <int FORMAT>
@@ -1019,15 +988,14 @@ int encode_staged_with(const LzmaParams &prm, const uint8_t *src, size_t n, cons
 	e->n = n;
 	e->counts = sl.early.counts;
 	e->words = sl.early.pairs;
-	e->stage_limit = sl.early_positions < n ? sl.early_positions : 0;
+	e->stage_limit = sl.early_positions < n ? (sl.early_positions ? sl.early_positions : 1) : 0; // (1: ask at once)
+	e->stage_have = sl.early_positions;
 	e->stage_rest = sl.rest;
 	e->stage_ctx = sl.ctx;
-	if (e->stage_limit == 0 && sl.early_positions < n)
-		e->stage_limit = 1; // (no early positions at all: ask for the rest at once)
 	e->rc.out = dest;
 	e->rc.cap = dest_cap;
 	e->setup(prm);
-	e->run_staged();
+	e->run();
 	if (e->stage_failed)
 		return LZ_ERROR_PARAM;
 	if (e->rc.overflow) {

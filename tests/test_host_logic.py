@@ -303,7 +303,7 @@ int main()
 
 @pytest.mark.parametrize("level,kind", [(7, "text"), (7, "longrange"), (7, "zeros"), (7, "few"), (5, "phrases"), (3, "text")])
 def test_parser_started_on_a_prefix_of_the_lists(B, O, level, kind):
-    """Early start of a block (DESIGN section 9): the parser begins on the lists of the first positions and asks for
+    """Early start of a block (DESIGN section 5): the parser begins on the lists of the first positions and asks for
     the rest when its search could reach beyond them.  The harness behind lrzgpu_lzma_encode_with_lists_staged hides
     everything from early_positions on (bytes overwritten, lists cut off) until then; the stream must be the
     reference's LzmaCompress bytes whatever the switch position -- inside a literal run, inside a long match, inside
@@ -325,6 +325,12 @@ def test_parser_started_on_a_prefix_of_the_lists(B, O, level, kind):
         for early in (0, 1, 1000, 2658, 2659, 5000, 77777, n // 2 + 3, n - 3000, n - 1, n, n + 10):
             rc, got = B.lzma_encode_with_lists_staged(data, counts, lists, early, level=level, dict_size=dict_size, fb=fb, list_format=fmt)
             assert rc == 0 and got == want, (fmt, early)
+        # many stages (the whole-file driver hands a block over piece by piece while its scan runs): steps shorter than
+        # the parser's reach (several requests before one search), of the reach, and long ones
+        for early, step in ((0, 1), (1000, 700), (5000, 2659), (3, 4096), (20000, 50001), (n // 2, 65536)):
+            rc, got = B.lzma_encode_with_lists_staged(data, counts, lists, early, level=level, dict_size=dict_size, fb=fb, list_format=fmt,
+                                                      stage_step=step)
+            assert rc == 0 and got == want, (fmt, early, step)
 
 
 @pytest.mark.parametrize("kind", ["text", "few", "phrases"])
