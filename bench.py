@@ -60,7 +60,7 @@ class Profile(C.Structure):
                 ("long_compare_launches", C.c_int64), ("long_compare_bytes", C.c_int64), ("spec_rollbacks", C.c_int64),
                 ("spec_cancelled_blocks", C.c_int64), ("victim_rescans", C.c_int64),
                 ("union_ms", C.c_double * 8), ("peak_concurrency", C.c_double * 8),
-                ("pipeline_s", C.c_double * 8), ("mf_wave_dbg", C.c_int64 * 4)]
+                ("pipeline_s", C.c_double * 8), ("mf_wave_dbg", C.c_int64 * 4), ("early_s", C.c_double * 4)]
 
 
 ALPHABETS = {
@@ -553,6 +553,10 @@ def main():
                          "encoders_busy_s_per_step": round(pl[0], 1), "encoders_idle_s_per_step": round(pl[1], 1),
                          "finder_workers_busy_s_per_step": round(pl[2], 1), "lists_d2h_s_per_step": round(pl[3], 1),
                          "last_finder_done_s": round(pl[5], 2), "last_encode_done_s": round(pl[6], 2),
+                         "first_encoder_start_s": round(prof.early_s[0] / steps, 2),
+                         "early_start": {"blocks_started_before_complete_per_step": round(prof.early_s[2] / steps, 1),
+                                         "finder_runs_on_their_prefixes_per_step": round(prof.early_s[3] / steps, 1),
+                                         "encoder_s_waiting_inside_a_started_block_per_step": round(prof.early_s[1] / steps, 1)},
                          "note": "a stage's figure is the time it needs on its own resources (busy seconds / workers; the scans "
                                  "run unthrottled from t = 0); the step cannot be shorter than the largest.  The finder "
                                  "workers are throttled by the encoders (a bounded number of blocks hold lists in host "

@@ -377,6 +377,11 @@ typedef struct lrzgpu_profile {
 	 * ended (4-6: since the start of their run), 7 wall time of the runs */
 	double pipeline_s[8];
 	int64_t mf_wave_dbg[4];       /* k_bt_wave: rounds of all waves, node visits, rounds walks waited for a son, positions */
+	/* early start of blocks (the encoder follows the finder through a block that is still being scanned), summed over
+	 * the runs since the reset: 0 when the first encoder started (seconds since the start of its run), 1 encoder seconds
+	 * spent waiting for the next part of a started block (counted in pipeline_s[1] too), 2 blocks started early,
+	 * 3 finder runs on their prefixes */
+	double early_s[4];
 } lrzgpu_profile;
 void lrzgpu_profile_reset(void);
 void lrzgpu_profile_get(lrzgpu_profile *out);

@@ -49,6 +49,7 @@
 #include <deque>
 #include <functional>
 #include <map>
+#include <set>
 #include <memory>
 #include <string>
 #include <mutex>
@@ -321,6 +322,26 @@ struct Job {
 	bool dispatched = false;
 	bool finished = false;
 	std::atomic<bool> cancelled{false};
+	// ---- early start: the block goes to an encoder before all of it exists.  The finder runs on
+	// growing PREFIXES of the block (lists below prefix - fb - 4 are the whole block's: lzma_mf.h block_n), bytes and
+	// lists land in the same host arrays stage by stage, the encoder follows through StagedLists::rest.  Guarded by
+	// Pipeline::mu.
+	bool early = false;
+	bool queued = false;         // sits in gpu_queue
+	bool in_gpu = false;         // a GPU worker is running a stage of it
+	bool held_slot = false;      // counted in Pipeline::held
+	bool enc_offered = false;    // sits in enc_queue or is with an encoder: the host side finishes it
+	bool with_encoder = false;
+	bool retiring = false;       // its encoder is done with it: no further stage
+	bool full_requested = false; // the scan has completed the block: the next finder run is the last
+	bool full_ready = false;     // whole-block lists and bytes on the host, gate agreed
+	bool refused = false;        // the gate said no after an optimistic start: stored
+	int64_t stage_want = 0;      // bytes of the block gathered so far
+	int64_t stage_done = 0;      // prefix the last finished finder run covered
+	int64_t valid = 0;           // positions whose lists on the host are final
+	int64_t bytes_copied = 0;    // host copy of the block's bytes
+	uint64_t words_at_valid = 0; // words of pairs[] in front of position `valid`
+	std::vector<std::unique_ptr<RawBuf<uint32_t>>> old_pairs; // outgrown list arrays an encoder may still read
 	// data
 	RawBuf<uint8_t> bytes;
 	RawBuf<uint8_t> counts;
@@ -349,6 +370,7 @@ struct Pipeline {
 
 	std::mutex mu;
 	std::condition_variable cv_jobs, cv_enc, cv_done;
+	std::condition_variable cv_rest; // early jobs: a stage arrived / the gate spoke / a worker left the job / cancelled
 	std::deque<Job *> gpu_queue; // blocks waiting for a GPU worker
 	std::deque<Job *> enc_queue; // blocks with match lists and a positive gate, waiting for a host encoder
 	size_t held = 0;             // blocks holding host match lists (bounds host memory)
@@ -357,11 +379,98 @@ struct Pipeline {
 	double t_last_mf = 0, t_last_enc = 0;
 	double mf_busy = 0, d2h_busy = 0, blk_busy = 0, enc_busy = 0, enc_wait = 0;
 	std::vector<std::thread> threads;
+	// early start
+	int early_mode = 1;         // 0 off, 1 while encoders have nothing to do, 2 every block (LRZGPU_EARLY_START; tests force 2)
+	int64_t early_first = 0;    // bytes of a block that must be there before its first finder run
+	int64_t early_step = 0;     // ... and between two runs
+	bool early_split = true;    // a complete block met by idle encoders gets a short first finder run too
+	int enc_waiting = 0;        // encoder threads with nothing to do
+	int early_unclaimed = 0;    // early jobs no encoder has taken yet
+	double rest_wait = 0, t_first_enc = 0;
+	int64_t n_early_jobs = 0, n_early_stages = 0;
 
 	// the waiting block that comes first in the FILE (chunks are scanned side by side and their blocks arrive
 	// interleaved): chunks then complete one after the other and are laid out / written while later ones are
 	// still being encoded, instead of all at the very end
-	static Job *take_first(std::deque<Job *> &q);
+	static bool file_order_before(const Job *a, const Job *b)
+	{
+		return a->chunk->index < b->chunk->index || (a->chunk->index == b->chunk->index && a->ref.streamno == b->ref.streamno && a->ref.off < b->ref.off);
+	}
+	// next block for an encoder (mu held): withdrawn ones first (dropping them is what their chunk's scanner waits for),
+	// then complete blocks in file order, a block that is still arriving only when nothing else waits
+	Job *take_enc()
+	{
+		size_t best = 0;
+		auto rank = [](const Job *j) { return j->cancelled ? 0 : ((j->early && !j->full_ready && !j->refused) ? 2 : 1); };
+		for (size_t i = 1; i < enc_queue.size(); i++) {
+			const Job *a = enc_queue[i], *b = enc_queue[best];
+			const int ra = rank(a), rb = rank(b);
+			if (ra < rb || (ra == rb && file_order_before(a, b)))
+				best = i;
+		}
+		Job *j = enc_queue[best];
+		enc_queue.erase(enc_queue.begin() + (long)best);
+		return j;
+	}
+	// next block for a GPU worker (mu held), nullptr if none may be taken now: stages of early blocks first (an encoder
+	// is following them), then file order; a block that holds no host buffers yet only below the limit
+	Job *take_gpu()
+	{
+		size_t best = gpu_queue.size();
+		for (size_t i = 0; i < gpu_queue.size(); i++) {
+			const Job *a = gpu_queue[i];
+			if (!a->held_slot && held >= held_limit)
+				continue;
+			if (best == gpu_queue.size()) {
+				best = i;
+				continue;
+			}
+			const Job *b = gpu_queue[best];
+			if (a->early != b->early ? a->early : file_order_before(a, b))
+				best = i;
+		}
+		if (best == gpu_queue.size())
+			return nullptr;
+		Job *j = gpu_queue[best];
+		gpu_queue.erase(gpu_queue.begin() + (long)best);
+		return j;
+	}
+	void enqueue_gpu(Job *j) // mu held
+	{
+		if (j->early) {
+			j->full_requested = true; // (the only way an early job comes here again: its block is complete)
+			j->stage_want = j->ref.len;
+			if (j->queued || j->in_gpu || j->retiring || j->finished)
+				return;
+		}
+		j->queued = true;
+		gpu_queue.push_back(j);
+	}
+	// the scanner has gathered `have` bytes of an early block (mu not held)
+	void stage(Job *j, int64_t have)
+	{
+		std::lock_guard<std::mutex> lk(mu);
+		if (j->full_requested || j->finished || j->retiring || j->cancelled)
+			return;
+		j->stage_want = have;
+		if (j->queued || j->in_gpu)
+			return; // the worker looks again when it is through
+		if (have - j->stage_done >= (j->stage_done ? early_step : early_first)) {
+			j->queued = true;
+			gpu_queue.push_back(j);
+			cv_jobs.notify_all();
+		}
+	}
+	// should a block be started early now? (mu not held)
+	bool want_early()
+	{
+		if (early_mode == 2)
+			return true;
+		if (early_mode == 0)
+			return false;
+		std::lock_guard<std::mutex> lk(mu);
+		return enc_waiting > early_unclaimed && enc_queue.empty();
+	}
 
 	void fail(int e)
 	{
@@ -372,24 +481,34 @@ struct Pipeline {
 			cv_jobs.notify_all();
 			cv_enc.notify_all();
 			cv_done.notify_all();
+			cv_rest.notify_all();
 		}
 		if (on_fail)
 			on_fail();
 	}
 	int error() const { return err.load(); }
 
-	void mark_finished(Job *j, bool held_lists)
+	void finish_locked(Job *j) // mu held; the job's buffers have been given back
+	{
+		if (j->held_slot) {
+			j->held_slot = false;
+			held--;
+			cv_jobs.notify_all();
+		}
+		if (j->early && !j->with_encoder)
+			early_unclaimed--;
+		j->finished = true;
+		cv_done.notify_all();
+		cv_rest.notify_all();
+	}
+	void mark_finished(Job *j, bool)
 	{
 		j->bytes.release();
 		j->counts.release();
 		j->pairs.release();
+		j->old_pairs.clear();
 		std::lock_guard<std::mutex> lk(mu);
-		if (held_lists) {
-			held--;
-			cv_jobs.notify_all();
-		}
-		j->finished = true;
-		cv_done.notify_all();
+		finish_locked(j);
 	}
 
 	void store_raw(Job *j)
@@ -409,12 +528,67 @@ struct Pipeline {
 		bool compressible = j->compressible_mf && !j->cancelled;
 		if (compressible && j->gate_needed)
 			compressible = lz4_compresses_decision(j->ref.len, sz.threshold, [&](int, int) { return j->lz4_size; }) != 0;
+		if (j->enc_offered) {
+			// started early: an encoder has the block (or will take it from the queue) and finishes it either way
+			if (compressible)
+				j->full_ready = true;
+			else
+				j->refused = true;
+			cv_rest.notify_all();
+			return 0;
+		}
 		if (compressible) {
+			if (j->early) {
+				j->full_ready = true;
+				j->enc_offered = true;
+			}
 			enc_queue.push_back(j);
 			cv_enc.notify_one();
 			return 0;
 		}
 		return 1;
+	}
+
+	// ---- the encoder's side of an early block ------------------------------------------------------------
+	struct RestCtx {
+		Pipeline *P;
+		Job *j;
+		int64_t seen; // the limit the parser was told last
+		MatchLists ml;
+		double waited = 0;
+	};
+	// StagedLists::rest: blocks until the finder has covered more of the block (or all of it and the gate agreed)
+	static const MatchLists *rest_cb(void *ctx, size_t *valid)
+	{
+		RestCtx *r = (RestCtx *)ctx;
+		Pipeline *P = r->P;
+		Job *j = r->j;
+		const double t0 = now_s();
+		std::unique_lock<std::mutex> lk(P->mu);
+		P->cv_rest.wait(lk, [&] { return P->err || j->cancelled || j->refused || j->full_ready || j->valid > r->seen; });
+		r->waited += now_s() - t0;
+		if (P->err || j->cancelled || j->refused)
+			return nullptr;
+		r->seen = j->full_ready ? j->ref.len : j->valid;
+		r->ml.counts = j->counts.data();
+		r->ml.pairs = j->pairs.data(); // (may have moved: an outgrown array stays alive in old_pairs)
+		*valid = (size_t)r->seen;
+		return &r->ml;
+	}
+	// the encoder is through with an early block: no further finder run on it, and none still running
+	void retire(Job *j)
+	{
+		std::unique_lock<std::mutex> lk(mu);
+		j->retiring = true;
+		if (j->queued) {
+			for (size_t i = 0; i < gpu_queue.size(); i++)
+				if (gpu_queue[i] == j) {
+					gpu_queue.erase(gpu_queue.begin() + (long)i);
+					break;
+				}
+			j->queued = false;
+		}
+		cv_rest.wait(lk, [&] { return !j->in_gpu; });
 	}
 
 	// reference lzma_compress_buf(), src/stream.c:429-494, host half
@@ -423,12 +597,30 @@ struct Pipeline {
 		for (;;) {
 			Job *j = nullptr;
 			const double tw0 = now_s();
+			bool staged = false;
+			RestCtx rcx{this, nullptr, 0, MatchLists(), 0};
 			{
 				std::unique_lock<std::mutex> lk(mu);
+				enc_waiting++;
 				cv_enc.wait(lk, [&] { return !enc_queue.empty() || closing || err; });
+				enc_waiting--;
 				if (err || (enc_queue.empty() && closing))
 					return;
-				j = take_first(enc_queue);
+				j = take_enc();
+				if (j->early) {
+					if (!j->with_encoder)
+						early_unclaimed--;
+					j->with_encoder = true;
+					staged = true;
+					rcx.j = j;
+					rcx.seen = j->full_ready ? j->ref.len : j->valid;
+					rcx.ml.counts = j->counts.data();
+					rcx.ml.pairs = j->pairs.data();
+					rcx.ml.packed = j->packed;
+					rcx.ml.tail_flags = true;
+				}
+				if (t_first_enc == 0)
+					t_first_enc = now_s();
 			}
 			const double te0 = now_s();
 			TRACE_EVENT("enc_start", j);
@@ -455,19 +647,43 @@ struct Pipeline {
 			} else if (!j->cancelled) {
 				LzmaParams p;
 				lzma_normalize(p, sz.level, sz.dict_size, 3, 0, 2, sz.level < 7 ? 32 : 64);
-				MatchLists ml;
-				ml.counts = j->counts.data();
-				ml.pairs = j->pairs.data();
-				ml.packed = j->packed;
-				ml.tail_flags = true;
 				// dlen = round_up_page(s_len * 1.02), src/stream.c:443
 				size_t cap = (size_t)((double)j->ref.len * 1.02);
 				cap = (cap + kPage - 1) / kPage * kPage;
 				RawBuf<uint8_t> dst;
 				dst.alloc(cap);
 				size_t out_len = 0;
-				int r = lzma_encode_block(p, j->bytes.data(), (size_t)j->ref.len, ml, dst.data(), cap, &out_len);
-				if (r == LZ_OK && (int64_t)out_len < j->ref.len) {
+				int r;
+				if (staged) {
+					// the lists arrive while the parse runs (lzma_enc.h StagedLists); the gate's verdict was taken
+					// for granted: a refusal withdraws the block (rest_cb returns nullptr) and it is stored
+					StagedLists sl;
+					sl.early = rcx.ml;
+					sl.early_positions = (size_t)rcx.seen;
+					sl.rest = &Pipeline::rest_cb;
+					sl.ctx = &rcx;
+					r = lzma_encode_block_staged(p, j->bytes.data(), (size_t)j->ref.len, sl, dst.data(), cap, &out_len);
+					// whatever the parser said, the verdict on the block needs all of it (an overflow of dst can end the
+					// parse before the block is complete; a stored block needs every byte on the host)
+					std::unique_lock<std::mutex> lk(mu);
+					const double t0 = now_s();
+					cv_rest.wait(lk, [&] { return err || j->cancelled || j->refused || j->full_ready; });
+					rcx.waited += now_s() - t0;
+					if (err)
+						return;
+					if (j->cancelled || j->refused)
+						r = j->refused ? LZ_ERROR_OUTPUT_EOF : LZ_OK; // (stored / dropped below)
+				} else {
+					MatchLists ml;
+					ml.counts = j->counts.data();
+					ml.pairs = j->pairs.data();
+					ml.packed = j->packed;
+					ml.tail_flags = true;
+					r = lzma_encode_block(p, j->bytes.data(), (size_t)j->ref.len, ml, dst.data(), cap, &out_len);
+				}
+				if (j->cancelled) {
+					// withdrawn: nothing of it is used
+				} else if (r == LZ_OK && (int64_t)out_len < j->ref.len) {
 					j->done.c_type = CTYPE_LZMA;
 					j->done.payload.assign(dst.data(), dst.data() + out_len);
 				} else if (r == LZ_OK || r == LZ_ERROR_OUTPUT_EOF) {
@@ -477,11 +693,14 @@ struct Pipeline {
 					return;
 				}
 			}
+			if (staged)
+				retire(j);
 			{
 				std::lock_guard<std::mutex> lk(mu);
 				t_last_enc = now_s();
-				enc_busy += t_last_enc - te0;
-				enc_wait += te0 - tw0;
+				enc_busy += t_last_enc - te0 - rcx.waited;
+				enc_wait += te0 - tw0 + rcx.waited;
+				rest_wait += rcx.waited;
 			}
 			TRACE_EVENT("enc_end", j);
 			mark_finished(j, true);
@@ -558,18 +777,171 @@ struct Pipeline {
 		const bool lzma_ok = lzma_normalize(lp, sz.level, sz.dict_size, 3, 0, 2, sz.level < 7 ? 32 : 64) == LZ_OK;
 		// lists with the tail flag; one word per pair when the format allows it (lzma_mf.hip k_gather)
 		const bool pack = lzma_ok && lp.dict_size <= (1u << 25) && lp.fb <= 65;
+		// the finder on d_blk[0..n), a prefix of a block of block_n bytes (0: the block itself); grows the pool when the
+		// data needs more list entries than it holds
+		auto run_finder = [&](const uint8_t *d_blk, size_t n, size_t block_n, unsigned long long *total) -> int {
+			for (int attempt = 0;; attempt++) {
+				if (!ws) {
+					ws = WorkspacePool::get().take_mf(bufsize, per_pos, device, &ws_per_pos);
+					if (!ws)
+						return LRZGPU_E_NOMEM;
+				}
+				int r = mf_run_device(ws, d_blk, n, lp.dict_size, (uint32_t)lp.fb, lp.cut(), s, total, pack ? 2 : 1, lp.fast, block_n);
+				if (r == 0)
+					return 0;
+				if (r == -4 && attempt < 3) { // pool too small for this data: grow and retry
+					mf_workspace_destroy(ws);
+					ws = nullptr;
+					per_pos = ws_per_pos * 3;
+					continue;
+				}
+				return LRZGPU_E_INTERNAL;
+			}
+		};
+		// ---- one finder run of an early block: the prefix that is there, or the whole block ----
+		auto early_stage = [&](Job *j) -> int {
+			const int64_t n = j->ref.len;
+			int64_t P, from, have_bytes;
+			uint64_t w_from;
+			bool full;
+			{
+				std::lock_guard<std::mutex> lk(mu);
+				full = j->full_requested;
+				P = full ? n : j->stage_want;
+				// a complete block that idle encoders are waiting for: a short run first, they start on its lists
+				if (full && early_split && j->stage_done == 0 && !j->enc_offered && enc_waiting > 0 && n >= 8 * early_first && n >= (1 << 20)) {
+					P = n / 8;
+					full = false;
+				}
+				from = j->valid;
+				w_from = j->words_at_valid;
+				have_bytes = j->bytes_copied;
+			}
+			const uint8_t *d_blk = j->chunk->stream1.p + j->ref.off;
+			int64_t new_valid = from;
+			uint64_t new_words_at_valid = w_from;
+			bool compressible = true;
+			double tw1 = now_s(), tw2 = tw1;
+			const double tw0 = tw1;
+			if (!j->cancelled && (full || P - (int64_t)lp.fb - 4 > from)) {
+				if (!j->bytes.p)
+					j->bytes.alloc((size_t)n, want_pinned && n >= (1 << 20));
+				if (!j->counts.p)
+					j->counts.alloc((size_t)n, want_pinned);
+				if (P > have_bytes && d2h(j->bytes.data() + have_bytes, j->bytes.pinned, d_blk + have_bytes, (size_t)(P - have_bytes), stage, s) != 0)
+					return LRZGPU_E_HIP;
+				have_bytes = P > have_bytes ? P : have_bytes;
+				if (full && sz.lz4_test && !j->gate_needed) { // blocks outside the batched gate take the serial one
+					int pct = lrzgpu_lz4_compresses_dev(d_blk, n, sz.threshold, device);
+					if (pct < 0)
+						return pct;
+					compressible = pct != 0;
+				}
+				tw1 = now_s();
+				if (compressible) {
+					unsigned long long total = 0;
+					int fr = run_finder(d_blk, (size_t)P, full ? 0 : (size_t)n, &total);
+					if (fr)
+						return fr;
+					tw2 = now_s();
+					const uint64_t words = pack ? total / 2 : total;
+					new_valid = full ? n : P - (int64_t)lp.fb - 4;
+					if (!full) { // where the next run's lists will differ from this one's
+						unsigned long long e = 0;
+						if (d2h_pageable(&e, ws->offsets + new_valid, 8, s) != hipSuccess)
+							return LRZGPU_E_HIP;
+						new_words_at_valid = pack ? e / 2 : e;
+					} else
+						new_words_at_valid = words;
+					uint64_t copy_from = w_from;
+					if (!j->pairs.p || words > j->pairs.n) {
+						// (first run, or the block turned out denser than its first part promised)
+						std::unique_ptr<RawBuf<uint32_t>> fresh(new RawBuf<uint32_t>());
+						const double per = (double)words / (double)P;
+						size_t cap_words = full ? (size_t)words : (size_t)(per * 1.5 * (double)n) + ((size_t)4 << 20);
+						if (cap_words < words)
+							cap_words = (size_t)words;
+						fresh->alloc(cap_words, want_pinned);
+						copy_from = 0;
+						std::lock_guard<std::mutex> lk(mu); // (an encoder reads the pointer under mu: rest_cb)
+						std::swap(fresh->p, j->pairs.p);
+						std::swap(fresh->n, j->pairs.n);
+						std::swap(fresh->cap, j->pairs.cap);
+						std::swap(fresh->pinned, j->pairs.pinned);
+						if (fresh->p)
+							j->old_pairs.push_back(std::move(fresh));
+					}
+					j->packed = pack;
+					// positions below `from` are final on the host and may be being read: only what lies behind is copied
+					if (d2h(j->counts.data() + from, j->counts.pinned, ws->counts + from, (size_t)(P - from), stage, s) != 0 ||
+					    (words > copy_from && d2h(j->pairs.data() + copy_from, j->pairs.pinned, ws->pool_out + copy_from, (size_t)(words - copy_from) * 4, stage, s) != 0))
+						return LRZGPU_E_HIP;
+				}
+			}
+			int act = 0;
+			bool drop = false;
+			{
+				std::lock_guard<std::mutex> lk(mu);
+				n_early_stages++;
+				j->bytes_copied = have_bytes;
+				if (!j->cancelled) {
+					if (P > j->stage_done)
+						j->stage_done = P;
+					if (full) {
+						j->mf_done = true;
+						j->compressible_mf = compressible;
+						if (compressible) {
+							j->valid = n;
+							j->words_at_valid = new_words_at_valid;
+						}
+						act = route(j);
+					} else if (new_valid > j->valid) {
+						j->valid = new_valid;
+						j->words_at_valid = new_words_at_valid;
+						if (!j->enc_offered) {
+							j->enc_offered = true;
+							enc_queue.push_back(j);
+							cv_enc.notify_one();
+						}
+					}
+				}
+				j->in_gpu = false;
+				if (j->cancelled && !j->enc_offered && !j->finished)
+					drop = true; // nobody on the host side has it: it ends here
+				else if (!j->cancelled && !j->retiring && !j->mf_done &&
+					 (j->full_requested || j->stage_want - j->stage_done >= early_step)) {
+					j->queued = true;
+					gpu_queue.push_back(j);
+					cv_jobs.notify_all();
+				}
+				t_last_mf = now_s();
+				blk_busy += tw1 - tw0;
+				mf_busy += tw2 - tw1;
+				d2h_busy += t_last_mf - tw2;
+				cv_rest.notify_all();
+			}
+			if (act == 1 && !j->cancelled)
+				store_raw(j);
+			if (act == 1 || drop)
+				mark_finished(j, true);
+			return 0;
+		};
 		for (;;) {
 			Job *j = nullptr;
 			{
 				std::unique_lock<std::mutex> lk(mu);
-				cv_jobs.wait(lk, [&] { return err || (!gpu_queue.empty() && held < held_limit) || (closing && gpu_queue.empty()); });
-				if (err || (gpu_queue.empty() && closing)) {
+				cv_jobs.wait(lk, [&] { return err || (closing && gpu_queue.empty()) || (j = take_gpu()) != nullptr; });
+				if (!j) {
 					lk.unlock();
 					cleanup();
 					return;
 				}
-				j = take_first(gpu_queue);
-				held++; // released in mark_finished
+				j->queued = false;
+				j->in_gpu = true;
+				if (!j->held_slot) {
+					j->held_slot = true;
+					held++; // released in finish_locked
+				}
 			}
 			const double tw0 = now_s();
 			TRACE_EVENT("gpu_start", j);
@@ -581,6 +953,16 @@ struct Pipeline {
 				fail(LRZGPU_E_PARAM);
 				cleanup();
 				return;
+			}
+			if (j->early) {
+				int er = early_stage(j);
+				TRACE_EVENT("gpu_end", j);
+				if (er) {
+					fail(er);
+					cleanup();
+					return;
+				}
+				continue;
 			}
 			// block bytes: device view + host copy
 			const uint8_t *d_blk = nullptr;
@@ -633,25 +1015,9 @@ struct Pipeline {
 			if (compressible && !sz.zstd) {
 				// match finder on the GPU (runs concurrently with the gate launch of this block)
 				unsigned long long total = 0;
-				for (int attempt = 0;; attempt++) {
-					if (!ws) {
-						ws = WorkspacePool::get().take_mf(bufsize, per_pos, device, &ws_per_pos);
-						if (!ws) {
-							fail(LRZGPU_E_NOMEM);
-							cleanup();
-							return;
-						}
-					}
-					int r = mf_run_device(ws, d_blk, (size_t)n, lp.dict_size, (uint32_t)lp.fb, lp.cut(), s, &total, pack ? 2 : 1, lp.fast);
-					if (r == 0)
-						break;
-					if (r == -4 && attempt < 3) { // pool too small for this data: grow and retry
-						mf_workspace_destroy(ws);
-						ws = nullptr;
-						per_pos = ws_per_pos * 3;
-						continue;
-					}
-					fail(LRZGPU_E_INTERNAL);
+				int fr = run_finder(d_blk, (size_t)n, 0, &total);
+				if (fr) {
+					fail(fr);
 					cleanup();
 					return;
 				}
@@ -673,6 +1039,7 @@ struct Pipeline {
 				std::lock_guard<std::mutex> lk(mu);
 				j->mf_done = true;
 				j->compressible_mf = compressible;
+				j->in_gpu = false;
 				act = route(j);
 				t_last_mf = now_s();
 				blk_busy += tw1 - tw0;
@@ -738,8 +1105,37 @@ struct Pipeline {
 	void cancel_and_wait(const std::vector<Job *> &jobs)
 	{
 		std::unique_lock<std::mutex> lk(mu);
-		for (Job *j : jobs)
+		for (Job *j : jobs) {
 			j->cancelled = true;
+			// an early block no encoder has taken yet leaves the queues here (the encoders may all be busy for seconds);
+			// one that is in a finder run is ended by its worker, one that is with an encoder by the encoder
+			if (j->early && j->enc_offered && !j->with_encoder && !j->finished) {
+				for (size_t i = 0; i < enc_queue.size(); i++)
+					if (enc_queue[i] == j) {
+						enc_queue.erase(enc_queue.begin() + (long)i);
+						j->enc_offered = false;
+						break;
+					}
+				if (!j->enc_offered) {
+					if (j->queued) {
+						for (size_t i = 0; i < gpu_queue.size(); i++)
+							if (gpu_queue[i] == j) {
+								gpu_queue.erase(gpu_queue.begin() + (long)i);
+								break;
+							}
+						j->queued = false;
+					}
+					if (!j->in_gpu) {
+						j->bytes.release();
+						j->counts.release();
+						j->pairs.release();
+						j->old_pairs.clear();
+						finish_locked(j);
+					}
+				}
+			}
+		}
+		cv_rest.notify_all();
 		cv_done.wait(lk, [&] {
 			if (err)
 				return true;
@@ -750,19 +1146,6 @@ struct Pipeline {
 		});
 	}
 };
-
-Job *Pipeline::take_first(std::deque<Job *> &q)
-{
-	size_t best = 0;
-	for (size_t i = 1; i < q.size(); i++) {
-		const Job *a = q[i], *b = q[best];
-		if (a->chunk->index < b->chunk->index || (a->chunk->index == b->chunk->index && a->ref.streamno == b->ref.streamno && a->ref.off < b->ref.off))
-			best = i;
-	}
-	Job *j = q[best];
-	q.erase(q.begin() + (long)best);
-	return j;
-}
 
 // What a scanner thread needs to feed blocks to the pipeline while its scan is running.
 struct Feeder {
@@ -811,7 +1194,7 @@ struct Feeder {
 		{
 			std::lock_guard<std::mutex> lk(P.mu);
 			for (Job *j : jobs) {
-				P.gpu_queue.push_back(j);
+				P.enqueue_gpu(j);
 				TRACE_EVENT("submit", j);
 			}
 			P.cv_jobs.notify_all();
@@ -1331,7 +1714,16 @@ struct Run {
 		int64_t blocks_out = 0; // full stream-1 blocks already submitted
 		bool violated = false;
 		std::map<int64_t, Job *> early; // stream-1 offset -> job
+		std::set<Job *> starting;       // early jobs whose block is not complete yet
 		std::vector<MatchRec> rec_buf;
+		// early start of blocks: LZMA blocks only, and not under a filter (a block is filtered once, in place, whole)
+		const bool can_early = speculate && P.early_mode != 0 && !P.sz.zstd && !P.sz.no_compress && !P.filter_flag && bufsize >= 4096;
+		auto make_early = [&](Job *j) {
+			std::lock_guard<std::mutex> lk(P.mu);
+			j->early = true;
+			P.early_unclaimed++;
+			P.n_early_jobs++;
+		};
 
 		auto advance = [&](const ScanState &h, int64_t upto, bool final_call, const std::vector<MatchRec> *final_recs) -> int {
 			const int64_t nrec = final_recs ? (int64_t)final_recs->size() : h.n_records;
@@ -1385,8 +1777,18 @@ struct Run {
 				return 0;
 			std::vector<Job *> fresh;
 			while ((blocks_out + 1) * bufsize <= Sg) {
-				Job *j = F.new_job(cc, BlockRef{1, blocks_out * bufsize, bufsize});
-				early[blocks_out * bufsize] = j;
+				const int64_t off = blocks_out * bufsize;
+				auto it = early.find(off);
+				Job *j = it != early.end() ? it->second : nullptr; // started while it was being filled: now whole
+				if (j)
+					starting.erase(j);
+				else {
+					j = F.new_job(cc, BlockRef{1, off, bufsize});
+					// encoders with nothing to do: the finder hands them a first part of the block at once
+					if (can_early && P.early_split && P.want_early())
+						make_early(j);
+					early[off] = j;
+				}
 				fresh.push_back(j);
 				blocks_out++;
 			}
@@ -1397,6 +1799,22 @@ struct Run {
 			int sr2 = F.submit(fresh);
 			if (sr2)
 				return sr2;
+			// the block under construction: once a first part of it is there and encoders have
+			// nothing to do, the finder runs on what is there and an encoder starts on those lists; every further
+			// piece is another run on the longer prefix
+			if (can_early) {
+				const int64_t off = blocks_out * bufsize, have = Sg - off;
+				auto it = early.find(off);
+				Job *ej = it != early.end() ? it->second : nullptr;
+				if (!ej && have >= P.early_first && P.want_early()) {
+					ej = F.new_job(cc, BlockRef{1, off, bufsize});
+					make_early(ej);
+					early[off] = ej;
+					starting.insert(ej);
+				}
+				if (ej)
+					P.stage(ej, have);
+			}
 			if (P.error())
 				return P.error();
 			return F.poll(false);
@@ -1471,6 +1889,8 @@ struct Run {
 				if (it != early.end()) {
 					j = it->second;
 					early.erase(it);
+					if (starting.erase(j))
+						fresh.push_back(j); // started early, completed by the last piece of the scan: the whole block now
 				}
 			}
 			if (!j) {
@@ -1479,8 +1899,20 @@ struct Run {
 			}
 			cc->file_order.push_back(j);
 		}
-		if (!early.empty()) // cannot happen: every early block is a full stream-1 block of the final layout
-			return LRZGPU_E_INTERNAL;
+		if (!early.empty()) {
+			// a block started early that the chunk's last, shorter block took the place of: withdrawn (every other
+			// early block is a full stream-1 block of the final layout)
+			std::vector<Job *> dead;
+			for (auto &kv : early) {
+				if (!starting.count(kv.second))
+					return LRZGPU_E_INTERNAL;
+				dead.push_back(kv.second);
+			}
+			P.cancel_and_wait(dead);
+			if (P.error())
+				return P.error();
+			early.clear();
+		}
 		return F.submit(fresh);
 	}
 
@@ -1564,6 +1996,24 @@ int Run::run()
 	ctl->threads_used = P.sz.threads;
 	ctl->st_size = in.n;
 	speculate = !getenv("LRZGPU_NO_OVERLAP");
+	// early start of blocks.  LRZGPU_EARLY_START: 0 off, 1 (default) while encoders have nothing to
+	// do, 2 every block (tests); LRZGPU_EARLY_STEP: bytes of a block between two finder runs (default 1/16 of a block).
+	// None of it changes the output.
+	{
+		const char *e = getenv("LRZGPU_EARLY_START"); // read per run: tests flip it inside one process
+		P.early_mode = e ? atoi(e) : 1;
+		if (P.early_mode < 0 || P.early_mode > 2)
+			P.early_mode = 1;
+		int64_t step = P.sz.stream_bufsize / 16;
+		if (const char *t = getenv("LRZGPU_EARLY_STEP"))
+			if (atoll(t) > 0)
+				step = atoll(t);
+		if (step < 4096)
+			step = 4096;
+		P.early_step = step;
+		P.early_first = step;
+		P.early_split = !getenv("LRZGPU_EARLY_NO_SPLIT");
+	}
 
 	// the chunks of the file (src/rzip.c:1041: at least one pass, even for an empty input; STDIN mode: one more,
 	// empty, when the input ends exactly where a chunk does)
@@ -1770,6 +2220,10 @@ int Run::run()
 		const double vals[8] = {P.enc_busy, P.enc_wait, P.mf_busy, P.d2h_busy, t_scan_last - t0, P.t_last_mf - t0, P.t_last_enc - t0, now_s() - t0};
 		for (int k = 0; k < 8; k++)
 			ps.p.pipeline_s[k] += vals[k] > 0 ? vals[k] : 0;
+		ps.p.early_s[0] += P.t_first_enc > t0 ? P.t_first_enc - t0 : 0;
+		ps.p.early_s[1] += P.rest_wait;
+		ps.p.early_s[2] += (double)P.n_early_jobs;
+		ps.p.early_s[3] += (double)P.n_early_stages;
 	}
 	{
 		LzmaParams p;

@@ -1,0 +1,128 @@
+"""Early start of blocks in the whole-file driver (the reference's back end starts on a buffer
+while the scan is still running, src/stream.c:1836-1875, and its encoder consumes match blocks as the finder produces
+them, src/lzma/C/LzFindMt.c:946-981, LzmaEnc.c:1079-1123): a block under construction goes to the finder as a growing
+PREFIX (lrzgpu_lzma_match_lists_prefix's mode) and to an encoder that follows the lists stage by stage; the gate's
+verdict is taken for granted and a refusal withdraws the block.  None of it may change a byte: every case here is the
+whole .lrz image against the oracle's, with the early start FORCED on every block (LRZGPU_EARLY_START=2; by default it
+only happens while encoders have nothing to do, i.e. in every other test's first moments too) and small steps, so that
+a block sees many finder runs."""
+import ctypes as C
+import hashlib
+
+import pytest
+
+import datagen
+from test_compress_gpu import _both, RAM
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def forced(monkeypatch):
+    monkeypatch.setenv("LRZGPU_EARLY_START", "2")
+    monkeypatch.setenv("LRZGPU_EARLY_STEP", str(1 << 20))
+    monkeypatch.setenv("LRZGPU_SEG_BYTES", str(1 << 20))  # scan progress (and with it a new piece of the block) every MiB
+    return monkeypatch
+
+
+def _profile(B):
+    from test_chunks_gpu import _bench, _profile as prof
+    return prof(B, _bench())
+
+
+@pytest.mark.parametrize("kind", ["text", "longrange", "random", "zeros", "phrases", "few"])
+def test_every_block_started_early(B, O, forced, kind):
+    """34 MiB in 10 MiB blocks (-p16): three whole blocks started at their first MiB and followed through ~10 finder
+    runs each, and a short last block whose early start is withdrawn when the chunk ends (its length, hence the
+    encoder's view of it, was a guess).  'random': the gate refuses every literal block AFTER its encoder started."""
+    n = (34 << 20) + 77 if kind != "phrases" else (21 << 20) + 5
+    data = datagen.KINDS[kind](n, seed=41)
+    B.lib().lrzgpu_profile_reset()
+    fs = _both(B, O, data, level=7, threads=16, processors=16)
+    assert fs.stream_bufsize == 10 << 20
+    p = _profile(B)
+    if kind in ("text", "random", "few"):  # (little is matched away: stream 1 really has those blocks)
+        assert p.early_s[2] >= 3 and p.early_s[3] >= 3 * 5, list(p.early_s)
+
+
+@pytest.mark.parametrize("level", [1, 3, 5, 6, 8, 9])
+def test_levels_started_early(B, O, forced, level):
+    """HC5 lists + the greedy parser (levels 1-4) and the other dictionaries / fast-byte settings behind the same path."""
+    data = datagen.text_like((23 << 20) + 1234, seed=50 + level)
+    _both(B, O, data, level=level, threads=16, processors=16)
+
+
+def test_step_sizes_and_no_split(B, O, forced):
+    data = datagen.long_range((26 << 20) + 9, seed=43, base_frac=0.2, mutate_every=70001)
+    for step, seg in ((4096, 1 << 16), (300000, 1 << 18), (5 << 20, 1 << 20)):
+        forced.setenv("LRZGPU_EARLY_STEP", str(step))
+        forced.setenv("LRZGPU_SEG_BYTES", str(seg))
+        _both(B, O, data[:(12 << 20) + 3] if step == 4096 else data, level=7, threads=16, processors=16)
+    forced.setenv("LRZGPU_EARLY_NO_SPLIT", "1")
+    _both(B, O, data, level=7, threads=16, processors=16)
+
+
+def test_rollback_of_blocks_started_early(B, O, forced):
+    """A later match reaching back over literal bytes already released voids the chunk's early blocks -- including the
+    one an encoder is following (tests/test_compress_gpu.py test_early_release_rollback's second case, forced early)."""
+    forced.setenv("LRZGPU_SPEC_MARGIN", "0")
+    forced.setenv("LRZGPU_SEG_BYTES", str(4 << 20))
+    base = datagen.random_bytes(4 << 20, seed=81)
+    parts, pos = [base], len(base)
+    for k in range(14, 18):
+        start = k * (4 << 20) + 1 - (1 + k % 2)
+        parts.append(datagen.text_like(start - pos, seed=100 + k))
+        parts.append(base[:65536])
+        pos = start + 65536
+    parts.append(datagen.text_like(1 << 20, seed=99))
+    data = b"".join(parts)
+    B.lib().lrzgpu_profile_reset()
+    _both(B, O, data, level=7, threads=16, processors=16)
+    p = _profile(B)
+    assert p.spec_rollbacks >= 1 and p.spec_cancelled_blocks >= 1
+
+
+def test_multi_chunk_default_steps(B, O, monkeypatch):
+    """Three 100 MiB chunks, 71.7 MB blocks, the default step (1/16 block), chunks scanned side by side: every first
+    block is followed by an encoder from its first sixteenth on."""
+    monkeypatch.setenv("LRZGPU_EARLY_START", "2")
+    data = datagen.long_range(250 * 1048576 + 4097, seed=14, base_frac=0.08, mutate_every=300007)
+    B.lib().lrzgpu_profile_reset()
+    fs = _both(B, O, data, level=7, threads=4, processors=8, window=1)
+    assert fs.n_chunks == 3
+    p = _profile(B)
+    assert p.early_s[2] >= 3
+
+
+def test_victim_round_rescan_with_early_blocks(B, O, forced):
+    """A chunk scanned from the wrong victim_round is voided and scanned again -- with encoders inside its blocks."""
+    from test_chunks_gpu import _moving_victim_data
+    data = _moving_victim_data(O)
+    want, fs = O.compress_buffer(data, compression_level=7, threads=8, processors=16, ramsize=RAM, window=1, workers=16)
+    B.lib().lrzgpu_profile_reset()
+    got, ctl = B.compress_buffer(data, level=7, threads=8, processors=16, ramsize=RAM, window=1, host_threads=16)
+    assert got == want
+    assert _profile(B).victim_rescans >= 1
+
+
+def test_stdin_mode_and_device_input_started_early(B, O, forced):
+    import torch
+    ram = 60 << 20
+    chunk = (ram // 3) // 4096 * 4096
+    data = (datagen.text_like(chunk, seed=5) * 3)[:2 * chunk + 12345]
+    want, _ = O.compress_buffer(data, compression_level=5, threads=2, processors=2, ramsize=ram, workers=4, stdin_mode=1, stdout_mode=1)
+    got, _ = B.compress_buffer(data, level=5, threads=2, processors=2, ramsize=ram, host_threads=4, stdin_mode=1, stdout_mode=1)
+    assert got == want
+    data = datagen.long_range((31 << 20) + 5, seed=15, base_frac=0.3)
+    want, _ = O.compress_buffer(data, compression_level=7, threads=16, processors=16, ramsize=RAM, workers=8)
+    t = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    got, ctl = B.compress_device(t.data_ptr(), t.numel(), level=7, threads=16, processors=16, ramsize=RAM, host_threads=8)
+    assert got == want and bytes(ctl.hash_resblock) == hashlib.md5(data).digest()
+
+
+def test_early_start_off_is_the_same_image(B, O, monkeypatch):
+    data = datagen.text_like((21 << 20) + 3, seed=77)
+    monkeypatch.setenv("LRZGPU_EARLY_START", "0")
+    B.lib().lrzgpu_profile_reset()
+    _both(B, O, data, level=7, threads=16, processors=16)
+    assert _profile(B).early_s[2] == 0
