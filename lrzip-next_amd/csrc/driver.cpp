@@ -570,6 +570,8 @@ struct Pipeline {
 		if (P->err || j->cancelled || j->refused)
 			return nullptr;
 		r->seen = j->full_ready ? j->ref.len : j->valid;
+		if (tracing_events())
+			fprintf(stderr, "ev %.3f rest chunk %d stream 1 off %lld len %lld waited %.3f\n", now_s() - g_trace_t0, j->chunk->index, (long long)j->ref.off, (long long)r->seen, now_s() - t0);
 		r->ml.counts = j->counts.data();
 		r->ml.pairs = j->pairs.data(); // (may have moved: an outgrown array stays alive in old_pairs)
 		*valid = (size_t)r->seen;
@@ -817,6 +819,8 @@ struct Pipeline {
 				w_from = j->words_at_valid;
 				have_bytes = j->bytes_copied;
 			}
+			if (tracing_events())
+				fprintf(stderr, "ev %.3f stage_start chunk %d stream 1 off %lld len %lld\n", now_s() - g_trace_t0, j->chunk->index, (long long)j->ref.off, (long long)P);
 			const uint8_t *d_blk = j->chunk->stream1.p + j->ref.off;
 			int64_t new_valid = from;
 			uint64_t new_words_at_valid = w_from;

@@ -110,8 +110,8 @@ def test_stdin_mode_and_device_input_started_early(B, O, forced):
     ram = 60 << 20
     chunk = (ram // 3) // 4096 * 4096
     data = (datagen.text_like(chunk, seed=5) * 3)[:2 * chunk + 12345]
-    want, _ = O.compress_buffer(data, compression_level=5, threads=2, processors=2, ramsize=ram, workers=4, stdin_mode=1, stdout_mode=1)
-    got, _ = B.compress_buffer(data, level=5, threads=2, processors=2, ramsize=ram, host_threads=4, stdin_mode=1, stdout_mode=1)
+    want, _ = O.compress_buffer(data, compression_level=1, threads=2, processors=2, ramsize=ram, workers=4, stdin_mode=1, stdout_mode=1)
+    got, _ = B.compress_buffer(data, level=1, threads=2, processors=2, ramsize=ram, host_threads=4, stdin_mode=1, stdout_mode=1)
     assert got == want
     data = datagen.long_range((31 << 20) + 5, seed=15, base_frac=0.3)
     want, _ = O.compress_buffer(data, compression_level=7, threads=16, processors=16, ramsize=RAM, workers=8)

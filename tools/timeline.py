@@ -5,7 +5,9 @@ ev = collections.defaultdict(dict)
 for l in open(sys.argv[1]):
     if not l.startswith("ev "):
         continue
-    _, t, what, _, c, _, s, _, off, _, ln = l.split()
+    _, t, what, _, c, _, s, _, off, _, ln = l.split()[:11]
+    if what in ("stage_start", "rest"):
+        continue  # (tools/ramp.py reads those)
     ev[(int(c), int(s), int(off))][what] = float(t)
     ev[(int(c), int(s), int(off))]["len"] = int(ln)
 blocks = [v for v in ev.values() if "enc_start" in v and "enc_end" in v]
