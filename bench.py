@@ -145,30 +145,46 @@ KERNEL_UNIT = {"k_resolve": "rzip_scan.hip", "k_tag_scan": "rzip_scan.hip", "k_l
                "k_lz4_size": "lz4_gate.hip"}
 
 
+def _elf_section(path, name):
+    """Bytes of one section of an ELF64 file (None if it has none of that name)."""
+    import struct
+    with open(path, "rb") as f:
+        d = f.read()
+    if d[:4] != b"\x7fELF" or d[4] != 2:
+        return None
+    shoff, = struct.unpack_from("<Q", d, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", d, 0x3A)
+    def sh(i):
+        return struct.unpack_from("<IIQQQQIIQQ", d, shoff + i * shentsize)
+    str_off, str_size = sh(shstrndx)[4], sh(shstrndx)[5]
+    names = d[str_off:str_off + str_size]
+    for i in range(shnum):
+        h = sh(i)
+        nm = names[h[0]:names.index(b"\0", h[0])].decode()
+        if nm == name:
+            return d[h[4]:h[4] + h[5]]
+    return None
+
+
 def build_id(unit=None):
-    """Identifies the DEVICE code a PMC summary was measured for: every .hip translation unit of csrc/ (or, with
-    `unit`, that one alone) and the local headers they include, transitively (HBM bytes per launch of a kernel are a
-    property of the kernel's translation unit and of the workload key stored next to it; host-only sources -- parser,
-    hashes, read side -- do not enter)."""
-    import re
+    """Identifies the DEVICE code a PMC summary was measured for: the gfx950 code objects themselves -- the
+    .hip_fatbin section of every csrc/*.hip.o (or, with `unit`, of that unit's object alone).  HBM bytes per launch of a
+    kernel are a property of its code object and of the workload key stored next to it; a change to host code -- the
+    parser, the driver, a header only host code reads, the host half of a .hip file -- leaves the id alone (round 3
+    hashed the sources and every header they include: host-only edits to lzma_enc.h invalidated the round's last PMC
+    pass).  Falls back to the sources when an object is missing (a tree that was never built)."""
     src = os.path.join(ROOT, "lrzip-next_amd", "csrc")
-    todo = [os.path.join(src, unit)] if unit else sorted(glob.glob(os.path.join(src, "*.hip")))
-    seen = []
-    while todo:
-        p = todo.pop(0)
-        if p in seen or not os.path.exists(p):
-            continue
-        seen.append(p)
-        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(p, encoding="utf-8", errors="replace").read(), re.M):
-            for base in (os.path.dirname(p), os.path.join(ROOT, "include")):
-                q = os.path.normpath(os.path.join(base, inc))
-                if os.path.exists(q):
-                    todo.append(q)
-                    break
+    units = [unit] if unit else sorted(os.path.basename(p) for p in glob.glob(os.path.join(src, "*.hip")))
     h = hashlib.sha256()
-    for p in sorted(seen):
-        h.update(os.path.basename(p).encode())
-        h.update(open(p, "rb").read())
+    for u in units:
+        h.update(u.encode())
+        obj = os.path.join(src, u + ".o")
+        fat = _elf_section(obj, ".hip_fatbin") if os.path.exists(obj) else None
+        if fat is None:
+            h.update(b"source:")
+            h.update(open(os.path.join(src, u), "rb").read())
+        else:
+            h.update(fat)
     return h.hexdigest()[:16]
 
 
@@ -187,11 +203,11 @@ def pmc_traffic(kernel, workload_key):
         return None, "no PMC summary committed (tools/pmc_collect.py)"
     same_unit = ""
     if d.get("build_id") != build_id():
-        # another build: the figure still stands if the translation unit this kernel comes from is byte-identical
+        # another build: the figure still stands if the code object this kernel comes from is byte-identical
         unit = KERNEL_UNIT.get(kernel)
         if not unit or d.get("unit_build_ids", {}).get(unit) != build_id(unit):
             return None, "PMC summary is for build %s, this is build %s: not reported" % (d.get("build_id"), build_id())
-        same_unit = "; measured on build %s, this is build %s with %s and its headers unchanged" % (d.get("build_id"), build_id(), unit)
+        same_unit = "; measured on build %s, this is build %s with the code object of %s unchanged" % (d.get("build_id"), build_id(), unit)
     if d.get("workload_key") != workload_key:
         return None, "PMC summary is for workload %s" % d.get("workload_key")
     ks = d.get("kernels", {})

@@ -202,13 +202,16 @@ int lrzgpu_close_stream_out(lrzgpu_control *control, void *ss);
  *                    undone on every literal block)
  *   read_stream      src/stream.c:2220-2250  bytes read (fewer than asked for at the end of the stream), -1 on failure
  *   close_stream_in  src/stream.c:2299-2319  leaves f where the next chunk, or the hash, starts; frees the handle
- *   write_1g / put_fdout   src/stream.c:802-850   to control->fd_out;  read_1g  src/stream.c:897-945 */
+ *   write_1g / put_fdout   src/stream.c:802-850   to control->fd_out;  read_1g  src/stream.c:897-945
+ *   get_readseek     src/stream.c:1078-1088  (src/include/stream.h:22; runzip_chunk calls it, src/runzip.c:293): the
+ *                    offset fd stands at, -1 if it cannot be told (the reference calls fatal() there) */
 void *lrzgpu_open_stream_in(lrzgpu_control *control, int f, int n, char cbytes);
 int64_t lrzgpu_read_stream(lrzgpu_control *control, void *ss, int streamno, uint8_t *p, int64_t len);
 int lrzgpu_close_stream_in(lrzgpu_control *control, void *ss);
 int64_t lrzgpu_write_1g(lrzgpu_control *control, const void *buf, int64_t len);
 int64_t lrzgpu_read_1g(lrzgpu_control *control, int fd, void *buf, int64_t len);
 int64_t lrzgpu_put_fdout(lrzgpu_control *control, const void *offset_buf, int64_t ret);
+int64_t lrzgpu_get_readseek(lrzgpu_control *control, int fd);
 
 /* The per-block back-end dispatch seam: static int lzma_compress_buf(rzip_control*, struct compress_thread*,
  * int current_thread), src/stream.c:429-494 (and zstd_compress_buf 167-230 under LRZGPU_FLAG_ZSTD), called

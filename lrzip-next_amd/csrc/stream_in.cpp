@@ -357,3 +357,13 @@ extern "C" int64_t lrzgpu_put_fdout(lrzgpu_control *control, const void *offset_
 {
 	return lrzgpu_write_1g(control, offset_buf, ret);
 }
+
+// i64 get_readseek(control, fd): where the read side stands in its input (src/stream.c:1078-1088; runzip_chunk prints
+// it before every chunk header, src/runzip.c:293).  The reference's other branch -- STDIN spooled into a temporary
+// input buffer, control->in_ofs -- is its command-line front end's; a caller of this library reads from an fd.
+extern "C" int64_t lrzgpu_get_readseek(lrzgpu_control *control, int fd)
+{
+	(void)control;
+	const off_t at = lseek(fd, 0, SEEK_CUR);
+	return at == (off_t)-1 ? -1 : (int64_t)at;
+}

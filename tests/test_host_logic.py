@@ -203,9 +203,11 @@ print("ok")
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
 
 
-def test_bench_pmc_traffic_is_tied_to_the_kernels_translation_unit(monkeypatch, tmp_path):
+def test_bench_pmc_traffic_is_tied_to_the_kernels_code_object(monkeypatch, tmp_path):
     """bench.py reports roofline.traffic from the committed PMC summary only for the device code it was measured on:
-    the same build, or another build whose translation unit of THAT kernel (and its headers) is byte-identical."""
+    the same gfx950 code objects (.hip_fatbin of csrc/*.hip.o), or another build in which THAT kernel's unit has the
+    same code object.  Host-only edits -- a header only host code reads, the host half of a .hip file's text -- do not
+    invalidate a summary (round 3 lost its last PMC pass to exactly that)."""
     import importlib.util, json, shutil
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
@@ -213,16 +215,14 @@ def test_bench_pmc_traffic_is_tied_to_the_kernels_translation_unit(monkeypatch, 
     spec.loader.exec_module(bench)
     ids = bench.unit_build_ids()
     assert set(bench.KERNEL_UNIT.values()) <= set(ids) and all(len(v) == 16 for v in ids.values())
-    # a scratch tree: the device sources + a summary written for them
+    # a scratch tree: the device sources, their objects + a summary written for them
     src = os.path.join(root, "lrzip-next_amd", "csrc")
     dst = tmp_path / "lrzip-next_amd" / "csrc"
     dst.mkdir(parents=True)
     for f in os.listdir(src):
-        if f.endswith((".hip", ".h")):
+        if f.endswith((".hip", ".h", ".hip.o")):
             shutil.copy(os.path.join(src, f), dst / f)
-    (tmp_path / "include").mkdir()
-    for f in os.listdir(os.path.join(root, "include")):
-        shutil.copy(os.path.join(root, "include", f), tmp_path / "include" / f)
+    assert (dst / "rzip_scan.hip.o").exists(), "build() first: the identity is read from the objects"
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     assert bench.build_id() and bench.unit_build_ids() == ids
     (tmp_path / "profiles").mkdir()
@@ -231,15 +231,27 @@ def test_bench_pmc_traffic_is_tied_to_the_kernels_translation_unit(monkeypatch, 
     (tmp_path / "profiles" / "pmc_summary.json").write_text(json.dumps(summary))
     assert bench.pmc_traffic("k_resolve", "w") == (123, "n")
     assert bench.pmc_traffic("k_resolve", "other")[0] is None
-    # the finder's unit changes: the resolver's figure stands (and says so), the finder's does not
-    with open(dst / "lzma_mf.hip", "a") as f:
-        f.write("// changed\n")
+    # source text and headers change, the objects do not (host-only edits): everything stands
+    for name in ("lzma_mf.hip", "rzip_resolve_mw.h", "lzma_enc.h"):
+        with open(dst / name, "a") as f:
+            f.write("// changed\n")
+    assert bench.pmc_traffic("k_resolve", "w") == (123, "n") and bench.pmc_traffic("k_bt", "w")[0] == 456
+
+    def flip_device_code(name):
+        obj = dst / name
+        fat = bench._elf_section(str(obj), ".hip_fatbin")
+        raw = bytearray(obj.read_bytes())
+        at = raw.find(fat)
+        raw[at + len(fat) // 2] ^= 0xFF
+        obj.write_bytes(bytes(raw))
+
+    # the finder's code object changes: the resolver's figure stands (and says so), the finder's does not
+    flip_device_code("lzma_mf.hip.o")
     got, note = bench.pmc_traffic("k_resolve", "w")
-    assert got == 123 and "rzip_scan.hip and its headers unchanged" in note
+    assert got == 123 and "rzip_scan.hip" in note and "unchanged" in note
     assert bench.pmc_traffic("k_bt", "w")[0] is None
-    # a header the resolver includes changes: nothing stands
-    with open(dst / "rzip_resolve_mw.h", "a") as f:
-        f.write("// changed\n")
+    # the resolver's changes: nothing stands
+    flip_device_code("rzip_scan.hip.o")
     assert bench.pmc_traffic("k_resolve", "w")[0] is None
 
 

@@ -28,6 +28,8 @@ def runzip(B, img: bytes, tmp_path, threads=4):
     L.lrzgpu_write_1g.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     L.lrzgpu_read_1g.restype = C.c_int64
     L.lrzgpu_read_1g.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
+    L.lrzgpu_get_readseek.restype = C.c_int64
+    L.lrzgpu_get_readseek.argtypes = [C.c_void_p, C.c_int]
     m = B.read_magic(img)
     src, dst = tmp_path / "in.lrz", tmp_path / "out.bin"
     src.write_bytes(img)
@@ -49,6 +51,8 @@ def runzip(B, img: bytes, tmp_path, threads=4):
     try:
         while True:
             cb = C.create_string_buffer(1)
+            # "Reading chunk_bytes at ..." (src/runzip.c:293): the chunk header starts where the previous chunk ended
+            assert L.lrzgpu_get_readseek(cp, fi) == os.lseek(fi, 0, os.SEEK_CUR) >= m.magic_len + m.comment_length
             assert L.lrzgpu_read_1g(cp, fi, cb, 1) == 1
             chunk_bytes = cb.raw[0]
             ss = L.lrzgpu_open_stream_in(cp, fi, 2, cb.raw[0:1])
