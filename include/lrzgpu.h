@@ -24,6 +24,7 @@ extern "C" {
 #define LRZGPU_E_IO (-104)
 #define LRZGPU_E_INTERNAL (-105)
 #define LRZGPU_E_FORMAT (-106) /* not a .lrz this library can read, or a failed CRC/MD5/size check */
+#define LRZGPU_E_PEER (-107)   /* sharded run: another rank failed (that rank returns its own error) */
 
 /* rzip_control.flags bits this path reads (src/include/lrzip_private.h:257-370) */
 #define LRZGPU_FLAG_NO_COMPRESS (1u << 5)  /* FLAG_NO_COMPRESS, -n */
@@ -123,7 +124,8 @@ int lrzgpu_compress_buffer_dev(lrzgpu_control *control, const void *d_in, int64_
  * chain victim_out[k-1] == victim_in[k] and ask again for a chunk whose guess was wrong: what on_chunk reports
  * is authoritative -- with stride > 1 the library cannot check the chain itself (it does with stride == 1).
  * with_md5: also compute the MD5 of the whole input into control->hash_resblock (one caller does).
- * lrzgpu_assemble_chunks (host only): magic + the chunk images in order + MD5 = the .lrz file. */
+ * lrzgpu_assemble_chunks (host only): magic + the chunk images in order + the whole-input hash = the .lrz file;
+ * digest = lrzgpu_hash_length(control->hash_code) bytes (16 for MD5, up to 64; none read for code 0). */
 typedef int (*lrzgpu_chunk_fn)(void *ctx, int chunk_index, int64_t victim_in, int64_t victim_out,
 			       const uint8_t *chunk_image, int64_t len);
 int lrzgpu_compress_chunks(lrzgpu_control *control, const uint8_t *in, int64_t n, int first, int stride,
@@ -131,7 +133,7 @@ int lrzgpu_compress_chunks(lrzgpu_control *control, const uint8_t *in, int64_t n
 int lrzgpu_compress_chunks_dev(lrzgpu_control *control, const void *d_in, int64_t n, int first, int stride,
 			       const int64_t *victim_in, int with_md5, lrzgpu_chunk_fn on_chunk, void *ctx);
 int lrzgpu_assemble_chunks(lrzgpu_control *control, int64_t st_size, int n_chunks, const uint8_t *const *chunk_img,
-			   const int64_t *chunk_len, const uint8_t md5[16], uint8_t **out, int64_t *out_len);
+			   const int64_t *chunk_len, const uint8_t *digest, uint8_t **out, int64_t *out_len);
 
 /* The whole one-file-over-N-ranks protocol behind the C ABI (csrc/shard.cpp): every rank calls the same function with
  * its rank / world and three transport callbacks; rank r compresses chunks r, r + world, ... (the whole GPU path),
@@ -148,7 +150,12 @@ int lrzgpu_assemble_chunks(lrzgpu_control *control, int64_t st_size, int n_chunk
  *   lrzgpu_shard_protocol               the protocol alone over any per-rank chunk compressor `fn` (same contract as
  *                                        lrzgpu_compress_chunks: chunks k % stride == first, victim_in[k] >= 0 = start
  *                                        value, on_chunk per finished chunk); digest = the whole-input hash (rank 0)
- * *redone (may be NULL): chunks compressed again because of the chain, over all ranks. */
+ * *redone (may be NULL): chunks compressed again because of the chain, over all ranks.
+ * Failure: a rank whose compressor fails (out of memory, a HIP error) still enters the next all-reduce with an error
+ * flag set, so every rank leaves with an error together -- the failing rank with its own code, the others with
+ * LRZGPU_E_PEER -- before any send / recv.  A failing TRANSPORT cannot be reported through itself: the callbacks must be
+ * abortable (a failed or timed-out collective / send / recv on one rank has to fail the peers' pending calls:
+ * ncclCommAbort, a gloo timeout), and any callback error ends the protocol with LRZGPU_E_IO on that rank. */
 typedef struct lrzgpu_shard_comm {
 	void *ctx;
 	int rank, world;

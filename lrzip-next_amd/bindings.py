@@ -187,8 +187,11 @@ def compress_chunks(data=None, first=0, stride=1, victim_in=None, with_md5=False
 
 
 def assemble_chunks(images, st_size, md5, ctl=None, **kw):
-    """magic + chunk images in order + MD5 -> .lrz bytes (host only)."""
+    """magic + chunk images in order + the whole-input hash (`md5`: lrzgpu_hash_length(hash_code) bytes) -> .lrz bytes
+    (host only)."""
     c = ctl if ctl is not None else make_control(**kw)
+    need = lib().lrzgpu_hash_length(c.hash_code) if c.hash_code else 0
+    assert need >= 0 and len(md5) >= need, "digest shorter than hash code %d needs (%d bytes)" % (c.hash_code, need)
     k = len(images)
     arr = (C.c_char_p * k)(*images)
     lens = (C.c_int64 * k)(*[len(i) for i in images])

@@ -502,6 +502,8 @@ extern "C" void lrzgpu_profile_reset(void)
 	memset(&ps.p, 0, sizeof(ps.p));
 	for (auto &v : ps.iv)
 		v.clear();
+	for (auto &d : ps.dropped)
+		d = 0;
 	// time zero of the launch intervals: an event on the current device, recorded and completed now
 	if (ps.base) {
 		(void)hipEventDestroy(ps.base);

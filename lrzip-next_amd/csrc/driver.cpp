@@ -2056,11 +2056,11 @@ int Run::run()
 		std::lock_guard<std::mutex> lk(mu);
 		cv.notify_all();
 	};
-	P.start();
-	std::vector<std::thread> side;
 	const bool want_md5 = !sel || sel->with_md5;
 	if (in.dev_chunks && (want_md5 || !sel))
-		return LRZGPU_E_PARAM; // the whole-input hash needs the whole input
+		return LRZGPU_E_PARAM; // the whole-input hash needs the whole input (checked before any thread exists)
+	P.start();
+	std::vector<std::thread> side;
 	if (want_md5)
 		side.emplace_back([this] { P.guarded([this] { md5_main(); }, 3); });
 	side.emplace_back([this] { P.guarded([this] { reader_main(); }, 4); });
@@ -2517,9 +2517,10 @@ extern "C" int lrzgpu_compress_chunks(lrzgpu_control *control, const uint8_t *in
 
 // rank 0's half: the file from finished chunk images, in order (magic, chunks, MD5) -- host only
 extern "C" int lrzgpu_assemble_chunks(lrzgpu_control *control, int64_t st_size, int n_chunks, const uint8_t *const *chunk_img,
-				      const int64_t *chunk_len, const uint8_t md5[16], uint8_t **out, int64_t *out_len)
+				      const int64_t *chunk_len, const uint8_t *digest, uint8_t **out, int64_t *out_len)
 {
-	if (!control || st_size < 0 || n_chunks < 1 || !chunk_img || !chunk_len || !md5 || !out || !out_len)
+	// digest: lrzgpu_hash_length(control->hash_code) bytes (up to 64); none read for hash code 0
+	if (!control || st_size < 0 || n_chunks < 1 || !chunk_img || !chunk_len || (!digest && control->hash_code != 0) || !out || !out_len)
 		return LRZGPU_E_PARAM;
 	return abi_guard([&] {
 		Sizing s;
@@ -2545,7 +2546,8 @@ extern "C" int lrzgpu_assemble_chunks(lrzgpu_control *control, int64_t st_size, 
 			big_copy(o + at, chunk_img[c], (size_t)chunk_len[c]);
 			at += (size_t)chunk_len[c];
 		}
-		memcpy(o + at, md5, (size_t)hash_len);
+		if (hash_len)
+			memcpy(o + at, digest, (size_t)hash_len);
 		*out = o;
 		*out_len = (int64_t)total;
 		control->st_size = st_size;

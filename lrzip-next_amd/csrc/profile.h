@@ -18,8 +18,12 @@ struct ProfileStore {
 	// when every launch of a kind started and ended, in ms since `base` (recorded by lrzgpu_profile_reset): launches of
 	// one kind run side by side on different streams (a resolver per chunk, a finder per GPU slot), so the SUM of their
 	// durations says nothing about the wall time they cover -- the union of these intervals does
+	// Bounded: a process that reset once and then compresses for days keeps the first kMaxIntervals launches of a kind
+	// (2 MB per kind) and counts the rest (`dropped`; union_ms / peak_concurrency then describe the recorded ones).
+	static constexpr size_t kMaxIntervals = (size_t)1 << 18;
 	hipEvent_t base = nullptr;
 	std::vector<std::pair<float, float>> iv[PK_COUNT];
+	long long dropped[PK_COUNT] = {0};
 	static ProfileStore &get()
 	{
 		static ProfileStore s;
@@ -55,7 +59,9 @@ struct EventTimer {
 	{
 		const double d = ms();
 		float at = 0;
-		if (ps.base && a && hipEventElapsedTime(&at, ps.base, a) == hipSuccess)
+		if (ps.base && a && ps.iv[kind].size() >= ProfileStore::kMaxIntervals)
+			ps.dropped[kind]++;
+		else if (ps.base && a && hipEventElapsedTime(&at, ps.base, a) == hipSuccess)
 			ps.iv[kind].push_back(std::make_pair(at, at + (float)d));
 		else
 			(void)hipGetLastError();

@@ -17,6 +17,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <new>
 #include <vector>
 
 #include "../../include/lrzgpu.h"
@@ -68,22 +69,38 @@ int protocol(lrzgpu_control *control, int64_t n, const lrzgpu_shard_comm *comm, 
 	const int n_chunks = (int)sizes.size();
 	std::map<int, std::unique_ptr<Image>> images;
 	Collector col{&images, 0};
+	// A failure of this rank's compressor must not leave the peers blocked in the next collective: it is carried
+	// through it (one more word: how many ranks have failed) and every rank leaves together
+	int local_rc = 0;
+	auto safe_fn = [&](int first, int stride, const int64_t *victim) -> int { // (nothing may skip the next collective)
+		try {
+			return fn(fn_ctx, first, stride, victim, collect_chunk, &col);
+		} catch (const std::bad_alloc &) {
+			return LRZGPU_E_NOMEM;
+		} catch (...) {
+			return LRZGPU_E_INTERNAL;
+		}
+	};
 	if (rank < n_chunks) {
-		rc = fn(fn_ctx, rank, world, nullptr, collect_chunk, &col);
+		rc = safe_fn(rank, world, nullptr);
 		if (rc || col.rc)
-			return rc ? rc : col.rc;
+			local_rc = rc ? rc : col.rc;
 	}
 	int64_t redone = 0;
-	std::vector<int64_t> meta((size_t)n_chunks * 3);
+	std::vector<int64_t> meta((size_t)n_chunks * 3 + 1);
 	for (;;) {
 		std::fill(meta.begin(), meta.end(), 0);
-		for (auto &kv : images) {
-			meta[(size_t)kv.first * 3 + 0] = kv.second->vin;
-			meta[(size_t)kv.first * 3 + 1] = kv.second->vout;
-			meta[(size_t)kv.first * 3 + 2] = kv.second->len;
-		}
-		if (world > 1 && comm->allreduce_sum_i64(comm->ctx, meta.data(), n_chunks * 3) != 0)
-			return LRZGPU_E_IO;
+		if (!local_rc)
+			for (auto &kv : images) {
+				meta[(size_t)kv.first * 3 + 0] = kv.second->vin;
+				meta[(size_t)kv.first * 3 + 1] = kv.second->vout;
+				meta[(size_t)kv.first * 3 + 2] = kv.second->len;
+			}
+		meta[(size_t)n_chunks * 3] = local_rc ? 1 : 0;
+		if (world > 1 && comm->allreduce_sum_i64(comm->ctx, meta.data(), n_chunks * 3 + 1) != 0)
+			return local_rc ? local_rc : LRZGPU_E_IO;
+		if (meta[(size_t)n_chunks * 3] != 0)
+			return local_rc ? local_rc : LRZGPU_E_PEER;
 		// the chain of src/rzip.c:308: chunk k must have started from what chunk k - 1 left
 		int bad = -1;
 		for (int k = 1; k < n_chunks && bad < 0; k++)
@@ -91,17 +108,17 @@ int protocol(lrzgpu_control *control, int64_t n, const lrzgpu_shard_comm *comm, 
 				bad = k;
 		if (bad < 0)
 			break;
+		if (++redone > (int64_t)n_chunks * 4 + 16)
+			return LRZGPU_E_INTERNAL; // (cannot happen: every round fixes the first wrong chunk for good; all ranks count alike)
 		// only the FIRST wrong chunk is certain to be wrong: its new end value decides about the rest
 		if (bad % world == rank) {
 			std::vector<int64_t> victim((size_t)n_chunks, -1);
 			victim[(size_t)bad] = meta[(size_t)(bad - 1) * 3 + 1];
 			images.erase(bad);
-			rc = fn(fn_ctx, bad, n_chunks > bad + 1 ? n_chunks : bad + 1, victim.data(), collect_chunk, &col); // chunk `bad` alone
+			rc = safe_fn(bad, n_chunks > bad + 1 ? n_chunks : bad + 1, victim.data()); // chunk `bad` alone
 			if (rc || col.rc)
-				return rc ? rc : col.rc;
+				local_rc = rc ? rc : col.rc; // reported by the next round's all-reduce
 		}
-		if (++redone > (int64_t)n_chunks * 4 + 16)
-			return LRZGPU_E_INTERNAL; // (cannot happen: every round fixes the first wrong chunk for good)
 	}
 	if (redone_out)
 		*redone_out = redone;

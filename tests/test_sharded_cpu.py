@@ -141,3 +141,47 @@ def test_single_rank_chain_redo():
     assert img[21:-16] == b"p0@0" + b"p1@0" + b"p2@3" + b"p3@3" and redone == 2
     assert seen == [(0, 0), (1, 0), (2, 0), (3, 0), (2, 3), (3, 3)]
     assert SH.owner(5, 2) == 1
+
+
+def _failing_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, HERE)
+    SH = _load("lrzip_next_amd_sharded", "lrzip-next_amd/sharded.py")
+    B = _load("lrzip_next_amd_bindings", "lrzip-next_amd/bindings.py")
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        n = 4 * (2 << 20)
+
+        def compress_fn(first, stride, victim_in):
+            if rank == 1:
+                raise MemoryError("rank 1 cannot compress its chunks")
+            return {k: (0, 0, b"p%d" % k) for k in range(first, 4, stride)}
+
+        comm, keep = SH.torch_comm(rank, world, dist, torch, torch.device("cpu"))
+        try:
+            B.shard_protocol(n, comm, compress_fn, bytes(16), no_compress=True, threads=1, ramsize=RAM)
+            q.put((rank, "no error"))
+        except RuntimeError as e:
+            q.put((rank, str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failing_rank_fails_every_rank_instead_of_hanging_them():
+    """a rank whose compressor fails used to return at once and leave its peers blocked in the all-reduce.
+    Now the failure travels through the collective: the failing rank returns its own error, the other LRZGPU_E_PEER
+    (-107), before any send / recv."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    msgs = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert "rc=-107" in msgs[0], msgs
+    assert "rc=-1" in msgs[1] and "rc=-107" not in msgs[1], msgs
