@@ -25,8 +25,7 @@ int lrzgpu_hash_final(void *h, uint8_t *out); /* also closes h */
 /* The hash of a run is control->hash_code (lrzgpu.h), 1 = MD5 unless changed: the whole-file entry points compute
  * and append it; the chunk-sharded ones compute it when asked to (with_md5) and lrzgpu_assemble_chunks appends
  * lrzgpu_hash_length(control->hash_code) bytes.  control->hash_full receives the digest, hash_resblock its first 16
- * bytes.  lrzgpu_select_hash() sets the default lrzgpu_control_init() hands out (-H of the reference's command line). */
-int lrzgpu_select_hash(int hash_code);
+ * bytes.  (-H <n> of the reference's command line = that field; lrzgpu_control_init() sets 1.) */
 
 /* This rewrites the trailer of an image (or
  * of any 0.14 image without encryption) for another hash code: magic[14] = hash_code, the old digest dropped,
@@ -65,9 +64,8 @@ int lrzgpu_read_magic(const uint8_t *lrz, int64_t n, lrzgpu_magic *m);
  * literal block goes through it before its back end, magic[16] says so, the lz4 test is off (src/main.c:858-861).
  * In the whole-file and chunk-sharded entry points the block is filtered in HBM where the scan left it
  * (lrzgpu_filter_block_dev below); the stream API filters its host buffers with the host converters.
- * lrzgpu_select_filter() / lrzgpu_select_hash() only set the DEFAULTS lrzgpu_control_init() hands out from then on
- * (--x86 ... --delta=N, -H of the reference's command line, src/main.c:612-660); a run reads nothing but its control. */
-int lrzgpu_select_filter(int filter_flag, int delta);
+ * (--x86 ... --delta=N of the reference's command line, src/main.c:612-660, = those fields; lrzgpu_control_init()
+ * sets none.)  A run reads nothing but its control. */
 /* the compress direction over a block resident on `device` (d_data 4-byte aligned), in place: one thread per
  * word / Thumb pair / IA-64 bundle; x86 and RISC-V as candidate compaction + per-run resolution + parallel conversion
  * (csrc/filters_gpu.hip); bit-identical to lrzgpu_filter_block(..., encode = 1) */

@@ -84,8 +84,6 @@ static void role_cpu_add(int role, double s)
 }
 
 namespace lrzgpu {
-int selected_hash_code();
-int selected_filter(int *delta);
 int control_filter(const lrzgpu_control *c, int *flag, int *delta);
 } // namespace lrzgpu
 extern "C" void lrzgpu_control_init(lrzgpu_control *c)
@@ -99,25 +97,12 @@ extern "C" void lrzgpu_control_init(lrzgpu_control *c)
 	c->processors = c->threads;
 	long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGE_SIZE);
 	c->ramsize = (pages > 0 && psz > 0) ? (int64_t)pages * psz : (int64_t)8 << 30; // src/lrzip.c:95-125
-	c->hash_code = lrzgpu::selected_hash_code(); // MD5 (src/lrzip.c:1842) unless lrzgpu_select_hash() changed the default
-	c->filter_flag = lrzgpu::selected_filter(&c->delta);
+	c->hash_code = 1; // MD5 (src/lrzip.c:1842); -H <n> of the reference's command line = this field, filter options =
+	                  // filter_flag / delta (0: none): per run, where the reference keeps them (rzip_control)
 	c->fd_out = -1;
 }
 
-// Defaults lrzgpu_control_init() hands out.  The selection itself lives in the control (hash_code, filter_flag, delta
-// -- where the reference keeps it, rzip_control): a run reads its own control once and nothing else, so concurrent
-// files with different selections do not see each other.
-static std::atomic<int> g_hash_code{1};
-extern "C" int lrzgpu_select_hash(int hash_code)
-{
-	if (lrzgpu::hash_length(hash_code) < 0)
-		return LRZGPU_E_PARAM;
-	g_hash_code.store(hash_code);
-	return 0;
-}
-// the filter options of the reference's command line (--x86 ... --delta=N, src/main.c:612-660): the filter every
-// literal block of the whole-file compress entry points goes through from now on; 0 = none (default)
-static std::atomic<int> g_filter{0}; // flag | delta << 8: one word, so a reader never pairs a flag with another call's delta
+// the filter options of the reference's command line (--x86 ... --delta=N, src/main.c:612-660) as they stand in a control
 static int check_filter(int filter_flag, int delta)
 {
 	if (filter_flag != 0 && !lrzgpu::filter_supported(filter_flag, delta))
@@ -126,21 +111,7 @@ static int check_filter(int filter_flag, int delta)
 		return LRZGPU_E_PARAM; // magic[16] codes 1..16, 32, 48 ... 256 only (src/lrzip.c:148-156)
 	return 0;
 }
-extern "C" int lrzgpu_select_filter(int filter_flag, int delta)
-{
-	if (check_filter(filter_flag, delta))
-		return LRZGPU_E_PARAM;
-	g_filter.store(filter_flag | ((filter_flag == lrzgpu::FILTER_DELTA ? delta : 0) << 8));
-	return 0;
-}
 namespace lrzgpu {
-int selected_hash_code() { return g_hash_code.load(); }
-int selected_filter(int *delta)
-{
-	const int v = g_filter.load();
-	*delta = v >> 8;
-	return v & 0xFF;
-}
 int control_filter(const lrzgpu_control *c, int *flag, int *delta)
 {
 	*flag = c->filter_flag;
@@ -215,39 +186,13 @@ static bool tracing_events()
 				(j)->ref.streamno, (long long)(j)->ref.off, (long long)(j)->ref.len);                                 \
 	} while (0)
 
-// Experiment (LRZGPU_SCAN_EXCLUSIVE_CUS=n, 1..16; unset = off): every scanner owns n CUs that nothing else may use --
-// its scan stream is masked to them (make_scan_stream) and every other stream of the pipeline to the rest of the chip.
-// The resolver is one latency-bound workgroup; measured with the finder's wave-per-bucket launches spread over the
-// chip, whatever shares its CU costs it (470 -> 741 ms per launch).
-static int scan_exclusive_cus()
-{
-	static const int n = [] {
-		const char *e = getenv("LRZGPU_SCAN_EXCLUSIVE_CUS");
-		const int v = e ? atoi(e) : 0;
-		return v < 0 ? 0 : (v > 16 ? 16 : v);
-	}();
-	return n;
-}
 static hipError_t make_stream(hipStream_t *s, bool high_priority = false)
 {
 	const int dev = current_device_or0();
-	const int excl = high_priority ? 0 : scan_exclusive_cus();
-	const int kind = high_priority ? 1 : (excl ? 64 : 0);
+	const int kind = high_priority ? 1 : 0;
 	if ((*s = StreamPool::get().take(dev, kind)) != nullptr)
 		return hipSuccess;
 	hipError_t e = hipErrorUnknown;
-	if (excl) {
-		hipDeviceProp_t prop;
-		if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 8 * excl + 32) {
-			const int ncu = prop.multiProcessorCount > 256 ? 256 : prop.multiProcessorCount;
-			uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-			for (int c = 8 * excl; c < ncu; c++)
-				mask[c >> 5] |= 1u << (c & 31);
-			e = hipExtStreamCreateWithCUMask(s, (uint32_t)((ncu + 31) / 32), mask);
-			if (e != hipSuccess)
-				(void)hipGetLastError();
-		}
-	}
 	if (high_priority) {
 		// a scan stream must never queue behind a multi-second gate/finder kernel: streams share a
 		// small pool of hardware queues (GPU_MAX_HW_QUEUES), priority streams get their own
@@ -287,7 +232,6 @@ struct ZstdLib {
 };
 
 struct Job;
-static std::vector<int> encoder_cpu_order();
 
 
 struct ChunkCtx {
@@ -363,7 +307,7 @@ struct Pipeline {
 	lrzgpu_control *ctl = nullptr;
 	Sizing sz;
 	int device = 0;
-	int filter_flag = 0, filter_delta = 0; // lrzgpu_select_filter(): every literal block through this filter first
+	int filter_flag = 0, filter_delta = 0; // control->filter_flag / delta: every literal block through this filter first
 	int n_gpu_workers = 2, n_encoders = 1;
 	std::atomic<int> err{0};          // first failure; read by every thread of the run
 	std::function<void()> on_fail;    // wakes the run's own waiters (reader, scanners, committer)
@@ -758,7 +702,7 @@ struct Pipeline {
 		uint8_t *stage[2] = {nullptr, nullptr};
 		double per_pos = 16;
 		const size_t bufsize = (size_t)sz.stream_bufsize;
-		static const bool want_pinned = !getenv("LRZGPU_NO_PINNED_LISTS");
+		const bool want_pinned = true; // lists and block bytes land in pinned host buffers from the pool
 		auto cleanup = [&] {
 			WorkspacePool::get().give_mf(ws, ws_per_pos, device);
 			ws = nullptr;
@@ -1078,19 +1022,8 @@ struct Pipeline {
 	{
 		for (int i = 0; i < n_gpu_workers; i++)
 			threads.emplace_back([this] { guarded([this] { gpu_worker_main(); }, 1); });
-		std::vector<int> pin;
-		if (const char *e = getenv("LRZGPU_PIN_ENCODERS"))
-			if (*e == '1')
-				pin = encoder_cpu_order();
-		for (int i = 0; i < n_encoders; i++) {
+		for (int i = 0; i < n_encoders; i++)
 			threads.emplace_back([this] { guarded([this] { encoder_main(); }, 0); });
-			if (!pin.empty()) {
-				cpu_set_t one;
-				CPU_ZERO(&one);
-				CPU_SET(pin[(size_t)i % pin.size()], &one);
-				(void)pthread_setaffinity_np(threads.back().native_handle(), sizeof(one), &one);
-			}
-		}
 	}
 	void stop()
 	{
@@ -1306,54 +1239,6 @@ struct Feeder {
 	}
 };
 
-// Where to run the k-th encoder thread (LRZGPU_PIN_ENCODERS=1): one core per L3 domain first (on a chiplet CPU an
-// encoder that has a last-level cache to itself keeps the hot part of its 67 MB block and its price tables in
-// it), then second cores of every domain, first SMT thread of a core only, inside the process's affinity mask.
-static std::vector<int> encoder_cpu_order()
-{
-	std::vector<int> order;
-	cpu_set_t allowed;
-	if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0)
-		return order;
-	const int ncpu = (int)sysconf(_SC_NPROCESSORS_CONF);
-	std::map<std::string, std::vector<int>> domains; // L3 shared_cpu_list -> first SMT threads of its cores
-	for (int c = 0; c < ncpu && c < CPU_SETSIZE; c++) {
-		if (!CPU_ISSET(c, &allowed))
-			continue;
-		char path[160], buf[256];
-		snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
-		FILE *f = fopen(path, "r");
-		if (!f)
-			continue;
-		int first = -1;
-		if (fscanf(f, "%d", &first) != 1)
-			first = -1;
-		fclose(f);
-		if (first != c)
-			continue; // not the first hardware thread of its core
-		snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", c);
-		f = fopen(path, "r");
-		std::string key = "none";
-		if (f) {
-			if (fgets(buf, sizeof(buf), f))
-				key = buf;
-			fclose(f);
-		}
-		domains[key].push_back(c);
-	}
-	for (size_t r = 0;; r++) {
-		bool any = false;
-		for (auto &d : domains)
-			if (r < d.second.size()) {
-				order.push_back(d.second[r]);
-				any = true;
-			}
-		if (!any)
-			break;
-	}
-	return order;
-}
-
 // CPUs this process may burn: the affinity mask, capped by a cgroup CPU quota (v2 cpu.max, v1 cfs_quota_us)
 static int usable_cpus()
 {
@@ -1535,7 +1420,7 @@ struct Run {
 	}
 
 	// ---- whole-input hash (the reference feeds it from cksumthread, src/rzip.c:564-584): MD5 unless
-	// lrzgpu_select_hash() asked for another of hashes[] (src/main.c:64-79) ------------------------------
+	// control->hash_code names another of hashes[] (src/main.c:64-79) ---------------------------------------
 	uint8_t digest[64] = {0};
 	const int hash_code = ctl->hash_code; // control->hash_code, src/rzip.c:943-950, 1195-1219
 	void md5_main()
@@ -1626,17 +1511,15 @@ struct Run {
 	std::atomic<int> scanner_ids{0};
 	hipError_t make_scan_stream(hipStream_t *s)
 	{
-		static const bool off = getenv("LRZGPU_NO_SCAN_CU_MASK") != nullptr;
 		hipDeviceProp_t prop;
-		if ((scan_slots > 1 || scan_exclusive_cus()) && !off && hipGetDeviceProperties(&prop, P.device) == hipSuccess && prop.multiProcessorCount >= 64) {
+		if (scan_slots > 1 && hipGetDeviceProperties(&prop, P.device) == hipSuccess && prop.multiProcessorCount >= 64) {
 			const int ncu = prop.multiProcessorCount > 256 ? 256 : prop.multiProcessorCount;
 			const int k = scanner_ids.fetch_add(1) % 8;
-			const int excl = scan_exclusive_cus(); // experiment: CUs k, k + 8, ... below 8 * excl, and nobody else's
-			const int kind = (excl ? 48 : 16) + k;
+			const int kind = 16 + k;
 			if ((*s = StreamPool::get().take(P.device, kind)) != nullptr)
 				return hipSuccess;
 			uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-			for (int c = k; c < (excl ? 8 * excl : ncu); c += 8)
+			for (int c = k; c < ncu; c += 8)
 				mask[c >> 5] |= 1u << (c & 31);
 			if (hipExtStreamCreateWithCUMask(s, (uint32_t)((ncu + 31) / 32), mask) == hipSuccess) {
 				StreamPool::get().created(*s, P.device, kind);
@@ -2040,9 +1923,6 @@ int Run::run()
 		if (!sel || (sel->stride > 0 && (int)k % sel->stride == sel->first))
 			mine.push_back((int)k);
 	scan_slots = ctl->scan_slots > 0 ? ctl->scan_slots : 8;
-	if (const char *e = getenv("LRZGPU_SCAN_SLOTS"))
-		if (atoi(e) > 0)
-			scan_slots = atoi(e);
 	if ((size_t)scan_slots > mine.size())
 		scan_slots = mine.empty() ? 1 : (int)mine.size();
 	if (ctl->verbose)

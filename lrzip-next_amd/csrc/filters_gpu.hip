@@ -16,9 +16,9 @@
 //     after three parcels that are neither JAL nor AUIPC the RISC-V scan visits the next candidate whatever happened
 //     before.  So: (1) compact the candidate positions (hipCUB select), (2) one thread per run of candidates that lie
 //     closer than that walks its run exactly like the serial scan and marks what is converted (and with which
-//     history), (3) one thread per marked candidate converts it -- converted units never overlap.  Blocks whose
-//     candidates are denser than one per eight bytes (not machine code) take a one-thread kernel that is the serial
-//     scan itself.
+//     history), (3) one thread per marked candidate converts it -- converted units never overlap.  The candidate
+//     list holds every position if it must: a block dense in opcode bytes (not machine code) goes the same way, its
+//     candidates forming fewer, longer runs (round 3 had a one-thread kernel for such blocks: seconds per block).
 // Bound: HBM, ~3 B per block byte (count + select read the block, the word kernels read + write it).
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -248,55 +248,6 @@ __global__ void __launch_bounds__(256) k_x86_apply(uint8_t *__restrict__ d, cons
 		d[p + 4] = (uint8_t)(0 - ((v >> 24) & 1));
 	}
 }
-// the scan itself, one thread: blocks whose opcode bytes are too dense for the candidate list
-__global__ void k_x86_serial(uint8_t *d, size_t n)
-{
-	if (n < 5 || threadIdx.x || blockIdx.x)
-		return;
-	const size_t limit = n - 4;
-	unsigned recent = 0;
-	size_t pos = 0;
-	for (;;) {
-		size_t p = pos;
-		while (p < limit && (d[p] & 0xFE) != 0xE8)
-			p++;
-		const size_t gap = p - pos;
-		pos = p;
-		if (p >= limit)
-			return;
-		if (gap > 2)
-			recent = 0;
-		else {
-			recent >>= gap;
-			if (recent != 0 && (recent > 4 || recent == 3 || sign_byte(d[p + (recent >> 1) + 1]))) {
-				recent = (recent >> 1) | 4;
-				pos++;
-				continue;
-			}
-		}
-		if (sign_byte(d[p + 4])) {
-			uint32_t v = ld32(d + p + 1);
-			const uint32_t cur = (uint32_t)pos + 5;
-			pos += 5;
-			v += cur;
-			if (recent != 0) {
-				const unsigned sh = (recent & 6) << 2;
-				if (sign_byte((uint8_t)(v >> sh))) {
-					v ^= ((uint32_t)0x100 << sh) - 1;
-					v += cur;
-				}
-				recent = 0;
-			}
-			d[p + 1] = (uint8_t)v;
-			d[p + 2] = (uint8_t)(v >> 8);
-			d[p + 3] = (uint8_t)(v >> 16);
-			d[p + 4] = (uint8_t)(0 - ((v >> 24) & 1));
-		} else {
-			recent = (recent >> 1) | 4;
-			pos++;
-		}
-	}
-}
 
 // ---- RISC-V ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool rv_pair(uint32_t key, uint32_t next) { return (((next - 3) ^ (key << 8)) & 0xF8003u) == 0; }
@@ -384,25 +335,6 @@ __global__ void __launch_bounds__(256) k_rv_apply(uint8_t *__restrict__ d, const
 		if (mark[k])
 			rv_convert(d + 2 * (size_t)pos[k], 2 * pos[k], mark[k]);
 }
-__global__ void k_rv_serial(uint8_t *d, size_t n)
-{
-	n &= ~(size_t)1;
-	if (n <= 6 || threadIdx.x || blockIdx.x)
-		return;
-	const size_t lim = n - 6;
-	size_t i = 0;
-	while (i < lim) {
-		if (rv_key(d + i) & 0x77) {
-			i += 2;
-			continue;
-		}
-		unsigned step;
-		const unsigned what = rv_decide(d + i, &step);
-		if (what)
-			rv_convert(d + i, (uint32_t)i, what);
-		i += step;
-	}
-}
 
 unsigned grid_for(size_t items)
 {
@@ -418,8 +350,9 @@ size_t filter_scratch_bytes(int flag, size_t n)
 		return n + 256;
 	if (flag != FILTER_X86 && flag != FILTER_RISCV)
 		return 0;
-	// counter + count, the candidate list (one per eight bytes at most, else the serial kernel), marks, select's temp
-	const size_t cap = n / 8 + 1024;
+	// counter + count, the candidate list (every position may be one: a block dense in opcode bytes -- not machine
+	// code -- is walked by the same kernels, its candidates just form few long runs), marks, select's temp
+	const size_t cap = n + 1024;
 	size_t temp = 0, temp2 = 0;
 	hipcub::CountingInputIterator<uint32_t> it(0);
 	const int items = (int)(n > 0x7FFFFFFF ? 0x7FFFFFFF : n);
@@ -475,7 +408,7 @@ int filter_block_device(int flag, int delta, uint8_t *d, size_t n, uint8_t *scra
 				return 0;
 			n_items = (ne - 6) / 2;
 		}
-		const size_t cap = n / 8 + 1024;
+		const size_t cap = n + 1024;
 		unsigned long long *d_total = (unsigned long long *)scratch;
 		int *d_count = (int *)(scratch + 64);
 		uint32_t *d_pos = (uint32_t *)(scratch + 256);
@@ -491,13 +424,8 @@ int filter_block_device(int flag, int delta, uint8_t *d, size_t n, uint8_t *scra
 			return -3;
 		if (total == 0)
 			return 0;
-		if (total > cap) { // not machine code: the scan itself
-			if (x86)
-				hipLaunchKernelGGL(k_x86_serial, dim3(1), dim3(1), 0, s, d, n);
-			else
-				hipLaunchKernelGGL(k_rv_serial, dim3(1), dim3(1), 0, s, d, n);
-			break;
-		}
+		if (total > cap)
+			return -2; // (cannot happen: there are no more candidates than positions)
 		hipcub::CountingInputIterator<uint32_t> it(0);
 		hipError_t e;
 		if (x86)

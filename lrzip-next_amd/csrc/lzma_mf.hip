@@ -32,7 +32,6 @@
 #include <cstring>
 
 #include "common.h"
-#include "bt_tiers.h"
 #include "lzma_mf.h"
 #include "pools.h"
 #include "profile.h"
@@ -107,26 +106,22 @@ __global__ void __launch_bounds__(256) k_flag_heads(const uint32_t *__restrict__
 		flags[k] = (k == 0 || skey[k] != skey[k - 1]) ? 1 : 0;
 }
 
-// bucket lengths; n_ge[k] = how many of them have at least tiers.min_len[k] positions (the buckets are sorted by length
-// afterwards, so these counts are the launch boundaries: k_bt_wave from memory, k_bt_wave from LDS by capacity, k_bt)
+// bucket lengths; *n_long = how many of them have at least long_min positions (the buckets are sorted by length
+// afterwards, so that count is the boundary between the two walk kernels: k_bt_wave, k_bt)
 __global__ void __launch_bounds__(256) k_seg_len(const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ nseg_p,
-						 uint32_t n4, uint32_t *__restrict__ seg_len, BtTiers tiers, uint32_t *__restrict__ n_ge)
+						 uint32_t n4, uint32_t *__restrict__ seg_len, uint32_t long_min, uint32_t *__restrict__ n_long)
 {
 	uint32_t nseg = *nseg_p;
 	uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
 	uint32_t stride = gridDim.x * blockDim.x;
-	uint32_t mine[kBtTiers] = {0, 0, 0, 0, 0, 0};
+	uint32_t mine = 0;
 	for (; s < nseg; s += stride) {
 		const uint32_t len = (s + 1 < nseg ? seg_start[s + 1] : n4) - seg_start[s];
 		seg_len[s] = len;
-#pragma unroll
-		for (int k = 0; k < kBtTiers; k++)
-			mine[k] += len >= tiers.min_len[k] ? 1u : 0u;
+		mine += len >= long_min ? 1u : 0u;
 	}
-#pragma unroll
-	for (int k = 0; k < kBtTiers; k++)
-		if (mine[k])
-			atomicAdd(n_ge + k, mine[k]);
+	if (mine)
+		atomicAdd(n_long, mine);
 }
 
 constexpr int kMaxRec = 128; // u32 entries per position: 2 * (2 hash pairs + cut (<= 48)) -> 100
@@ -645,11 +640,8 @@ __device__ __forceinline__ void store_node_coh(BtNode *np, const BtNode &v)
 
 enum : uint32_t { W_IDLE = 0, W_LOAD = 1, W_SONS = 2, W_FINISH = 3, W_OVER = 4 };
 
-// CAP == 0: the tree nodes live in memory (`node`).  CAP > 0: the bucket has at most CAP positions and its nodes live
-// in LDS for the whole launch -- a tree only links positions of one bucket and nothing reads it once the bucket's last
-// position has been walked, so the nodes never reach memory at all: what is left of the kernel's traffic is the bucket's
-// positions and bytes in, its lists out, and a round is an LDS round trip instead of an L2 one.
-template <uint32_t CAP>
+// (Round 3 also kept the tree of buckets of up to 3840 positions in LDS -- k_bt_wave<CAP>: 2.4x less HBM traffic, 4x the
+// time on the bench text; tools/experiments/bt_tree_in_lds.patch has that build and its numbers.)
 __global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src, uint32_t n, uint32_t seg_base,
 						const uint32_t *__restrict__ spos,
 						const uint32_t *__restrict__ seg_len_sorted, const uint32_t *__restrict__ seg_start_sorted,
@@ -662,34 +654,17 @@ __global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src,
 						unsigned long long *__restrict__ stats)
 {
 	__shared__ uint32_t rec_s[kMaxRec][64];
-	__shared__ __attribute__((aligned(32))) uint32_t node_l[CAP ? CAP * 8 : 8];
 	__shared__ uint32_t st_i[64], st_w[5][64], st_c2[64], st_c3[64], st_b[64]; // the staged window of positions
-	// Orders a round's tree stores before the next round's loads.  Tree in memory: a workgroup-scope fence (waits for
-	// every outstanding store of the wave).  Tree in LDS: the LDS operations of ONE wavefront execute in program order,
-	// so the compiler must not move them and that is all -- above all the round does not wait for the global stores of
-	// the lists a finished walk has just written (1.5-2 us each: first build of the LDS kernel, 2.3 us per round).
-	auto tree_fence = [&]() {
-		if constexpr (CAP != 0)
-			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-		else
-			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-	};
+	// Orders a round's tree stores before the next round's loads: a workgroup-scope fence (one wave, one CU; an
+	// agent-scope fence writes the L2 back on this multi-XCD part: 27 us per round instead of 1.9)
+	auto tree_fence = [&]() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); };
 	const uint32_t lane = threadIdx.x;
 	const uint64_t lt_mask = ((uint64_t)1 << lane) - 1;
 	const uint32_t k0 = seg_start_sorted[seg_base + blockIdx.x];
 	const uint32_t L = seg_len_sorted[seg_base + blockIdx.x];
-	if (CAP && L > CAP) { // (the host sorts buckets into launches by length: cannot happen)
-		*err = 3;
-		return;
-	}
 	const uint32_t cyc_size = dict + 1;
 	// slot (x, side) = word 8 * x + side of the node array, x = sorted index
-	auto word_at = [&](uint32_t idx) -> uint32_t * {
-		if constexpr (CAP != 0)
-			return node_l + (idx - 8 * k0);
-		else
-			return reinterpret_cast<uint32_t *>(node) + idx;
-	};
+	auto word_at = [&](uint32_t idx) -> uint32_t * { return reinterpret_cast<uint32_t *>(node) + idx; };
 	auto node_at = [&](uint32_t x) -> BtNode * { return reinterpret_cast<BtNode *>(word_at(8 * x)); };
 	uint32_t stage_base = 0, stage_end = 0, stage_prev = 0; // wave-uniform: the window, and the position before it
 	uint32_t pd_c2 = 0, pd_c3 = 0, pd_bytes = 0;            // the walk's h2 / h3 candidates
@@ -1245,27 +1220,8 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 	int *d_err = (int *)((unsigned long long *)w->scalars + 3);           // [3]
 	EventTimer t_all(s);
 	EventTimer *t_bt = nullptr;
-	// second stream of the LRZGPU_BT_OVERLAP experiment; goes back to the pool idle on every way out
-	struct Fork {
-		hipStream_t s2 = nullptr;
-		hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-		bool drained = false; // the caller's stream waited for s2's last launch and was itself synchronised
-		~Fork()
-		{
-			if (s2 && !drained)
-				(void)hipStreamSynchronize(s2);
-			if (ev_fork)
-				(void)hipEventDestroy(ev_fork);
-			if (ev_join)
-				(void)hipEventDestroy(ev_join);
-			if (s2)
-				StreamPool::get().give(s2);
-		}
-	} fork;
-	hipStream_t &s2 = fork.s2;
-	hipEvent_t &ev_fork = fork.ev_fork, &ev_join = fork.ev_join;
 	HIPCHK(hipMemsetAsync(w->scalars, 0, 128, s));
-	uint32_t *d_nge = (uint32_t *)((unsigned long long *)w->scalars + 8); // [8..10]: kBtTiers bucket counts
+	uint32_t *d_nlong = (uint32_t *)((unsigned long long *)w->scalars + 8); // [8]: buckets for the wave-per-bucket kernel
 	*total_entries = 0;
 	if (n == 0)
 		return 0;
@@ -1329,80 +1285,25 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 			const long v = atol(e);                      // pipelined kernel) and a huge value (none) inside one process
 			long_min = (uint32_t)(v < 1 ? 1 : (v > 0x7FFFFFFF ? 0x7FFFFFFF : v));
 		}
-		// shorter ones down to this many positions get a wavefront each and keep their tree in LDS (k_bt_wave<CAP>, the
-		// launch by the capacity that holds them); the rest a lane each (k_bt).  Unset / 0: no LDS launches.
-		uint32_t lds_min = 0;
-		if (const char *e = getenv("LRZGPU_BT_LDS_MIN")) {
-			const long v = atol(e);
-			lds_min = (uint32_t)(v < 0 ? 0 : (v > 0x7FFFFFFF ? 0x7FFFFFFF : v));
-		}
-		// launch k (k >= 1) takes the buckets of tiers.min_len[k] .. tiers.min_len[k - 1] - 1 positions (bt_tiers.h)
-		const BtLaunchPlan plan = bt_plan_launches(long_min, lds_min);
-		const BtTiers &tiers = plan.tiers;
-		const uint32_t *lds_cap = plan.lds_cap;
-		const int ntier = plan.n;
-		hipLaunchKernelGGL(k_seg_len, dim3(g), dim3(256), 0, s, w->seg_start, d_nseg, n4, w->seg_len, tiers, d_nge);
-		uint32_t sc[22] = {0};
-		HIPCHK(d2h_pageable(sc, d_nseg, 88, s)); // nseg at [0], the tier counts at [12..]  (sleeps while the sorts run)
+		hipLaunchKernelGGL(k_seg_len, dim3(g), dim3(256), 0, s, w->seg_start, d_nseg, n4, w->seg_len, long_min, d_nlong);
+		uint32_t sc[14] = {0};
+		HIPCHK(d2h_pageable(sc, d_nseg, 56, s)); // nseg at [0], the long buckets at [12]  (sleeps while the sorts run)
 		const uint32_t nseg = sc[0];
-		uint32_t bound[kBtTiers];
-		for (int k = 0; k < ntier; k++) {
-			bound[k] = sc[12 + k] > nseg ? nseg : sc[12 + k];
-			if (k && bound[k] < bound[k - 1])
-				bound[k] = bound[k - 1];
-		}
-		const uint32_t nlong = bound[0], nwave = bound[ntier - 1];
+		const uint32_t nlong = sc[12] > nseg ? nseg : sc[12], nwave = nlong;
 		// longest buckets first
 		tb = w->cub_bytes;
 		HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(w->cub_tmp, tb, w->seg_len, w->seg_len_s, w->seg_start,
 								    w->seg_start_s, (int)nseg, 0, 32, s));
 		const uint32_t chunk = pool_chunk(w->pool_cap, (unsigned long long)nwave + (nseg - nwave + 63) / 64);
 		t_bt = new EventTimer(s);
-		// (experiment: LRZGPU_BT_OVERLAP=1 puts the wave-per-bucket launches on a second stream beside k_bt: they
-		//  work on different buckets and share only the pool cursor, an atomic)
-		hipStream_t sw = s;
-		if (getenv("LRZGPU_BT_OVERLAP") && nwave && nseg > nwave) {
-			s2 = pooled_stream();
-			if (s2 && hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) == hipSuccess &&
-			    hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) == hipSuccess) {
-				HIPCHK(hipEventRecord(ev_fork, s));
-				HIPCHK(hipStreamWaitEvent(s2, ev_fork, 0));
-				sw = s2;
-			}
-		}
-#define LRZGPU_BT_WAVE_ARGS(base)                                                                                                \
-	d_src, (uint32_t)n, (uint32_t)(base), w->spos, w->seg_len_s, w->seg_start_s, (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, \
-		w->counts, w->tmp_start, w->pool_tmp, d_cursor, w->pool_cap, chunk, d_err, (unsigned long long *)w->scalars + 4
 		if (nlong)
-			hipLaunchKernelGGL(k_bt_wave<0>, dim3(nlong), dim3(64), 0, sw, LRZGPU_BT_WAVE_ARGS(0));
-		for (int k = 1; k < ntier; k++) {
-			const uint32_t cnt = bound[k] - bound[k - 1];
-			if (!cnt)
-				continue;
-			switch (lds_cap[k]) {
-			case 3840: hipLaunchKernelGGL(k_bt_wave<3840>, dim3(cnt), dim3(64), 0, sw, LRZGPU_BT_WAVE_ARGS(bound[k - 1])); break;
-			case 2048: hipLaunchKernelGGL(k_bt_wave<2048>, dim3(cnt), dim3(64), 0, sw, LRZGPU_BT_WAVE_ARGS(bound[k - 1])); break;
-			case 1024: hipLaunchKernelGGL(k_bt_wave<1024>, dim3(cnt), dim3(64), 0, sw, LRZGPU_BT_WAVE_ARGS(bound[k - 1])); break;
-			case 512: hipLaunchKernelGGL(k_bt_wave<512>, dim3(cnt), dim3(64), 0, sw, LRZGPU_BT_WAVE_ARGS(bound[k - 1])); break;
-			default: hipLaunchKernelGGL(k_bt_wave<256>, dim3(cnt), dim3(64), 0, sw, LRZGPU_BT_WAVE_ARGS(bound[k - 1])); break;
-			}
-		}
-#undef LRZGPU_BT_WAVE_ARGS
-		// (experiment: LRZGPU_BT_PAD_LDS = bytes of unused dynamic LDS per k_bt wavefront, i.e. fewer of them per CU --
-		//  fewer buckets in flight, a smaller set of tree tops competing for the L2)
-		unsigned bt_pad = 0;
-		if (const char *e = getenv("LRZGPU_BT_PAD_LDS")) {
-			const long v = atol(e);
-			bt_pad = (unsigned)(v < 0 ? 0 : (v > 30720 ? 30720 : v));
-		}
+			hipLaunchKernelGGL(k_bt_wave, dim3(nlong), dim3(64), 0, s, d_src, (uint32_t)n, 0u, w->spos, w->seg_len_s, w->seg_start_s,
+					   (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, w->counts, w->tmp_start, w->pool_tmp, d_cursor,
+					   w->pool_cap, chunk, d_err, (unsigned long long *)w->scalars + 4);
 		if (nseg > nwave)
-			hipLaunchKernelGGL(k_bt, dim3((nseg - nwave + 63) / 64), dim3(64), bt_pad, s, d_src, (uint32_t)n, w->spos, w->seg_len_s,
+			hipLaunchKernelGGL(k_bt, dim3((nseg - nwave + 63) / 64), dim3(64), 0, s, d_src, (uint32_t)n, w->spos, w->seg_len_s,
 					   w->seg_start_s, d_nseg, nwave, (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, w->counts,
 					   w->tmp_start, w->pool_tmp, d_cursor, w->pool_cap, chunk, d_err);
-		if (sw != s) { // join: everything behind this point on `s` follows both
-			HIPCHK(hipEventRecord(ev_join, s2));
-			HIPCHK(hipStreamWaitEvent(s, ev_join, 0));
-		}
 		t_bt->stop();
 	}
 	{
@@ -1429,7 +1330,6 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 			ps.p.mf_wave_dbg[k] += (int64_t)host_sc[4 + k];
 	}
 	delete t_bt;
-	fork.drained = true; // `s` waited for s2's last launch (the join) and has been drained by the copy above
 	int err = (int)(host_sc[3] & 0xFFFFFFFFu);
 	if (err == 1)
 		return -4; // pool too small

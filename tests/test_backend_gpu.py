@@ -231,38 +231,3 @@ def test_match_lists_with_forced_bucket_kernels(B, O, wave_min):
             os.environ["LRZGPU_BT_WAVE_MIN"] = old
 
 
-@pytest.mark.parametrize("lds_min", ["1", "300", "1500"])
-def test_match_lists_with_lds_resident_buckets(B, O, lds_min):
-    """LRZGPU_BT_LDS_MIN=m: buckets of m..3840 positions are walked by k_bt_wave<CAP> with their tree nodes in LDS (one
-    launch per capacity 256 / 512 / 1024 / 2048 / 3840), longer ones by k_bt_wave<0> from memory, shorter ones by k_bt.
-    The text mixes vocabularies of 60..5000 words so that every capacity gets buckets (about 0.4-1.4 M positions each);
-    the other cases put runs, two-symbol data and a small dictionary (cut-off inside walks) through the same launches."""
-    import os
-    old = os.environ.get("LRZGPU_BT_LDS_MIN")
-    os.environ["LRZGPU_BT_LDS_MIN"] = lds_min
-    try:
-        rng = np.random.default_rng(12)
-        tiers = (datagen.text_alnum(1200000, seed=6, nwords=400) + datagen.text_alnum(1000000, seed=7, nwords=150) +
-                 datagen.text_alnum(800000, seed=8, nwords=60) + datagen.text_alnum(500000, seed=9, nwords=5000))
-        cases = [
-            (tiers, 1 << 25, 64),
-            (tiers[:1500000], 1 << 16, 32),
-            (datagen.text_like(600000, seed=31), 1 << 25, 64),
-            (bytes(rng.integers(0, 2, 200000, dtype=np.uint8)), 1 << 25, 64),
-            (datagen.phrase_mix(500000, seed=33), 1 << 16, 32),
-            (datagen.text_like(3000, seed=34) + bytes(3000) + datagen.text_like(3000, seed=35) + b"\x07" * 2500 + b"ab" * 1800 + bytes(200000), 1 << 25, 64),
-            (b"abcabcabd" * 30000, 1 << 12, 64),
-        ]
-        for n in (0, 1, 3, 4, 5, 63, 64, 65, 129, 1000):
-            cases.append((datagen.KINDS["few"](n, seed=n + 1), 1 << 25, 64))
-        for data, dict_size, fb in cases:
-            cut = 16 + fb // 2
-            oc, op = _lists_from_oracle(O, data, dict_size, fb, cut)
-            gc, gp = B.lzma_match_lists(data, dict_size=dict_size, fb=fb, cut=cut, per_pos=110)
-            assert np.array_equal(gc, oc), (lds_min, len(data), dict_size)
-            assert np.array_equal(gp, op), (lds_min, len(data), dict_size)
-    finally:
-        if old is None:
-            del os.environ["LRZGPU_BT_LDS_MIN"]
-        else:
-            os.environ["LRZGPU_BT_LDS_MIN"] = old

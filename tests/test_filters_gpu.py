@@ -46,7 +46,7 @@ def test_device_filters_equal_reference(B, R, flag):
 
 def test_device_x86_histories_and_dense_fallback(B, R):
     """Bursts of opcode / sign bytes between stretches of filler (the candidate-list path with every history and skip
-    case), and inputs of nothing but such bytes (denser than the list allows: the one-thread scan)."""
+    case), and inputs of nothing but such bytes (every position a candidate: one long run)."""
     for seed in range(40):
         rnd = random.Random(seed)
         alphabet = rnd.choice([[0xE8, 0xE9, 0, 0xFF, 1], [0xE8, 0, 0xFF], [0xE8, 0xE9, 0, 0xFF, 0x7F, 0x80, 0xFE, 2], [0xE8, 0xFF]])

@@ -255,64 +255,6 @@ def test_bench_pmc_traffic_is_tied_to_the_kernels_code_object(monkeypatch, tmp_p
     assert bench.pmc_traffic("k_resolve", "w")[0] is None
 
 
-def test_bt_launch_plan_partitions_the_bucket_lengths(tmp_path):
-    """bt_tiers.h (host side of the BT4 finder's dispatch): for every cut-over / LDS threshold, each bucket length
-    belongs to exactly one launch, an LDS launch's capacity holds every length it takes, no LDS launch exists when the
-    switch is off, and the capacities are the ones k_bt_wave is instantiated for."""
-    import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = tmp_path / "plan.cpp"
-    src.write_text(r'''
-#include "bt_tiers.h"
-#include <cstdio>
-using namespace lrzgpu;
-int main()
-{
-	const uint32_t longs[] = {1, 2, 64, 200, 256, 257, 512, 1000, 1024, 1025, 2048, 3000, 3840, 3841, 3842, 4096, 5000, 1000000000u, 0x7FFFFFFFu};
-	const uint32_t ldss[] = {0, 1, 2, 100, 255, 256, 257, 300, 512, 513, 1024, 1500, 2048, 2049, 3840, 3841, 4000, 4096, 100000, 0x7FFFFFFFu};
-	long checked = 0;
-	for (uint32_t lm : longs)
-		for (uint32_t dm : ldss) {
-			const BtLaunchPlan p = bt_plan_launches(lm, dm);
-			if (p.n < 1 || p.n > kBtTiers || p.lds_cap[0] != 0) { printf("bad n %u %u\n", lm, dm); return 1; }
-			for (int k = 1; k < p.n; k++) {
-				if (!(p.tiers.min_len[k] < p.tiers.min_len[k - 1])) { printf("order %u %u\n", lm, dm); return 1; }
-				if (p.lds_cap[k] < p.tiers.min_len[k - 1] - 1) { printf("capacity %u %u k %d\n", lm, dm, k); return 1; }
-				bool known = false;
-				for (uint32_t c : kBtLdsCap) known |= c == p.lds_cap[k];
-				if (!known || (k > 1 && p.lds_cap[k] >= p.lds_cap[k - 1])) { printf("cap set %u %u\n", lm, dm); return 1; }
-				if (p.tiers.min_len[k] < dm) { printf("below the switch %u %u\n", lm, dm); return 1; }
-			}
-			for (int k = p.n; k < kBtTiers; k++)
-				if (p.tiers.min_len[k] != 0xFFFFFFFFu) { printf("tail %u %u\n", lm, dm); return 1; }
-			// off, or a threshold no capacity can hold: exactly the two-kernel dispatch
-			if ((dm == 0 || dm > 3840) && (p.n != 1 || p.tiers.min_len[0] != lm)) { printf("off %u %u\n", lm, dm); return 1; }
-			// lengths the LDS launches must cover: [dm, min(lm, 3841)) when the switch is on and reaches below the cut-over
-			if (dm && dm <= 3840 && dm < p.tiers.min_len[0]) {
-				if (p.tiers.min_len[p.n - 1] != dm && p.n > 1) { printf("floor %u %u\n", lm, dm); return 1; }
-				for (uint32_t len = 1; len <= 5000; len++) {
-					int owner = -1; // -1: the lane kernel
-					for (int k = 0; k < p.n; k++)
-						if (len >= p.tiers.min_len[k]) { owner = k; break; }
-					const bool want_wave = len >= dm;
-					if (want_wave != (owner >= 0)) { printf("owner %u %u len %u\n", lm, dm, len); return 1; }
-					if (owner > 0 && len > p.lds_cap[owner]) { printf("overflow %u %u len %u\n", lm, dm, len); return 1; }
-					if (owner == 0 && len <= 3840 && len < lm && dm <= 3840) { printf("in memory though it fits %u %u len %u\n", lm, dm, len); return 1; }
-					checked++;
-				}
-			}
-		}
-	printf("ok %ld\n", checked);
-	return 0;
-}
-''')
-    exe = tmp_path / "plan"
-    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "lrzip-next_amd", "csrc"), str(src), "-o", str(exe)], check=True)
-    out = subprocess.run([str(exe)], capture_output=True, text=True)
-    assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout
-    assert int(out.stdout.split()[1]) > 100000
-
-
 @pytest.mark.parametrize("level,kind", [(7, "text"), (7, "longrange"), (7, "zeros"), (7, "few"), (5, "phrases"), (3, "text")])
 def test_parser_started_on_a_prefix_of_the_lists(B, O, level, kind):
     """Early start of a block (DESIGN section 5): the parser begins on the lists of the first positions and asks for
