@@ -425,7 +425,22 @@ def main():
     # lrzgpu_compress_sharded_chunks_dev takes one device pointer per owned chunk
     chunk_ptrs = None
     if world > 1:
-        comm, comm_keep = SH.torch_comm(rank, world, dist, torch, comm_dev)
+        # the hand-off's transport: the library's own, in C over RCCL (csrc/shard_rccl.cpp; torch.distributed only
+        # carries the 128-byte unique id and the barriers of the measurement); gloo / LRZGPU_BENCH_TRANSPORT=torch:
+        # the three callbacks over torch.distributed (lrzip-next_amd/sharded.py)
+        transport = os.environ.get("LRZGPU_BENCH_TRANSPORT", "rccl-c" if backend == "nccl" else "torch")
+        comm_close = None
+        if transport == "rccl-c":
+            def bcast_id(uid):
+                t = torch.zeros(128, dtype=torch.uint8, device=comm_dev)
+                if uid is not None:
+                    t.copy_(torch.frombuffer(bytearray(uid), dtype=torch.uint8))
+                dist.broadcast(t, src=0)
+                return bytes(t.cpu().numpy().tobytes())
+            comm, comm_close = SH.rccl_comm(L, rank, world, local_dev, bcast_id)
+            comm_keep = None
+        else:
+            comm, comm_keep = SH.torch_comm(rank, world, dist, torch, comm_dev)
         if rank != 0:
             mine = {}
             for k in range(rank, n_chunks, world):
@@ -603,7 +618,7 @@ def main():
                            [(nm, round(role_cpu[i] / steps, 1)) for i, nm in enumerate(("encoders (parser + range coder)", "gpu workers", "scanners", "whole-input hash", "reader"))] +
                            [("everything else (committer, Python, HIP runtime threads)", round((cpu_s - sum(role_cpu)) / steps, 1))]),
                        "parallelism": ("%d chunks scanned concurrently on 1 GPU" % n_chunks) if world == 1 else
-                                      ("chunk k -> GPU k mod %d, chunk images handed to rank 0 over %s send/recv" % (world, "RCCL" if backend == "nccl" else backend))},
+                                      ("chunk k -> GPU k mod %d, chunk images handed to rank 0 over %s send/recv" % (world, ("RCCL (C transport, csrc/shard_rccl.cpp)" if transport == "rccl-c" else "RCCL via torch.distributed") if backend == "nccl" else backend))},
             "roofline": roofline, "cpu_baseline": cpu,
             "critical_path": critical_path,
             "value_file_to_file": file_leg,
@@ -617,6 +632,8 @@ def main():
             line["round_trip_ok"] = verified
         print(json.dumps(line), flush=True)
     if world > 1:
+        if comm_close:
+            comm_close()
         dist.destroy_process_group()
     # parked buffers, workspaces and streams go back before the process ends (a profiler wrapped around this
     # command wants to see every queue closed)

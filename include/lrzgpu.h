@@ -174,6 +174,23 @@ int lrzgpu_compress_sharded(lrzgpu_control *control, const uint8_t *in, int64_t 
 int lrzgpu_shard_protocol(lrzgpu_control *control, int64_t n, const lrzgpu_shard_comm *comm, lrzgpu_shard_compress_fn fn,
 			  void *fn_ctx, const uint8_t *digest, uint8_t **out, int64_t *out_len, int64_t *redone);
 
+/* The transport in C over RCCL (csrc/shard_rccl.cpp) -- xGMI between the GPUs of a node; "RCCL over xGMI only for chunk
+ * hand-off" as the path's definition says.  lrzgpu_rccl_comm_create fills a lrzgpu_shard_comm whose three callbacks
+ * are ncclAllReduce on a device copy of the words and ncclSend / ncclRecv through a pair of 32 MiB staging buffers
+ * (pinned host -> staging on a copy stream beside the send of the piece before; the receive of the next piece queued
+ * before a piece is copied out).  Bootstrap as with RCCL itself: rank 0 makes the 128-byte id, the caller carries it to
+ * the other ranks (MPI_Bcast, a file, a TCP store), every rank creates its communicator on its own device.  RCCL is
+ * taken from the process at run time (dlopen librccl.so.1); without it these return LRZGPU_E_NODEVICE.  A failed call
+ * aborts the communicator (ncclCommAbort), which fails the peers' pending calls: the abortable transport the protocol
+ * asks for.  lrzgpu_rccl_loopback: self test of the staging / send / receive path on one rank (grouped send + receive to
+ * itself). */
+#define LRZGPU_RCCL_ID_BYTES 128
+int lrzgpu_rccl_available(void);
+int lrzgpu_rccl_unique_id(uint8_t id[LRZGPU_RCCL_ID_BYTES]);
+int lrzgpu_rccl_comm_create(const uint8_t id[LRZGPU_RCCL_ID_BYTES], int rank, int world, int device, lrzgpu_shard_comm *comm);
+int lrzgpu_rccl_comm_destroy(lrzgpu_shard_comm *comm);
+int lrzgpu_rccl_loopback(lrzgpu_shard_comm *comm, const void *src, void *dst, int64_t n);
+
 /* ---- stream layer, compress side: src/include/stream.h:14-32 kept call for call ---------------------
  * For a caller that produces the two rzip streams itself (the reference's hash_search() through
  * put_header/put_literal/put_match, src/rzip.c:184-265): the same functions with the same argument lists,

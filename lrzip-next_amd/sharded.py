@@ -1,4 +1,5 @@
-"""One file across one process per GPU -- the TRANSPORT half only.
+"""One file across one process per GPU -- the TRANSPORT half only (and since round 4 only the fall-back and test
+transport: bench.py --gpus N hands the chunks off through the library's own RCCL transport in C, rccl_comm() below).
 
 The protocol (chunk k -> rank k mod world, the victim_round chain check and redo, the chunk hand-off to rank 0, the
 layout of the one .lrz) lives in the library behind the C ABI (csrc/shard.cpp: lrzgpu_compress_sharded*,
@@ -64,3 +65,24 @@ def torch_comm(rank, world, dist, torch, device, piece=1 << 30):
 
     cbs = (ALLREDUCE(allreduce), SEND(send), RECV(recv))
     return ShardComm(None, rank, world, *cbs), cbs
+
+
+def rccl_comm(lib, rank, world, device, bcast_id):
+    """lrzgpu_shard_comm over the library's own RCCL transport (csrc/shard_rccl.cpp): ncclAllReduce / ncclSend /
+    ncclRecv in C, no Python on the hand-off.  bcast_id(bytes or None) -> bytes carries rank 0's 128-byte unique id to
+    every rank (the caller's bootstrap).  Returns (ShardComm, close); raises RuntimeError when RCCL cannot be used."""
+    if not lib.lrzgpu_rccl_available():
+        raise RuntimeError("no librccl in this process")
+    uid = None
+    if rank == 0:
+        raw = (C.c_ubyte * 128)()
+        rc = lib.lrzgpu_rccl_unique_id(raw)
+        if rc:
+            raise RuntimeError("lrzgpu_rccl_unique_id rc=%d" % rc)
+        uid = bytes(raw)
+    uid = bcast_id(uid)
+    comm = ShardComm()
+    rc = lib.lrzgpu_rccl_comm_create((C.c_ubyte * 128).from_buffer_copy(uid), rank, world, device, C.byref(comm))
+    if rc:
+        raise RuntimeError("lrzgpu_rccl_comm_create rc=%d" % rc)
+    return comm, (lambda: lib.lrzgpu_rccl_comm_destroy(C.byref(comm)))

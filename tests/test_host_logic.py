@@ -310,3 +310,17 @@ def test_parser_started_on_the_lists_of_a_prefix_run(B, O, kind):
             rc, got = B.lzma_encode_with_lists_staged(data, counts, lists, P - fb - 4, level=level, dict_size=dict_size, fb=fb,
                                                       list_format=fmt, early_counts=pcounts, early_pairs=plists)
             assert rc == 0 and got == want, (P, fmt)
+
+
+def test_rccl_transport_entry_points_check_their_arguments(B):
+    """csrc/shard_rccl.cpp on a box without a GPU: the library loads (RCCL is dlopen'd, not linked), the entry points
+    exist and refuse bad arguments before touching a device."""
+    import ctypes as C
+    L = B.lib()
+    assert L.lrzgpu_rccl_available() in (0, 1)
+    assert L.lrzgpu_rccl_unique_id(None) == -101  # LRZGPU_E_PARAM
+    raw = (C.c_ubyte * 128)()
+    assert L.lrzgpu_rccl_comm_create(raw, 2, 2, 0, None) == -101
+    assert L.lrzgpu_rccl_comm_create(raw, 2, 2, 0, raw) == -101  # rank outside the world
+    assert L.lrzgpu_rccl_comm_destroy(None) == -101
+    assert L.lrzgpu_rccl_loopback(None, None, None, 0) == -101
