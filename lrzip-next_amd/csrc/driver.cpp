@@ -280,6 +280,8 @@ struct Job {
 	bool full_requested = false; // the scan has completed the block: the next finder run is the last
 	bool full_ready = false;     // whole-block lists and bytes on the host, gate agreed
 	bool refused = false;        // the gate said no after an optimistic start: stored
+	bool probed = false;         // the first part of the block went through the lz4 gate (a hint: is an early start worth it?)
+	bool declined = false;       // ... and looked incompressible: no finder run before the block is complete
 	int64_t stage_want = 0;      // bytes of the block gathered so far
 	int64_t stage_done = 0;      // prefix the last finished finder run covered
 	int64_t valid = 0;           // positions whose lists on the host are final
@@ -771,7 +773,21 @@ struct Pipeline {
 			bool compressible = true;
 			double tw1 = now_s(), tw2 = tw1;
 			const double tw0 = tw1;
-			if (!j->cancelled && (full || P - (int64_t)lp.fb - 4 > from)) {
+			// The gate's verdict is taken for granted when a block is started early; on data it refuses (random bytes:
+			// BASELINE configs[4]) that would be a finder run and an encoder per block for nothing.  So the first part of
+			// the block goes through the gate once, as a hint: if lz4 finds nothing in it, the block waits for its
+			// completion like any other (the verdict that counts is the one on the whole block, as ever).
+			if (!full && !j->cancelled && sz.lz4_test && !j->probed) {
+				j->probed = true;
+				int pct = lrzgpu_lz4_compresses_dev(d_blk, P, sz.threshold, device);
+				if (pct < 0)
+					return pct;
+				j->declined = pct == 0;
+				if (tracing_events())
+					fprintf(stderr, "ev %.3f %s chunk %d stream 1 off %lld len %lld\n", now_s() - g_trace_t0, j->declined ? "probe_no" : "probe_yes",
+						j->chunk->index, (long long)j->ref.off, (long long)P);
+			}
+			if (!j->cancelled && (full || (!j->declined && P - (int64_t)lp.fb - 4 > from))) {
 				if (!j->bytes.p)
 					j->bytes.alloc((size_t)n, want_pinned && n >= (1 << 20));
 				if (!j->counts.p)
@@ -1045,14 +1061,17 @@ struct Pipeline {
 		for (Job *j : jobs) {
 			j->cancelled = true;
 			// an early block no encoder has taken yet leaves the queues here (the encoders may all be busy for seconds);
-			// one that is in a finder run is ended by its worker, one that is with an encoder by the encoder
-			if (j->early && j->enc_offered && !j->with_encoder && !j->finished) {
-				for (size_t i = 0; i < enc_queue.size(); i++)
-					if (enc_queue[i] == j) {
-						enc_queue.erase(enc_queue.begin() + (long)i);
-						j->enc_offered = false;
-						break;
-					}
+			// one that is in a finder run is ended by its worker, one that is with an encoder by the encoder.  A block
+			// that was never offered to the encoders (its first part looked incompressible to the gate, or its first
+			// finder run has not happened yet) and sits in no queue between two stages has nobody else to end it.
+			if (j->early && !j->with_encoder && !j->finished) {
+				if (j->enc_offered)
+					for (size_t i = 0; i < enc_queue.size(); i++)
+						if (enc_queue[i] == j) {
+							enc_queue.erase(enc_queue.begin() + (long)i);
+							j->enc_offered = false;
+							break;
+						}
 				if (!j->enc_offered) {
 					if (j->queued) {
 						for (size_t i = 0; i < gpu_queue.size(); i++)
@@ -1925,6 +1944,36 @@ int Run::run()
 	scan_slots = ctl->scan_slots > 0 ? ctl->scan_slots : 8;
 	if ((size_t)scan_slots > mine.size())
 		scan_slots = mine.empty() ? 1 : (int)mine.size();
+	// Every GPU worker owns a finder workspace of ~240 bytes per byte of the largest block, for the whole run: with the
+	// 134 MB blocks of a 32 GiB chunk that is 32 GB each, and eight of them beside the chunk (input copy + stream 1) do
+	// not fit 288 GB.  So: as many workers as fit what the device has left beside the chunks in flight (at least one; the
+	// output does not depend on the number).  Parked pool memory counts as free (it is given back on demand).
+	if (!P.sz.zstd && !P.sz.no_compress && in.n > 0) {
+		size_t in_flight = 0;
+		for (int k : mine) {
+			const size_t c = (size_t)chunks[(size_t)k]->size;
+			if (c > in_flight)
+				in_flight = c;
+		}
+		// per scanner: stream 1 of the chunk, a copy of it unless the caller's device buffer can be used in place, ~4 GB
+		// of scan workspace
+		in_flight = (size_t)(scan_slots + (in.dev ? 0 : 1)) * (2 * in_flight + ((size_t)4 << 30));
+		const size_t avail = DeviceBudget::free_now() + WorkspacePool::get().idle_bytes + DevicePool::get().idle_bytes;
+		const size_t per_ws = WorkspacePool::mf_bytes((size_t)P.sz.stream_bufsize, 16.0);
+		if (avail != ~(size_t)0 && per_ws > ((size_t)1 << 30)) { // (small blocks: nothing to bound)
+			const size_t room = avail > in_flight + DeviceBudget::margin() ? avail - in_flight - DeviceBudget::margin() : 0;
+			size_t fit = room / per_ws;
+			if (fit < 1)
+				fit = 1;
+			if ((size_t)P.n_gpu_workers > fit) {
+				if (getenv("LRZGPU_TRACE"))
+					fprintf(stderr, "lrzgpu driver: %d GPU workers asked for, %zu finder workspaces of %zu MiB fit beside the chunks in flight\n",
+						P.n_gpu_workers, fit, per_ws >> 20);
+				P.n_gpu_workers = (int)fit;
+				P.held_limit = (size_t)P.n_encoders + (size_t)P.n_gpu_workers + 2;
+			}
+		}
+	}
 	if (ctl->verbose)
 		fprintf(stderr, "lrzgpu: threads %d bufsize %lld dict %u chunk %lld chunks %zu (%zu here) scanners %d encoders %d gpu workers %d\n",
 			P.sz.threads, (long long)P.sz.stream_bufsize, P.sz.dict_size, (long long)P.sz.max_chunk, chunks.size(), mine.size(),

@@ -106,22 +106,27 @@ __global__ void __launch_bounds__(256) k_flag_heads(const uint32_t *__restrict__
 		flags[k] = (k == 0 || skey[k] != skey[k - 1]) ? 1 : 0;
 }
 
-// bucket lengths; *n_long = how many of them have at least long_min positions (the buckets are sorted by length
-// afterwards, so that count is the boundary between the two walk kernels: k_bt_wave, k_bt)
+// bucket lengths; n_long[0] = how many of them have at least long_min positions, n_long[1] = at least mid_min (the
+// buckets are sorted by length afterwards, so those counts are the boundaries between the walk kernels: k_bt_group<64>,
+// k_bt_group<8>, k_bt)
 __global__ void __launch_bounds__(256) k_seg_len(const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ nseg_p,
-						 uint32_t n4, uint32_t *__restrict__ seg_len, uint32_t long_min, uint32_t *__restrict__ n_long)
+						 uint32_t n4, uint32_t *__restrict__ seg_len, uint32_t long_min, uint32_t mid_min,
+						 uint32_t *__restrict__ n_long)
 {
 	uint32_t nseg = *nseg_p;
 	uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
 	uint32_t stride = gridDim.x * blockDim.x;
-	uint32_t mine = 0;
+	uint32_t mine = 0, mid = 0;
 	for (; s < nseg; s += stride) {
 		const uint32_t len = (s + 1 < nseg ? seg_start[s + 1] : n4) - seg_start[s];
 		seg_len[s] = len;
 		mine += len >= long_min ? 1u : 0u;
+		mid += len >= mid_min ? 1u : 0u;
 	}
 	if (mine)
 		atomicAdd(n_long, mine);
+	if (mid)
+		atomicAdd(n_long + 1, mid);
 }
 
 constexpr int kMaxRec = 128; // u32 entries per position: 2 * (2 hash pairs + cut (<= 48)) -> 100
@@ -367,6 +372,32 @@ __device__ __forceinline__ unsigned long long wave_take(WaveAlloc &a, uint32_t c
 	return st;
 }
 
+// Match records of the walk in progress, one column per lane, in dynamic LDS sized for the launch's `cut`: a walk visits
+// at most `cut` nodes and every visit adds at most one (length, distance) record, so cut pairs per lane are enough --
+// 4-byte distances and 2-byte lengths (<= 273): 18 KB per wavefront at the cut of 48 of levels 7-9 instead of the 32 KB of
+// a fixed 128-entry column, i.e. seven wavefronts per CU where LDS allowed four (k_bt_group) or five (k_bt).
+struct RecColumns {
+	uint32_t *dist; // [pair][64]
+	uint16_t *len;  // [pair][64]
+	__device__ __forceinline__ void put(uint32_t pair, uint32_t lane, uint32_t l, uint32_t d) const
+	{
+		dist[pair * 64 + lane] = d;
+		len[pair * 64 + lane] = (uint16_t)l;
+	}
+	// entry k of the list as the finder writes it out: even = length, odd = distance - 1
+	__device__ __forceinline__ uint32_t entry(uint32_t k, uint32_t lane) const { return (k & 1) ? dist[(k >> 1) * 64 + lane] : len[(k >> 1) * 64 + lane]; }
+};
+static inline size_t rec_lds_bytes(uint32_t cut) { return (size_t)(cut < 1 ? 1 : cut) * 64 * 6; }
+__device__ __forceinline__ RecColumns rec_columns(uint32_t cut)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t rec_lds_raw[];
+	const uint32_t pairs = cut < 1 ? 1 : cut;
+	RecColumns r;
+	r.dist = reinterpret_cast<uint32_t *>(rec_lds_raw);
+	r.len = reinterpret_cast<uint16_t *>(rec_lds_raw + (size_t)pairs * 64 * 4);
+	return r;
+}
+
 // ---- short buckets: one lane per bucket ---------------------------------------------------------------------------
 // The lane replays its bucket's positions in order.  Match records are collected in LDS (one column per lane), output
 // space comes from wave_take().  The loop over the bucket is wave-uniform (lanes whose bucket is done idle along), so
@@ -382,7 +413,7 @@ __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint
 					   uint32_t *__restrict__ pool, unsigned long long *__restrict__ cursor,
 					   unsigned long long pool_cap, uint32_t chunk, int *__restrict__ err)
 {
-	__shared__ uint32_t rec_s[kMaxRec][64];
+	const RecColumns rec = rec_columns(cut);
 	const uint32_t lane = threadIdx.x;
 	const uint32_t g = first_seg + blockIdx.x * blockDim.x + threadIdx.x;
 	const bool have = g < *nseg_p;
@@ -454,8 +485,7 @@ __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint
 				me.son0 = run_s0;
 				me.son1 = run_s1;
 				node[self] = me;
-				rec_s[0][lane] = fb;
-				rec_s[1][lane] = 0;
+				rec.put(0, lane, fb, 0);
 				nrec = 2;
 			} else {
 				run_ok = false;
@@ -477,8 +507,7 @@ __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint
 					const uint32_t len = agree_len(N.w, me.w, cur, pb, len0 < len1 ? len0 : len1, len_limit);
 					if (max_len < len) {
 						max_len = len;
-						rec_s[nrec][lane] = len;
-						rec_s[nrec + 1][lane] = delta - 1;
+						rec.put(nrec >> 1, lane, len, delta - 1);
 						nrec += 2;
 						if (len == len_limit) {
 							*ptr1 = N.son0;
@@ -526,7 +555,7 @@ __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint
 				}
 			}
 			prev = pos;
-			nmix = mix_from(D, pos, dict, nrec != 0, nrec ? rec_s[1][lane] : 0, mix);
+			nmix = mix_from(D, pos, dict, nrec != 0, nrec ? rec.entry(1, lane) : 0, mix);
 		}
 		const uint32_t cnt = nmix + nrec;
 		const unsigned long long st = wave_take(wa, cnt, cursor);
@@ -540,7 +569,7 @@ __global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint
 					uint32_t *o = pool + st;
 					put_mix(o, mix, nmix);
 					for (uint32_t k = 0; k < nrec; k++)
-						o[nmix + k] = rec_s[k][lane];
+						o[nmix + k] = rec.entry(k, lane);
 				}
 			}
 		}
@@ -642,54 +671,118 @@ enum : uint32_t { W_IDLE = 0, W_LOAD = 1, W_SONS = 2, W_FINISH = 3, W_OVER = 4 }
 
 // (Round 3 also kept the tree of buckets of up to 3840 positions in LDS -- k_bt_wave<CAP>: 2.4x less HBM traffic, 4x the
 // time on the bench text; tools/experiments/bt_tree_in_lds.patch has that build and its numbers.)
-__global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src, uint32_t n, uint32_t seg_base,
-						const uint32_t *__restrict__ spos,
-						const uint32_t *__restrict__ seg_len_sorted, const uint32_t *__restrict__ seg_start_sorted,
-						BtNode *node,
-						const uint32_t *__restrict__ prev2, const uint32_t *__restrict__ prev3,
-						uint32_t dict, uint32_t fb, uint32_t cut,
-						uint8_t *__restrict__ counts, uint64_t *__restrict__ tmp_start,
-						uint32_t *__restrict__ pool, unsigned long long *__restrict__ cursor,
-						unsigned long long pool_cap, uint32_t chunk, int *__restrict__ err,
-						unsigned long long *__restrict__ stats)
+//
+// k_bt_group<G>: G lanes of a wavefront per bucket, 64 / G buckets per wavefront (round 4).  G = 64 is the kernel
+// above word for word (one wavefront per bucket, for the few buckets of 4096 positions and more).  What the measured
+// pipeline depth said -- 7 node visits retire per round whatever the number of lanes -- is that 56 of a wavefront's 64
+// lanes wait; and what bounds the lane-per-bucket kernel k_bt is its longest lane (a bucket of 4000 positions is a
+// serial chain of ~48 000 dependent node loads).  So the middle of the distribution (on text: 70 % of a block's
+// positions sit in buckets of 1024 - 4095) gets EIGHT lanes per bucket: the same pipelined walk, marks and all, with
+// everything that was wave-uniform (next position to start, the staged window, run handling) uniform per group of G
+// lanes instead -- ballots masked to the group, one staged window of G positions per group -- and the output allocator
+// still one prefix sum over the wavefront.  A bucket then moves ~4-5 times faster than on one lane at an eighth of a
+// wavefront.
+template <int G>
+__global__ void __launch_bounds__(64) k_bt_group(const uint8_t *__restrict__ src, uint32_t n, uint32_t seg_base, uint32_t seg_end,
+						 const uint32_t *__restrict__ spos,
+						 const uint32_t *__restrict__ seg_len_sorted, const uint32_t *__restrict__ seg_start_sorted,
+						 BtNode *node,
+						 const uint32_t *__restrict__ prev2, const uint32_t *__restrict__ prev3,
+						 uint32_t dict, uint32_t fb, uint32_t cut,
+						 uint8_t *__restrict__ counts, uint64_t *__restrict__ tmp_start,
+						 uint32_t *__restrict__ pool, unsigned long long *__restrict__ cursor,
+						 unsigned long long pool_cap, uint32_t chunk, int *__restrict__ err,
+						 unsigned long long *__restrict__ stats)
 {
-	__shared__ uint32_t rec_s[kMaxRec][64];
-	__shared__ uint32_t st_i[64], st_w[5][64], st_c2[64], st_c3[64], st_b[64]; // the staged window of positions
+	static_assert(G == 64 || G == 32 || G == 16 || G == 8 || G == 4, "lanes per bucket");
+	constexpr int NG = 64 / G;
+	const RecColumns rec = rec_columns(cut);
+	__shared__ uint32_t st_i[64], st_w[5][64], st_c2[64], st_c3[64], st_b[64]; // the staged windows: G positions per group
 	// Orders a round's tree stores before the next round's loads: a workgroup-scope fence (one wave, one CU; an
 	// agent-scope fence writes the L2 back on this multi-XCD part: 27 us per round instead of 1.9)
 	auto tree_fence = [&]() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); };
 	const uint32_t lane = threadIdx.x;
-	const uint64_t lt_mask = ((uint64_t)1 << lane) - 1;
-	const uint32_t k0 = seg_start_sorted[seg_base + blockIdx.x];
-	const uint32_t L = seg_len_sorted[seg_base + blockIdx.x];
+	const uint32_t grp = lane / G, gl = lane % G, gshift = grp * G;
+	const uint64_t full_g = G == 64 ? ~(uint64_t)0 : (((uint64_t)1 << (G & 63)) - 1);
+	const uint64_t gmask = full_g << gshift;                       // the lanes of this lane's group
+	const uint64_t lt_mask = (((uint64_t)1 << lane) - 1) & gmask;  // ... of those, the ones below this lane
+	const uint32_t bucket = seg_base + blockIdx.x * NG + grp;
+	const bool have = bucket < seg_end;
+	const uint32_t k0 = have ? seg_start_sorted[bucket] : 0;
+	const uint32_t L = have ? seg_len_sorted[bucket] : 0;
 	const uint32_t cyc_size = dict + 1;
 	// slot (x, side) = word 8 * x + side of the node array, x = sorted index
 	auto word_at = [&](uint32_t idx) -> uint32_t * { return reinterpret_cast<uint32_t *>(node) + idx; };
 	auto node_at = [&](uint32_t x) -> BtNode * { return reinterpret_cast<BtNode *>(word_at(8 * x)); };
-	uint32_t stage_base = 0, stage_end = 0, stage_prev = 0; // wave-uniform: the window, and the position before it
+	uint32_t stage_base = 0, stage_end = 0, stage_prev = 0; // group-uniform: the window, and the position before it
 	uint32_t pd_c2 = 0, pd_c3 = 0, pd_bytes = 0;            // the walk's h2 / h3 candidates
-	// stage the 64 positions of the bucket from `from` on (every lane loads one; called by the whole wave)
-	auto restage = [&](uint32_t from) {
+	// The next window of a group is fetched AHEAD, one level of its chain of dependent loads (place -> prefix and h2 / h3
+	// candidates -> the candidates' bytes) per round, issued beside the round's node loads: when the window in use runs
+	// out, the next one is in registers and staging it costs no memory round trip (with G = 8 a window lasts ~16 rounds
+	// and eight groups share a wavefront: loading it on the spot -- three round trips -- stalled every second round)
+	PosData pf{};
+	uint32_t pf_base = 0xFFFFFFFFu, pf_stage = 0; // group-uniform: the window pf is for; 0 nothing, 1 place, 2 + prefix, candidates, 3 whole
+	auto prefetch_step = [&]() {
+		const uint32_t want = stage_end; // (the next window starts where this one ends)
+		if (want >= L) {
+			pf_stage = 0;
+			return;
+		}
+		const uint32_t q = want + gl;
+		if (pf_base != want || pf_stage == 0) {
+			pf = PosData{};
+			pf_base = want;
+			if (q < L)
+				pf.i = spos[k0 + q];
+			pf_stage = 1;
+		} else if (pf_stage == 1) {
+			if (q < L) {
+				node_prefix(src + pf.i, n - pf.i, pf.w);
+				pf.c2 = prev2[pf.i];
+				pf.c3 = prev3[pf.i];
+			}
+			pf_stage = 2;
+		} else if (pf_stage == 2) {
+			if (q < L)
+				pf.bytes = cand_bytes(src, pf.c2, pf.c3);
+			pf_stage = 3;
+		}
+	};
+	// stage the G positions of the bucket from `from` on for the groups that `need` it (every lane of such a group
+	// holds or loads one; called by the whole wave)
+	auto restage = [&](bool need, uint32_t from) {
 		tree_fence(); // (the readers of the old window are done)
-		PosData d{};
-		const uint32_t q = from + lane;
-		if (q < L)
-			load_pos(d, src, n, spos, k0 + q, prev2, prev3);
-		st_i[lane] = d.i;
+		if (need) {
+			PosData d{};
+			uint32_t before; // 1-based position of the bucket's entry before the window (0: none)
+			if (from > stage_base && from == stage_end)
+				before = st_i[gshift + (from - 1 - stage_base)] + 1; // (the old window's last entry)
+			else
+				before = from ? spos[k0 + from - 1] + 1 : 0;
+			if (pf_stage == 3 && pf_base == from)
+				d = pf;
+			else {
+				const uint32_t q = from + gl;
+				if (q < L)
+					load_pos(d, src, n, spos, k0 + q, prev2, prev3);
+			}
+			st_i[lane] = d.i;
 #pragma unroll
-		for (int k = 0; k < 5; k++)
-			st_w[k][lane] = d.w[k];
-		st_c2[lane] = d.c2;
-		st_c3[lane] = d.c3;
-		st_b[lane] = d.bytes;
-		stage_prev = from ? spos[k0 + from - 1] + 1 : 0;
-		stage_base = from;
-		stage_end = from + 64 < L ? from + 64 : L;
+			for (int k = 0; k < 5; k++)
+				st_w[k][lane] = d.w[k];
+			st_c2[lane] = d.c2;
+			st_c3[lane] = d.c3;
+			st_b[lane] = d.bytes;
+			stage_prev = before;
+			stage_base = from;
+			stage_end = from + G < L ? from + G : L;
+			pf_stage = 0;
+		}
 		tree_fence();
 	};
-	restage(0);
+	restage(true, 0);
 	WaveAlloc wa{0, 0, chunk};
-	uint32_t next_j = 0; // wave-uniform: the next position of the bucket that has no walk yet
+	uint32_t next_j = 0; // group-uniform: the next position of the bucket that has no walk yet
 
 	// per-lane walk state
 	uint32_t state = W_IDLE;
@@ -707,18 +800,18 @@ __global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src,
 	for (;;) {
 		st_rounds++;
 		// ---- start walks on free lanes, in bucket order --------------------------------------------------------
-		// (what a walk needs of its position comes from the staged window: 64 positions loaded at once, below)
+		// (what a walk needs of its position comes from its group's staged window: G positions loaded at once)
 		{
 			const bool idle = state == W_IDLE;
-			const uint64_t m = __ballot(idle);
-			if (m) {
+			const uint64_t m = __ballot(idle) & gmask;
+			if (m) { // (group-uniform)
 				const uint32_t rank = (uint32_t)__popcll(m & lt_mask);
 				const uint32_t j = next_j + rank;
 				const uint32_t room = stage_end - next_j; // positions of the staged window not handed out yet
 				if (idle && next_j >= L)
 					state = W_OVER;
 				else if (idle && rank < room && j < L) {
-					const uint32_t q = j - stage_base;
+					const uint32_t q = gshift + (j - stage_base);
 					wj = j;
 					const uint32_t self = k0 + j;
 					i = st_i[q];
@@ -729,7 +822,7 @@ __global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src,
 					pd_c3 = st_c3[q];
 					pd_bytes = st_b[q];
 					pos = i + 1;
-					prev_pos = q ? st_i[q - 1] + 1 : stage_prev;
+					prev_pos = j != stage_base ? st_i[q - 1] + 1 : stage_prev;
 					const uint32_t avail = n - i;
 					len_limit = avail < fb ? avail : fb;
 					cbs = pos < cyc_size ? pos : cyc_size;
@@ -762,9 +855,10 @@ __global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src,
 				if (next_j > L)
 					next_j = L;
 			}
-			// the window is used up: stage the next 64 positions of the bucket
-			if (next_j == stage_end && next_j < L)
-				restage(next_j);
+			// a group's window is used up: stage the next G positions of its bucket
+			const bool need = next_j == stage_end && next_j < L;
+			if (__any(need))
+				restage(need, next_j);
 		}
 		if (__ballot(state != W_OVER) == 0)
 			break;
@@ -772,6 +866,8 @@ __global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src,
 		st_stalls += (state == W_SONS) ? 1u : 0u;
 		// the stores of this round (new nodes, resolved and marked slots) complete before the loads of the next
 		tree_fence();
+		if (G < 64)
+			prefetch_step();
 
 		// ---- one step of every walk -----------------------------------------------------------------------------
 		if (state == W_LOAD || state == W_SONS) {
@@ -797,8 +893,7 @@ __global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src,
 					n_side = 0;
 					if (max_len < len) {
 						max_len = len;
-						rec_s[nrec][lane] = len;
-						rec_s[nrec + 1][lane] = delta - 1;
+						rec.put(nrec >> 1, lane, len, delta - 1);
 						nrec += 2;
 						if (len == len_limit) {
 							n_side = 2;
@@ -827,8 +922,7 @@ __global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src,
 						run_s0 = s0;
 						run_s1 = s1;
 						state = W_FINISH;
-					} else
-						run_hit = run_hit && true; // waits; the verdict stands
+					} // else: waits; the verdict stands
 				} else {
 					const uint32_t next = n_side ? s1 : s0;
 					if (next != kPending) {
@@ -861,21 +955,19 @@ __global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src,
 			}
 		}
 
-		// ---- a run of one byte value at the head of the pipeline: 64 positions per round -------------------------------
+		// ---- a run of one byte value at the head of a group's pipeline: G positions per round ----------------------------
 		// (the walk that found it is the oldest in flight: everything younger stands at its first node, waiting for a
 		//  son of its predecessor, and has written nothing but its own node -- those walks are simply started again)
-		uint32_t run_from = L; // wave-uniform after the ballot below
+		uint32_t run_from = L; // group-uniform after the ballots below
 		{
 			const bool hit = state == W_FINISH && run_hit && len_limit == fb;
-			const uint64_t hm = __ballot(hit);
-			if (hm) {
-				const int src_lane = __ffsll((long long)hm) - 1;
-				const uint32_t hj = __shfl(wj, src_lane);
-				// older walks still in flight?
-				const uint64_t older = __ballot((state == W_LOAD || state == W_SONS || state == W_FINISH) && wj < hj);
-				if (!older && __popcll(hm) == 1)
-					run_from = hj;
-			}
+			const uint64_t hm = __ballot(hit) & gmask;
+			const int src_lane = hm ? __ffsll((long long)hm) - 1 : (int)lane;
+			const uint32_t hj = __shfl(wj, src_lane);
+			// older walks still in flight?
+			const uint64_t older = __ballot(hm != 0 && (state == W_LOAD || state == W_SONS || state == W_FINISH) && wj < hj) & gmask;
+			if (hm && !older && __popcll(hm) == 1)
+				run_from = hj;
 		}
 
 		// ---- finished walks: h2 / h3 candidates, lists out -----------------------------------------------------------------
@@ -889,7 +981,7 @@ __global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src,
 				d.c2 = pd_c2;
 				d.c3 = pd_c3;
 				d.bytes = pd_bytes;
-				nmix = mix_from(d, pos, dict, nrec != 0, nrec ? rec_s[1][lane] : 0, mix);
+				nmix = mix_from(d, pos, dict, nrec != 0, nrec ? rec.entry(1, lane) : 0, mix);
 			}
 			const uint32_t cnt = fin ? nmix + nrec : 0;
 			const unsigned long long st = wave_take(wa, cnt, cursor);
@@ -903,29 +995,31 @@ __global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src,
 						uint32_t *o = pool + st;
 						put_mix(o, mix, nmix);
 						for (uint32_t k = 0; k < nrec; k++)
-							o[nmix + k] = rec_s[k][lane];
+							o[nmix + k] = rec.entry(k, lane);
 					}
 				}
 				state = W_IDLE;
 			}
 		}
 
-		if (run_from != L) {
+		const bool in_run = run_from != L;
+		if (__any(in_run)) {
 			// the lane of walk run_from holds the run's byte and sons
-			const uint64_t om = __ballot(wj == run_from && run_hit);
-			const int ol = __ffsll((long long)om) - 1;
+			const uint64_t om = __ballot(in_run && wj == run_from && run_hit) & gmask;
+			const int ol = om ? __ffsll((long long)om) - 1 : (int)lane;
 			const uint32_t ri = __shfl(i, ol), rs0 = __shfl(run_s0, ol), rs1 = __shfl(run_s1, ol);
-			const uint32_t b = src[ri + fb - 1];
+			const uint32_t b = in_run ? src[ri + fb - 1] : 0;
 			uint32_t t = 0;
-			for (;;) {
-				const uint32_t idx = run_from + 1 + t + lane; // position of the bucket this lane looks at
-				const uint32_t iq = ri + t + 1 + lane;
-				bool ok = idx < L && (unsigned long long)iq + fb <= n;
+			bool going = in_run;
+			while (__any(going)) {
+				const uint32_t idx = run_from + 1 + t + gl; // position of the bucket this lane looks at
+				const uint32_t iq = ri + t + 1 + gl;
+				bool ok = going && idx < L && (unsigned long long)iq + fb <= n;
 				if (ok)
 					ok = spos[k0 + idx] == iq && src[iq + fb - 1] == b;
-				const uint64_t okm = __ballot(ok);
-				const uint32_t m = okm == ~(uint64_t)0 ? 64u : (uint32_t)(__ffsll((long long)~okm) - 1); // leading run of ok lanes
-				const bool mine = lane < m;
+				const uint64_t okm = (__ballot(ok) & gmask) >> gshift;
+				const uint32_t m = okm == full_g ? (uint32_t)G : (uint32_t)(__ffsll((long long)~okm) - 1); // leading run of ok lanes
+				const bool mine = going && gl < m;
 				const unsigned long long st = wave_take(wa, mine ? 2u : 0u, cursor);
 				if (mine) {
 					BtNode rn;
@@ -945,29 +1039,36 @@ __global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src,
 						pool[st + 1] = 0;
 					}
 				}
-				t += m;
-				if (m < 64)
-					break;
+				if (going) {
+					t += m;
+					if (m < (uint32_t)G)
+						going = false;
+				}
 			}
-			// everything younger starts again behind the run
-			next_j = run_from + 1 + t;
-			if (state != W_OVER || next_j < L)
-				state = W_IDLE;
-			run_hit = false;
-			if (next_j < L)
-				restage(next_j);
+			// everything younger of that group starts again behind the run
+			if (in_run) {
+				next_j = run_from + 1 + t;
+				if (state != W_OVER || next_j < L)
+					state = W_IDLE;
+				run_hit = false;
+			}
+			const bool need = in_run && next_j < L;
+			if (__any(need))
+				restage(need, next_j);
 		}
 	}
 	// how the pipeline did (tools/bt_case.py): rounds of this wave, node visits, rounds a walk spent waiting for a son
+	uint32_t st_len = have && gl == 0 ? L : 0;
 	for (int o = 32; o; o >>= 1) {
 		st_steps += __shfl_down(st_steps, o);
 		st_stalls += __shfl_down(st_stalls, o);
+		st_len += __shfl_down(st_len, o);
 	}
 	if (lane == 0) {
 		atomicAdd(stats + 0, (unsigned long long)st_rounds);
 		atomicAdd(stats + 1, (unsigned long long)st_steps);
 		atomicAdd(stats + 2, (unsigned long long)st_stalls);
-		atomicAdd(stats + 3, (unsigned long long)L);
+		atomicAdd(stats + 3, (unsigned long long)st_len);
 	}
 }
 
@@ -980,97 +1081,114 @@ __global__ void __launch_bounds__(64) k_bt_wave(const uint8_t *__restrict__ src,
 // position with the same 10/16-bit hash": all of them come from stable sorts, and, unlike the binary
 // tree, nothing a position does changes what a later one sees.  One thread per position.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_hc5(const uint8_t *__restrict__ src, uint32_t n, const uint32_t *__restrict__ prev2,
-					     const uint32_t *__restrict__ prev3, const uint32_t *__restrict__ prev5, uint32_t dict,
-					     uint32_t fb, uint32_t cut, uint8_t *__restrict__ counts, uint64_t *__restrict__ tmp_start,
-					     uint32_t *__restrict__ pool, unsigned long long *__restrict__ cursor,
-					     unsigned long long pool_cap, int *__restrict__ err)
+// Records live in LDS columns (RecColumns: 2 hash pairs + at most `cut` chain pairs per lane) -- as a register array indexed
+// by a variable they were 288 bytes of scratch memory per lane -- and a wavefront takes its output space with one atomic
+// (prefix sum over the lanes' counts) instead of one per position.
+__global__ void __launch_bounds__(64) k_hc5(const uint8_t *__restrict__ src, uint32_t n, const uint32_t *__restrict__ prev2,
+					    const uint32_t *__restrict__ prev3, const uint32_t *__restrict__ prev5, uint32_t dict,
+					    uint32_t fb, uint32_t cut, uint8_t *__restrict__ counts, uint64_t *__restrict__ tmp_start,
+					    uint32_t *__restrict__ pool, unsigned long long *__restrict__ cursor,
+					    unsigned long long pool_cap, int *__restrict__ err)
 {
+	const RecColumns rec = rec_columns(cut + 2);
+	const uint32_t lane = threadIdx.x;
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n)
-		return;
-	const uint32_t avail = n - i;
+	const uint32_t avail = i < n ? n - i : 0;
 	const uint32_t len_limit = avail < fb ? avail : fb;
-	if (len_limit < 5) // GET_MATCHES_HEADER(5): the position is skipped, no table is touched
-		return;
-	const uint32_t pos = i + 1;
-	const uint8_t *cur = src + i;
-	const uint32_t cbs = dict + 1;
-	const uint32_t mmm = pos < cbs ? pos : cbs; // SET_mmm
-	uint32_t d2 = pos - prev2[i], d3 = pos - prev3[i];
-	uint32_t rec[2 * 2 + 2 * 32];
-	uint32_t nrec = 0;
-	uint32_t max_len = 4;
-	bool chain = true;
-	{
-		bool have = false; // a pair whose length is still to be written sits at rec[nrec-2]
-		if (d2 < mmm && cur[-(int64_t)d2] == cur[0]) {
-			rec[nrec++] = 2;
-			rec[nrec++] = d2 - 1;
-			if (cur[2 - (int64_t)d2] == cur[2]) {
-				have = true;
+	const bool act = len_limit >= 5; // GET_MATCHES_HEADER(5): a position with fewer bytes is skipped, no table is touched
+	uint32_t np = 0;                 // pairs recorded
+	if (act) {
+		const uint32_t pos = i + 1;
+		const uint8_t *cur = src + i;
+		const uint32_t cbs = dict + 1;
+		const uint32_t mmm = pos < cbs ? pos : cbs; // SET_mmm
+		uint32_t d2 = pos - prev2[i], d3 = pos - prev3[i];
+		uint32_t max_len = 4;
+		bool chain = true;
+		{
+			bool have = false; // the last pair's length is still to be written
+			if (d2 < mmm && cur[-(int64_t)d2] == cur[0]) {
+				rec.put(np++, lane, 2, d2 - 1);
+				if (cur[2 - (int64_t)d2] == cur[2]) {
+					have = true;
+				} else if (d3 < mmm && cur[-(int64_t)d3] == cur[0]) {
+					rec.put(np++, lane, 0, d3 - 1);
+					d2 = d3;
+					have = true;
+				}
 			} else if (d3 < mmm && cur[-(int64_t)d3] == cur[0]) {
-				rec[nrec++] = 0;
-				rec[nrec++] = d3 - 1;
+				rec.put(np++, lane, 0, d3 - 1);
 				d2 = d3;
 				have = true;
 			}
-		} else if (d3 < mmm && cur[-(int64_t)d3] == cur[0]) {
-			rec[nrec++] = 0;
-			rec[nrec++] = d3 - 1;
-			d2 = d3;
-			have = true;
-		}
-		if (have) {
-			rec[nrec - 2] = 3;
-			if (cur[3 - (int64_t)d2] == cur[3]) {
-				uint32_t l = max_len; // UPDATE_maxLen: from byte 4 on
-				while (l != len_limit && cur[l - (int64_t)d2] == cur[l])
-					l++;
-				max_len = l;
-				rec[nrec - 2] = max_len;
-				if (max_len == len_limit)
-					chain = false;
+			if (have) {
+				uint32_t l3 = 3;
+				if (cur[3 - (int64_t)d2] == cur[3]) {
+					uint32_t l = max_len; // UPDATE_maxLen: from byte 4 on
+					while (l != len_limit && cur[l - (int64_t)d2] == cur[l])
+						l++;
+					max_len = l;
+					l3 = max_len;
+					if (max_len == len_limit)
+						chain = false;
+				}
+				rec.len[(np - 1) * 64 + lane] = (uint16_t)l3;
 			}
 		}
-	}
-	if (chain) {
-		uint32_t cm = prev5[i], cv = cut;
-		do {
-			if (cm == 0)
-				break;
-			const uint32_t delta = pos - cm;
-			if (delta >= cbs)
-				break;
-			const uint32_t next = prev5[cm - 1]; // the chain link that position stored
-			const uint8_t *pb = cur - delta;
-			if (cur[max_len] == pb[max_len]) {
-				uint32_t len = 0;
-				while (len != len_limit && cur[len] == pb[len])
-					len++;
-				if (len == len_limit) {
-					rec[nrec++] = len_limit;
-					rec[nrec++] = delta - 1;
+		if (chain) {
+			uint32_t cm = prev5[i], cv = cut;
+			do {
+				if (cm == 0)
 					break;
+				const uint32_t delta = pos - cm;
+				if (delta >= cbs)
+					break;
+				const uint32_t next = prev5[cm - 1]; // the chain link that position stored
+				const uint8_t *pb = cur - delta;
+				if (cur[max_len] == pb[max_len]) {
+					uint32_t len = 0;
+					while (len != len_limit && cur[len] == pb[len])
+						len++;
+					if (len == len_limit) {
+						rec.put(np++, lane, len_limit, delta - 1);
+						break;
+					}
+					if (max_len < len) {
+						max_len = len;
+						rec.put(np++, lane, len, delta - 1);
+					}
 				}
-				if (max_len < len) {
-					max_len = len;
-					rec[nrec++] = len;
-					rec[nrec++] = delta - 1;
-				}
-			}
-			cm = next;
-		} while (--cv);
+				cm = next;
+			} while (--cv);
+		}
 	}
-	counts[i] = (uint8_t)nrec;
-	if (nrec) {
-		const unsigned long long st = atomicAdd(cursor, (unsigned long long)nrec);
-		tmp_start[i] = st;
-		if (st + nrec > pool_cap)
-			*err = 1;
-		else
-			for (uint32_t k = 0; k < nrec; k++)
-				pool[st + k] = rec[k];
+	const uint32_t nrec = 2 * np;
+	// output space: one atomic per wavefront
+	uint32_t incl = nrec;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t v = __shfl_up(incl, o);
+		if ((int)lane >= o)
+			incl += v;
+	}
+	const uint32_t total = __shfl(incl, 63);
+	unsigned long long base = 0;
+	if (total) {
+		if (lane == 0)
+			base = atomicAdd(cursor, (unsigned long long)total);
+		base = __shfl(base, 0);
+	}
+	if (act) {
+		counts[i] = (uint8_t)nrec;
+		if (nrec) {
+			const unsigned long long st = base + (incl - nrec);
+			tmp_start[i] = st;
+			if (st + nrec > pool_cap)
+				*err = 1;
+			else
+				for (uint32_t k = 0; k < nrec; k++)
+					pool[st + k] = rec.entry(k, lane);
+		}
 	}
 }
 
@@ -1249,7 +1367,7 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 			HIPCHK(hipcub::DeviceRadixSort::SortPairs(w->cub_tmp, tb, w->key_a, w->key_b, w->val_a, w->val_b, (int)n5, 0, bits, s));
 			hipLaunchKernelGGL(k_link_prev, dim3(g), dim3(256), 0, s, w->key_b, w->val_b, n5, prev5);
 			t_bt = new EventTimer(s);
-			hipLaunchKernelGGL(k_hc5, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_src, (uint32_t)n, w->prev2, w->prev3, prev5, dict, fb,
+			hipLaunchKernelGGL(k_hc5, dim3((unsigned)((n + 63) / 64)), dim3(64), rec_lds_bytes(cut + 2), s, d_src, (uint32_t)n, w->prev2, w->prev3, prev5, dict, fb,
 					   cut, w->counts, w->tmp_start, w->pool_tmp, d_cursor, w->pool_cap, d_err);
 			t_bt->stop();
 		}
@@ -1279,30 +1397,44 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 		tb = w->cub_bytes;
 		HIPCHK(hipcub::DeviceSelect::Flagged(w->cub_tmp, tb, hipcub::CountingInputIterator<uint32_t>(0), w->flags,
 						     w->seg_start, d_nseg, (int)n4, s));
-		// buckets of at least this many positions get a wavefront each and keep their tree in memory (k_bt_wave<0>)
-		uint32_t long_min = 4096;
-		if (const char *e = getenv("LRZGPU_BT_WAVE_MIN")) { // read per call: tests force 1 (every bucket through the
-			const long v = atol(e);                      // pipelined kernel) and a huge value (none) inside one process
-			long_min = (uint32_t)(v < 1 ? 1 : (v > 0x7FFFFFFF ? 0x7FFFFFFF : v));
-		}
-		hipLaunchKernelGGL(k_seg_len, dim3(g), dim3(256), 0, s, w->seg_start, d_nseg, n4, w->seg_len, long_min, d_nlong);
+		// buckets of at least long_min positions get a wavefront each, those of at least mid_min eight lanes (k_bt_group),
+		// the rest one lane (k_bt); read per call: tests force 1 (every bucket through the pipelined kernels) and a huge
+		// value (none) inside one process
+		auto env_u32 = [](const char *name, uint32_t dflt) {
+			if (const char *e = getenv(name)) {
+				const long v = atol(e);
+				return (uint32_t)(v < 1 ? 1 : (v > 0x7FFFFFFF ? 0x7FFFFFFF : v));
+			}
+			return dflt;
+		};
+		const uint32_t long_min = env_u32("LRZGPU_BT_WAVE_MIN", 4096);
+		uint32_t mid_min = env_u32("LRZGPU_BT_GROUP_MIN", 512);
+		if (mid_min > long_min)
+			mid_min = long_min;
+		hipLaunchKernelGGL(k_seg_len, dim3(g), dim3(256), 0, s, w->seg_start, d_nseg, n4, w->seg_len, long_min, mid_min, d_nlong);
 		uint32_t sc[14] = {0};
-		HIPCHK(d2h_pageable(sc, d_nseg, 56, s)); // nseg at [0], the long buckets at [12]  (sleeps while the sorts run)
+		HIPCHK(d2h_pageable(sc, d_nseg, 56, s)); // nseg at [0], the long buckets at [12], long + middle at [13]  (sleeps while the sorts run)
 		const uint32_t nseg = sc[0];
-		const uint32_t nlong = sc[12] > nseg ? nseg : sc[12], nwave = nlong;
+		const uint32_t nlong = sc[12] > nseg ? nseg : sc[12];
+		const uint32_t nmid_end = sc[13] > nseg ? nseg : (sc[13] < nlong ? nlong : sc[13]);
+		const uint32_t ngrp_waves = (nmid_end - nlong + 7) / 8;
 		// longest buckets first
 		tb = w->cub_bytes;
 		HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(w->cub_tmp, tb, w->seg_len, w->seg_len_s, w->seg_start,
 								    w->seg_start_s, (int)nseg, 0, 32, s));
-		const uint32_t chunk = pool_chunk(w->pool_cap, (unsigned long long)nwave + (nseg - nwave + 63) / 64);
+		const uint32_t chunk = pool_chunk(w->pool_cap, (unsigned long long)nlong + ngrp_waves + (nseg - nmid_end + 63) / 64);
 		t_bt = new EventTimer(s);
 		if (nlong)
-			hipLaunchKernelGGL(k_bt_wave, dim3(nlong), dim3(64), 0, s, d_src, (uint32_t)n, 0u, w->spos, w->seg_len_s, w->seg_start_s,
+			hipLaunchKernelGGL(k_bt_group<64>, dim3(nlong), dim3(64), rec_lds_bytes(cut), s, d_src, (uint32_t)n, 0u, nlong, w->spos, w->seg_len_s, w->seg_start_s,
 					   (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, w->counts, w->tmp_start, w->pool_tmp, d_cursor,
 					   w->pool_cap, chunk, d_err, (unsigned long long *)w->scalars + 4);
-		if (nseg > nwave)
-			hipLaunchKernelGGL(k_bt, dim3((nseg - nwave + 63) / 64), dim3(64), 0, s, d_src, (uint32_t)n, w->spos, w->seg_len_s,
-					   w->seg_start_s, d_nseg, nwave, (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, w->counts,
+		if (ngrp_waves)
+			hipLaunchKernelGGL(k_bt_group<8>, dim3(ngrp_waves), dim3(64), rec_lds_bytes(cut), s, d_src, (uint32_t)n, nlong, nmid_end, w->spos, w->seg_len_s,
+					   w->seg_start_s, (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, w->counts, w->tmp_start, w->pool_tmp,
+					   d_cursor, w->pool_cap, chunk, d_err, (unsigned long long *)w->scalars + 4);
+		if (nseg > nmid_end)
+			hipLaunchKernelGGL(k_bt, dim3((nseg - nmid_end + 63) / 64), dim3(64), rec_lds_bytes(cut), s, d_src, (uint32_t)n, w->spos, w->seg_len_s,
+					   w->seg_start_s, d_nseg, nmid_end, (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, w->counts,
 					   w->tmp_start, w->pool_tmp, d_cursor, w->pool_cap, chunk, d_err);
 		t_bt->stop();
 	}

@@ -195,17 +195,19 @@ def test_mf_stream_in_btbuf_format(B, O):
         L.lrzgpu_lzma_mf_close(h)
 
 
-@pytest.mark.parametrize("wave_min", ["1", "64", "1000000000"])
-def test_match_lists_with_forced_bucket_kernels(B, O, wave_min):
-    """The two BT kernels on the same data: LRZGPU_BT_WAVE_MIN=1 sends EVERY bucket through the pipelined
-    wave-per-bucket kernel (k_bt_wave: walks of one bucket in flight together, pending-slot marks, the 64-wide run
-    path), a huge value sends every bucket through the lane-per-bucket kernel (k_bt).  A 5000-word vocabulary gives
-    buckets of 10^4..10^5 positions, a two-symbol alphabet long walks with full-length agreements, runs the bulk path,
-    a small dictionary the window cut-off inside walks."""
-    import os
-    old = os.environ.get("LRZGPU_BT_WAVE_MIN")
-    os.environ["LRZGPU_BT_WAVE_MIN"] = wave_min
-    try:
+@pytest.mark.parametrize("wave_min,group_min", [("1", "1"), ("1000000000", "1"), ("2000", "16"), ("1000000000", "1000000000")])
+def test_match_lists_with_forced_bucket_kernels(B, O, wave_min, group_min, monkeypatch):
+    """The three BT kernels on the same data.  LRZGPU_BT_WAVE_MIN=1 sends EVERY bucket through the pipelined kernel with
+    one wavefront per bucket (k_bt_group<64>: walks of one bucket in flight together, pending-slot marks, the 64-wide run
+    path); LRZGPU_BT_GROUP_MIN=1 under a huge wave minimum sends every bucket through the same kernel with EIGHT lanes
+    per bucket, eight buckets per wavefront (k_bt_group<8>: group-masked ballots, a staged window per group, runs of one
+    byte value eight at a time, groups of one wavefront finishing at different times); 2000 / 16 mixes all three; two
+    huge values send every bucket through the lane-per-bucket kernel (k_bt).  A 5000-word vocabulary gives buckets of
+    10^4..10^5 positions, a two-symbol alphabet long walks with full-length agreements, runs the bulk path, a small
+    dictionary the window cut-off inside walks."""
+    monkeypatch.setenv("LRZGPU_BT_WAVE_MIN", wave_min)
+    monkeypatch.setenv("LRZGPU_BT_GROUP_MIN", group_min)
+    if True:
         rng = np.random.default_rng(11)
         cases = [
             (datagen.text_like(1200000, seed=31), 1 << 25, 64),
@@ -222,12 +224,7 @@ def test_match_lists_with_forced_bucket_kernels(B, O, wave_min):
             cut = 16 + fb // 2
             oc, op = _lists_from_oracle(O, data, dict_size, fb, cut)
             gc, gp = B.lzma_match_lists(data, dict_size=dict_size, fb=fb, cut=cut, per_pos=110)
-            assert np.array_equal(gc, oc), (wave_min, len(data), dict_size)
-            assert np.array_equal(gp, op), (wave_min, len(data), dict_size)
-    finally:
-        if old is None:
-            del os.environ["LRZGPU_BT_WAVE_MIN"]
-        else:
-            os.environ["LRZGPU_BT_WAVE_MIN"] = old
+            assert np.array_equal(gc, oc), (wave_min, group_min, len(data), dict_size)
+            assert np.array_equal(gp, op), (wave_min, group_min, len(data), dict_size)
 
 

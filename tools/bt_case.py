@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Match finder alone on one block of the bench text (GPU): k_bt / k_bt_wave timing per cut-over, pipeline statistics.
-Arguments: MiB, then settings "WAVE_MIN" or "WAVE_MIN,LDS_MIN" (LRZGPU_BT_WAVE_MIN / LRZGPU_BT_LDS_MIN); the lists of
-every setting are compared with the first one's."""
+"""Match finder alone on one block of the bench text (GPU): k_bt / k_bt_group timing per cut-over, pipeline statistics.
+Arguments: MiB, then settings "WAVE_MIN" or "WAVE_MIN,GROUP_MIN" (LRZGPU_BT_WAVE_MIN: buckets from this length on get a
+wavefront; LRZGPU_BT_GROUP_MIN: from this length on eight lanes; below: one lane); the lists of every setting are
+compared with the first one's."""
 import ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -17,7 +18,7 @@ first = None
 for setting in sys.argv[2:] or ["1000000000", "1024"]:
     wm, _, lm = setting.partition(",")
     os.environ["LRZGPU_BT_WAVE_MIN"] = wm
-    os.environ["LRZGPU_BT_LDS_MIN"] = lm or "0"
+    os.environ["LRZGPU_BT_GROUP_MIN"] = lm or wm
     for rep in range(int(os.environ.get("BT_CASE_REPS", "2"))):
         L.lrzgpu_profile_reset()
         t0 = time.time()
@@ -29,5 +30,5 @@ for setting in sys.argv[2:] or ["1000000000", "1024"]:
         first = (gc, gp)
     else:
         print("  lists equal to the first setting's:", bool(np.array_equal(gc, first[0]) and np.array_equal(gp, first[1])))
-    print("wave_min %s: k_bt %.1f ms, finder %.1f ms, wall %.2f s; wave kernel: %d positions, rounds %d, visits %d (%.1f/pos), waits %d, visits/round %.2f"
+    print("wave_min,group_min %s: k_bt %.1f ms, finder %.1f ms, wall %.2f s; pipelined kernels: %d positions, rounds %d, visits %d (%.1f/pos), waits %d, visits/round %.2f"
           % (setting, p.mf_bt_ms, p.mf_total_ms, dt, d[3], d[0], d[1], d[1] / max(d[3], 1), d[2], d[1] / max(d[0], 1)), flush=True)
