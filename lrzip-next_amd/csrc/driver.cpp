@@ -700,7 +700,7 @@ struct Pipeline {
 		}
 		MfWorkspace *ws = nullptr;
 		double ws_per_pos = 0;
-		DevBuf d_stage, d_scratch;
+		DevBuf d_stage, d_scratch, d_probe;
 		uint8_t *stage[2] = {nullptr, nullptr};
 		double per_pos = 16;
 		const size_t bufsize = (size_t)sz.stream_bufsize;
@@ -710,6 +710,7 @@ struct Pipeline {
 			ws = nullptr;
 			d_stage.release();
 			d_scratch.release();
+			d_probe.release();
 			for (int k = 0; k < 2; k++)
 				if (stage[k])
 					(void)hipHostFree(stage[k]);
@@ -778,11 +779,19 @@ struct Pipeline {
 			// the block goes through the gate once, as a hint: if lz4 finds nothing in it, the block waits for its
 			// completion like any other (the verdict that counts is the one on the whole block, as ever).
 			if (!full && !j->cancelled && sz.lz4_test && !j->probed) {
+				// (on this worker's own stream, with its own descriptor: nothing here allocates, nothing waits actively)
 				j->probed = true;
-				int pct = lrzgpu_lz4_compresses_dev(d_blk, P, sz.threshold, device);
-				if (pct < 0)
-					return pct;
-				j->declined = pct == 0;
+				if (!d_probe.p && !d_probe.alloc(256, device))
+					return LRZGPU_E_NOMEM;
+				const int in_len = (int)(P < (int64_t)100 * 1048576 ? P : (int64_t)100 * 1048576);
+				const int below = (int)((double)in_len * ((double)sz.threshold / 100.0));
+				Lz4Job q{d_blk, in_len, in_len + 1, below};
+				int res = 0;
+				if (hipMemcpyAsync(d_probe.p, &q, sizeof(q), hipMemcpyHostToDevice, s) != hipSuccess ||
+				    lz4_sizes_device((const Lz4Job *)d_probe.p, 1, (int *)(d_probe.p + 64), s) != 0 ||
+				    d2h_pageable(&res, d_probe.p + 64, sizeof(int), s) != hipSuccess)
+					return LRZGPU_E_HIP;
+				j->declined = !(res > 0 && res < below);
 				if (tracing_events())
 					fprintf(stderr, "ev %.3f %s chunk %d stream 1 off %lld len %lld\n", now_s() - g_trace_t0, j->declined ? "probe_no" : "probe_yes",
 						j->chunk->index, (long long)j->ref.off, (long long)P);

@@ -402,21 +402,21 @@ __device__ __forceinline__ RecColumns rec_columns(uint32_t cut)
 // The lane replays its bucket's positions in order.  Match records are collected in LDS (one column per lane), output
 // space comes from wave_take().  The loop over the bucket is wave-uniform (lanes whose bucket is done idle along), so
 // that the allocation can be a wave operation; buckets are scheduled by length, a wave's 64 buckets are alike.
-__global__ void __launch_bounds__(64) k_bt(const uint8_t *__restrict__ src, uint32_t n,
-					   const uint32_t *__restrict__ spos,
-					   const uint32_t *__restrict__ seg_len_sorted, const uint32_t *__restrict__ seg_start_sorted,
-					   const uint32_t *__restrict__ nseg_p, uint32_t first_seg,
-					   BtNode *__restrict__ node,
-					   const uint32_t *__restrict__ prev2, const uint32_t *__restrict__ prev3,
-					   uint32_t dict, uint32_t fb, uint32_t cut,
-					   uint8_t *__restrict__ counts, uint64_t *__restrict__ tmp_start,
-					   uint32_t *__restrict__ pool, unsigned long long *__restrict__ cursor,
-					   unsigned long long pool_cap, uint32_t chunk, int *__restrict__ err)
+__device__ __forceinline__ void bt_lane_body(const uint32_t block, const uint8_t *__restrict__ src, uint32_t n,
+					     const uint32_t *__restrict__ spos,
+					     const uint32_t *__restrict__ seg_len_sorted, const uint32_t *__restrict__ seg_start_sorted,
+					     const uint32_t nseg, uint32_t first_seg,
+					     BtNode *__restrict__ node,
+					     const uint32_t *__restrict__ prev2, const uint32_t *__restrict__ prev3,
+					     uint32_t dict, uint32_t fb, uint32_t cut,
+					     uint8_t *__restrict__ counts, uint64_t *__restrict__ tmp_start,
+					     uint32_t *__restrict__ pool, unsigned long long *__restrict__ cursor,
+					     unsigned long long pool_cap, uint32_t chunk, int *__restrict__ err)
 {
 	const RecColumns rec = rec_columns(cut);
 	const uint32_t lane = threadIdx.x;
-	const uint32_t g = first_seg + blockIdx.x * blockDim.x + threadIdx.x;
-	const bool have = g < *nseg_p;
+	const uint32_t g = first_seg + block * 64 + threadIdx.x;
+	const bool have = g < nseg;
 	const uint32_t k0 = have ? seg_start_sorted[g] : 0;
 	const uint32_t L = have ? seg_len_sorted[g] : 0;
 	const uint32_t cyc_size = dict + 1;
@@ -682,22 +682,29 @@ enum : uint32_t { W_IDLE = 0, W_LOAD = 1, W_SONS = 2, W_FINISH = 3, W_OVER = 4 }
 // lanes instead -- ballots masked to the group, one staged window of G positions per group -- and the output allocator
 // still one prefix sum over the wavefront.  A bucket then moves ~4-5 times faster than on one lane at an eighth of a
 // wavefront.
+struct StagedWindows { // G positions per group of a wavefront, one column per lane
+	uint32_t st_i[64], st_w[5][64], st_c2[64], st_c3[64], st_b[64];
+};
 template <int G>
-__global__ void __launch_bounds__(64) k_bt_group(const uint8_t *__restrict__ src, uint32_t n, uint32_t seg_base, uint32_t seg_end,
-						 const uint32_t *__restrict__ spos,
-						 const uint32_t *__restrict__ seg_len_sorted, const uint32_t *__restrict__ seg_start_sorted,
-						 BtNode *node,
-						 const uint32_t *__restrict__ prev2, const uint32_t *__restrict__ prev3,
-						 uint32_t dict, uint32_t fb, uint32_t cut,
-						 uint8_t *__restrict__ counts, uint64_t *__restrict__ tmp_start,
-						 uint32_t *__restrict__ pool, unsigned long long *__restrict__ cursor,
-						 unsigned long long pool_cap, uint32_t chunk, int *__restrict__ err,
-						 unsigned long long *__restrict__ stats)
+__device__ __forceinline__ void bt_group_body(const uint32_t block, StagedWindows &sw, const uint8_t *__restrict__ src, uint32_t n,
+					      uint32_t seg_base, uint32_t seg_end, const uint32_t *__restrict__ spos,
+					      const uint32_t *__restrict__ seg_len_sorted, const uint32_t *__restrict__ seg_start_sorted,
+					      BtNode *node,
+					      const uint32_t *__restrict__ prev2, const uint32_t *__restrict__ prev3,
+					      uint32_t dict, uint32_t fb, uint32_t cut,
+					      uint8_t *__restrict__ counts, uint64_t *__restrict__ tmp_start,
+					      uint32_t *__restrict__ pool, unsigned long long *__restrict__ cursor,
+					      unsigned long long pool_cap, uint32_t chunk, int *__restrict__ err,
+					      unsigned long long *__restrict__ stats, const uint32_t io_min, const uint32_t io_mask)
 {
 	static_assert(G == 64 || G == 32 || G == 16 || G == 8 || G == 4, "lanes per bucket");
 	constexpr int NG = 64 / G;
 	const RecColumns rec = rec_columns(cut);
-	__shared__ uint32_t st_i[64], st_w[5][64], st_c2[64], st_c3[64], st_b[64]; // the staged windows: G positions per group
+	auto &st_i = sw.st_i;
+	auto &st_w = sw.st_w;
+	auto &st_c2 = sw.st_c2;
+	auto &st_c3 = sw.st_c3;
+	auto &st_b = sw.st_b;
 	// Orders a round's tree stores before the next round's loads: a workgroup-scope fence (one wave, one CU; an
 	// agent-scope fence writes the L2 back on this multi-XCD part: 27 us per round instead of 1.9)
 	auto tree_fence = [&]() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); };
@@ -706,7 +713,7 @@ __global__ void __launch_bounds__(64) k_bt_group(const uint8_t *__restrict__ src
 	const uint64_t full_g = G == 64 ? ~(uint64_t)0 : (((uint64_t)1 << (G & 63)) - 1);
 	const uint64_t gmask = full_g << gshift;                       // the lanes of this lane's group
 	const uint64_t lt_mask = (((uint64_t)1 << lane) - 1) & gmask;  // ... of those, the ones below this lane
-	const uint32_t bucket = seg_base + blockIdx.x * NG + grp;
+	const uint32_t bucket = seg_base + block * NG + grp;
 	const bool have = bucket < seg_end;
 	const uint32_t k0 = have ? seg_start_sorted[bucket] : 0;
 	const uint32_t L = have ? seg_len_sorted[bucket] : 0;
@@ -799,9 +806,13 @@ __global__ void __launch_bounds__(64) k_bt_group(const uint8_t *__restrict__ src
 
 	for (;;) {
 		st_rounds++;
+		// Starting walks and writing finished ones out are the long, thinly populated parts of a round (a handful of the
+		// 64 lanes each): they run when enough lanes wait for them, or every few rounds, not in every round.  A finished
+		// walk has resolved its slots already (nothing waits for its lists), an idle lane only lowers the parallelism.
+		bool do_io = (st_rounds & io_mask) == 1 || (uint32_t)__popcll(__ballot(state == W_IDLE || state == W_FINISH)) >= io_min;
 		// ---- start walks on free lanes, in bucket order --------------------------------------------------------
 		// (what a walk needs of its position comes from its group's staged window: G positions loaded at once)
-		{
+		if (do_io) {
 			const bool idle = state == W_IDLE;
 			const uint64_t m = __ballot(idle) & gmask;
 			if (m) { // (group-uniform)
@@ -866,7 +877,7 @@ __global__ void __launch_bounds__(64) k_bt_group(const uint8_t *__restrict__ src
 		st_stalls += (state == W_SONS) ? 1u : 0u;
 		// the stores of this round (new nodes, resolved and marked slots) complete before the loads of the next
 		tree_fence();
-		if (G < 64)
+		if (G < 64 && __any(stage_end < L && !(pf_stage == 3 && pf_base == stage_end)))
 			prefetch_step();
 
 		// ---- one step of every walk -----------------------------------------------------------------------------
@@ -969,9 +980,16 @@ __global__ void __launch_bounds__(64) k_bt_group(const uint8_t *__restrict__ src
 			if (hm && !older && __popcll(hm) == 1)
 				run_from = hj;
 		}
+		const bool in_run = run_from != L;
+		if (__any(in_run))
+			do_io = true; // (the run path below starts every lane of its group again: what is finished goes out first)
+		// a full-length first step that is not taken as a run NOW is never one: a round later the walks behind it may
+		// have moved on (its node's sons are resolved), and a finished walk may wait several rounds for its write-out
+		if (run_hit && state == W_FINISH && !(in_run && wj == run_from))
+			run_hit = false;
 
 		// ---- finished walks: h2 / h3 candidates, lists out -----------------------------------------------------------------
-		{
+		if (do_io) {
 			const bool fin = state == W_FINISH && (run_from == L || wj <= run_from);
 			uint32_t mix[4];
 			uint32_t nmix = 0;
@@ -1002,7 +1020,6 @@ __global__ void __launch_bounds__(64) k_bt_group(const uint8_t *__restrict__ src
 			}
 		}
 
-		const bool in_run = run_from != L;
 		if (__any(in_run)) {
 			// the lane of walk run_from holds the run's byte and sons
 			const uint64_t om = __ballot(in_run && wj == run_from && run_hit) & gmask;
@@ -1070,6 +1087,33 @@ __global__ void __launch_bounds__(64) k_bt_group(const uint8_t *__restrict__ src
 		atomicAdd(stats + 2, (unsigned long long)st_stalls);
 		atomicAdd(stats + 3, (unsigned long long)st_len);
 	}
+}
+
+// One launch for the three ways a bucket is walked, longest buckets first (workgroups are dispatched in index order, so
+// the few wavefront-per-bucket chains -- the launch's critical path -- start at once and the rest of the chip works
+// through the eight-lane groups and the lane-per-bucket waves beside them; as three launches on one stream they ran one
+// after the other: 17.8 + 41.6 + 8.1 ms on a 64 MiB block of the bench text).
+__global__ void __launch_bounds__(64) k_bt_walk(const uint8_t *__restrict__ src, uint32_t n, const uint32_t *__restrict__ spos,
+						const uint32_t *__restrict__ seg_len_sorted, const uint32_t *__restrict__ seg_start_sorted,
+						uint32_t nseg, uint32_t nlong, uint32_t nmid_end, BtNode *node,
+						const uint32_t *__restrict__ prev2, const uint32_t *__restrict__ prev3,
+						uint32_t dict, uint32_t fb, uint32_t cut,
+						uint8_t *__restrict__ counts, uint64_t *__restrict__ tmp_start,
+						uint32_t *__restrict__ pool, unsigned long long *__restrict__ cursor,
+						unsigned long long pool_cap, uint32_t chunk, int *__restrict__ err,
+						unsigned long long *__restrict__ stats, uint32_t io_min, uint32_t io_mask)
+{
+	__shared__ StagedWindows sw;
+	const uint32_t ngrp_waves = (nmid_end - nlong + 7) / 8;
+	if (blockIdx.x < nlong)
+		bt_group_body<64>(blockIdx.x, sw, src, n, 0u, nlong, spos, seg_len_sorted, seg_start_sorted, node, prev2, prev3, dict, fb, cut, counts,
+				  tmp_start, pool, cursor, pool_cap, chunk, err, stats, 1u, 0u);
+	else if (blockIdx.x < nlong + ngrp_waves)
+		bt_group_body<8>(blockIdx.x - nlong, sw, src, n, nlong, nmid_end, spos, seg_len_sorted, seg_start_sorted, node, prev2, prev3, dict, fb, cut,
+				 counts, tmp_start, pool, cursor, pool_cap, chunk, err, stats, io_min, io_mask);
+	else
+		bt_lane_body(blockIdx.x - nlong - ngrp_waves, src, n, spos, seg_len_sorted, seg_start_sorted, nseg, nmid_end, node, prev2, prev3, dict, fb,
+			     cut, counts, tmp_start, pool, cursor, pool_cap, chunk, err);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1424,18 +1468,21 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 								    w->seg_start_s, (int)nseg, 0, 32, s));
 		const uint32_t chunk = pool_chunk(w->pool_cap, (unsigned long long)nlong + ngrp_waves + (nseg - nmid_end + 63) / 64);
 		t_bt = new EventTimer(s);
-		if (nlong)
-			hipLaunchKernelGGL(k_bt_group<64>, dim3(nlong), dim3(64), rec_lds_bytes(cut), s, d_src, (uint32_t)n, 0u, nlong, w->spos, w->seg_len_s, w->seg_start_s,
-					   (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, w->counts, w->tmp_start, w->pool_tmp, d_cursor,
-					   w->pool_cap, chunk, d_err, (unsigned long long *)w->scalars + 4);
-		if (ngrp_waves)
-			hipLaunchKernelGGL(k_bt_group<8>, dim3(ngrp_waves), dim3(64), rec_lds_bytes(cut), s, d_src, (uint32_t)n, nlong, nmid_end, w->spos, w->seg_len_s,
-					   w->seg_start_s, (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, w->counts, w->tmp_start, w->pool_tmp,
-					   d_cursor, w->pool_cap, chunk, d_err, (unsigned long long *)w->scalars + 4);
-		if (nseg > nmid_end)
-			hipLaunchKernelGGL(k_bt, dim3((nseg - nmid_end + 63) / 64), dim3(64), rec_lds_bytes(cut), s, d_src, (uint32_t)n, w->spos, w->seg_len_s,
-					   w->seg_start_s, d_nseg, nmid_end, (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, w->counts,
-					   w->tmp_start, w->pool_tmp, d_cursor, w->pool_cap, chunk, d_err);
+		// the eight-lane kernel starts walks / writes finished ones out when 24 lanes of the wavefront wait for it, at the
+		// latest every 8th round (measured on a 64 MiB block of the bench text: every round 51.2 ms, 12 / 4: 47.8,
+		// 24 / 8: 46.5, 32 / 16: 45.9 -- rounds get cheaper faster than they get more)
+		const uint32_t io_min = 24, io_mask = 8 - 1;
+		const uint32_t nblocks = nlong + ngrp_waves + (nseg - nmid_end + 63) / 64;
+		// LDS per workgroup: the record columns, but never so little that a walk workgroup fits beside a resolver on its CU
+		// (k_resolve_mw<4> holds 136 of the 160 KB; a finder wave sharing its SIMDs is what slowed the scans down when the
+		// wave-per-bucket launches ran beside k_bt in round 3)
+		size_t walk_lds = rec_lds_bytes(cut);
+		if (walk_lds + sizeof(StagedWindows) < ((size_t)26 << 10))
+			walk_lds = ((size_t)26 << 10) - sizeof(StagedWindows);
+		if (nblocks)
+			hipLaunchKernelGGL(k_bt_walk, dim3(nblocks), dim3(64), walk_lds, s, d_src, (uint32_t)n, w->spos, w->seg_len_s, w->seg_start_s,
+					   nseg, nlong, nmid_end, (BtNode *)w->son, w->prev2, w->prev3, dict, fb, cut, w->counts, w->tmp_start, w->pool_tmp,
+					   d_cursor, w->pool_cap, chunk, d_err, (unsigned long long *)w->scalars + 4, io_min, io_mask);
 		t_bt->stop();
 	}
 	{

@@ -112,14 +112,22 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 	const i64 rec_cap = st->rec_cap;
 	i64 inserts = st->inserts, lookups = st->lookups;
 	int error = st->error;
-	i64 dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	// round / stop counters and the profile laps of wave 0: in LDS, bumped by one lane (as sixteen 64-bit values per lane
+	// they were 32 of the 512 registers of a kernel that spills)
+	__shared__ i64 dbg[16];
+	if (threadIdx.x < 16)
+		dbg[threadIdx.x] = 0;
+	auto bump = [&](int slot, i64 by) {
+		if (threadIdx.x == 0)
+			dbg[slot] += by;
+	};
 	u64 tclk = __builtin_amdgcn_s_memtime();
 	const bool prof = (batch_mode & 2) != 0 && master; // shader-clock laps of wave 0 between the barriers of a round
 	auto lap = [&](int slot) {
 		if (!prof)
 			return;
 		const u64 now = __builtin_amdgcn_s_memtime();
-		dbg[slot] += (i64)(now - tclk);
+		bump(slot, (i64)(now - tclk));
 		tclk = now;
 	};
 	i64 miss_acc = 0; // per lane, every wave
@@ -127,7 +135,7 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 
 	// One exact automaton step at candidate (P, T): see k_resolve.
 	auto serial_step = [&](i64 P, u64 T) {
-		dbg[2]++;
+		bump(2, 1);
 		bool again;
 		R.allow_abort = true;
 		do {
@@ -138,7 +146,7 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 			i64 mlen = R.lookup(T, P, &offset, &reverse);
 			if (R.aborted) {
 				lookups--;
-				dbg[2]--;
+				bump(2, -1);
 				R.tag_hits = hits0;
 				R.tag_misses = misses0;
 				if (P - 1 > p_skip)
@@ -784,10 +792,10 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 				n_ev += x_cnt[w2][3];
 			}
 			lookups += n_commit;
-			dbg[0]++;
-			dbg[1] += n_commit;
+			bump(0, 1);
+			bump(1, n_commit);
 			if (f < wcount && why_f >= 3 && why_f <= 7)
-				dbg[why_f]++;
+				bump(why_f, 1);
 			inserts += n_ins;
 			const i64 hc = R.hash_count + n_x;
 			R.hash_count = hc < R.hash_limit ? hc : R.hash_limit;

@@ -894,6 +894,38 @@ __device__ __forceinline__ void simulate_lanes(const Resolver &R, const Slot *__
 						L.hi = (uint32_t)(idx + 63 < tbl_size - 1 ? idx + 63 : tbl_size - 1);
 						fin = true;
 					} else {
+						// The slots whose fingerprint matches are looked at twice below (equal tags in front of the insert's
+						// stop, tag hits in front of the first empty slot), one dependent load after the other: the first three
+						// of them are fetched here, together -- one round trip instead of up to six (a fourth and later
+						// one, rare, is loaded where it is needed)
+						int q0 = -1, q1 = -1, q2 = -1;
+						u64 c0t = 0, c1t = 0, c2t = 0;
+						i64 c0o = 0, c1o = 0, c2o = 0;
+						{
+							u64 Qp = Q;
+							if (Qp) {
+								q0 = __ffsll((long long)Qp) - 1;
+								Qp &= Qp - 1;
+								const Slot c = tbl[idx + q0];
+								c0t = c.t;
+								c0o = c.offset;
+							}
+							if (Qp) {
+								q1 = __ffsll((long long)Qp) - 1;
+								Qp &= Qp - 1;
+								const Slot c = tbl[idx + q1];
+								c1t = c.t;
+								c1o = c.offset;
+							}
+							if (Qp) {
+								q2 = __ffsll((long long)Qp) - 1;
+								const Slot c = tbl[idx + q2];
+								c2t = c.t;
+								c2o = c.offset;
+							}
+						}
+						auto tag_at = [&](int q) -> u64 { return q == q0 ? c0t : q == q1 ? c1t : q == q2 ? c2t : tbl[idx + q].t; };
+						auto off_at = [&](int q) -> i64 { return q == q0 ? c0o : q == q1 ? c1o : q == q2 ? c2o : tbl[idx + q].offset; };
 						u64 Em = E;
 						if (kind < 0 && L.ins) {
 							int from = 0;
@@ -904,7 +936,7 @@ __device__ __forceinline__ void simulate_lanes(const Resolver &R, const Slot *__
 								while (eqb) {
 									const int q = __ffsll((long long)eqb) - 1;
 									eqb &= eqb - 1;
-									if (tbl[idx + q].t != T)
+									if (tag_at(q) != T)
 										continue; // fingerprint false positive
 									if (neq < MAXE)
 										eqs_lds[neq * eqs_stride + w_ticket] = (uint32_t)(idx + q);
@@ -924,7 +956,9 @@ __device__ __forceinline__ void simulate_lanes(const Resolver &R, const Slot *__
 								}
 								if (kind >= 0 || L.complex_ || s1 >= 64)
 									break;
-								const int rv = R.rk[idx + s1]; // just loaded: which kind of stop is it?
+								// the stop's rank byte, from the registers of this step (selects: an indexed array would go to scratch)
+								const u64 rw = s1 < 8 ? r4[0].a : s1 < 16 ? r4[0].b : s1 < 24 ? r4[1].a : s1 < 32 ? r4[1].b : s1 < 40 ? r4[2].a : s1 < 48 ? r4[2].b : s1 < 56 ? r4[3].a : r4[3].b;
+								const int rv = (int)((rw >> (8 * (s1 & 7))) & 0xFF); // which kind of stop is it?
 								const int k1 = rv == 0 ? 0 : rv < nb1 ? 1 : 2;
 								if (!seek_pred) {
 									kind = k1;
@@ -966,11 +1000,10 @@ __device__ __forceinline__ void simulate_lanes(const Resolver &R, const Slot *__
 						while (hm) {
 							const int q = __ffsll((long long)hm) - 1;
 							hm &= hm - 1;
-							const Slot sl = tbl[idx + q];
-							if (sl.t != T)
+							if (tag_at(q) != T)
 								continue; // fingerprint false positive
 							if (nhit < MAXH)
-								hit_lds[nhit * 64 + lane] = sl.offset;
+								hit_lds[nhit * 64 + lane] = off_at(q);
 							else
 								L.complex_ = true;
 							nhit++;

@@ -20,7 +20,7 @@ def pytest_configure(config):
 
 # The two full-size configurations run first: 32 GiB of input + a 34 GB image (and 16 GiB + its decode) want the
 # process's memory as a fresh process has it -- behind 250 other tests the same 32 GiB test took 116 s instead of 74.
-FULL_SIZE_FIRST = ("test_cfg5_full_32gib_random", "test_roundtrip_full_size_cfg3_headline")
+FULL_SIZE_FIRST = ("test_cfg5_full_32gib_random", "test_roundtrip_full_size_cfg3_headline", "test_cfg4_full_10gib_zstd_round_trip")
 
 
 def pytest_collection_modifyitems(config, items):

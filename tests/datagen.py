@@ -114,10 +114,12 @@ def victim_mover(n, hash_index, seed=1, every=65536, count_limit=None):
     return a.tobytes()
 
 
-def source_tree_tar(copies, tree_bytes, seed=1):
+def source_tree_tar(copies, tree_bytes, seed=1, variants=1):
     """BASELINE config 4 shape: an (uncompressed) tar of `copies` copies of one seeded synthetic source tree --
     a few hundred text files of 1..64 KiB (identifiers, punctuation, indentation, newlines) under per-copy
-    directory names, so headers differ and contents repeat at tree distance."""
+    directory names, so headers differ and contents repeat at tree distance.  variants > 1 (the full-size run: the
+    line-by-line generator is slow): only tree_bytes / variants are generated, the rest of the tree are copies of
+    those files under seeded permutations of the alphabet -- different text of the same make."""
     import io
     import tarfile
     rng = np.random.default_rng(seed)
@@ -125,6 +127,8 @@ def source_tree_tar(copies, tree_bytes, seed=1):
     punct = [b"(", b")", b";", b" = ", b", ", b"{", b"}", b"->", b"[i]", b" + ", b"// "]
     files = []
     total = 0
+    tree_bytes_wanted = tree_bytes
+    tree_bytes = tree_bytes // max(1, variants)
     while total < tree_bytes:
         size = int(rng.integers(1024, 65536))
         lines, got = [], 0
@@ -138,6 +142,18 @@ def source_tree_tar(copies, tree_bytes, seed=1):
         body = b"".join(lines)[:size]
         files.append(("src/mod%03d/file%04d.c" % (len(files) // 16, len(files)), body))
         total += size
+    if variants > 1:
+        base = list(files)
+        letters = np.frombuffer(b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789", dtype=np.uint8)
+        for v in range(1, variants):
+            table = np.arange(256, dtype=np.uint8)
+            table[letters] = rng.permutation(letters)
+            tb = table.tobytes()
+            for name, body in base:
+                if total >= tree_bytes_wanted:
+                    break
+                files.append(("src/mod%03d/file%04d.c" % (len(files) // 16, len(files)), body.translate(tb)))
+                total += len(body)
     out = io.BytesIO()
     with tarfile.open(fileobj=out, mode="w", format=tarfile.USTAR_FORMAT) as tf:
         for c in range(copies):

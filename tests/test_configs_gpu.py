@@ -117,3 +117,31 @@ def test_cfg4_2gib_zstd_round_trip(B):
     assert info.chunks == -(-len(data) // (7 * 104857600)) and info.chunks >= 3
     assert got[17] == (6 << 4) + 4 and got[18] == 15
     assert B.decompress_buffer(got) == data
+
+
+def test_cfg4_full_10gib_zstd_round_trip(B):
+    """cfg 4 at FULL size (BASELINE configs[3]): a 10 GiB tar of 40 copies of a 256 MiB synthetic source tree (a sixteenth of it generated line by line, the rest
+    are alphabet permutations of those files), --zstd
+    --zstd-level 15 -w 26 (=> rzip level 6, 4 chunks, zstd blocks through the host libzstd like the reference), host
+    input; the image through the library's decoder gives the input back (every chunk CRC, the MD5 over all of it).  The
+    byte-for-byte comparison with the oracle is test_cfg4_source_tree_tar_zstd15's, at the size the oracle finishes in
+    seconds."""
+    import time
+    t_gen = time.time()
+    data = datagen.source_tree_tar(40, 256 << 20, seed=7, variants=16)
+    t_gen = time.time() - t_gen
+    assert len(data) >= 10 << 30
+    ram = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    ncpu = os.cpu_count()
+    t0 = time.time()
+    got, ctl = B.compress_buffer(data, level=7, threads=ncpu, processors=ncpu, ramsize=ram, window=26, zstd=True, zstd_level=15)
+    dt = time.time() - t0
+    _note("cfg4: %d MiB tar of 40 copies of a 256 MiB synthetic source tree, --zstd --zstd-level 15 -w 26 (rzip level 6), host input: %.1f s = %.1f MB/s, "
+          "image %d bytes; generating the input took %.1f s" % (len(data) >> 20, dt, (len(data) >> 20) / dt, len(got), t_gen))
+    info = B.file_info(got)
+    assert info.chunks == -(-len(data) // (26 * 104857600)) and info.st_size == len(data)
+    assert got[17] == (6 << 4) + 4 and got[18] == 15 and got[19] >> 4 == 6
+    t0 = time.time()
+    back = B.decompress_buffer(got)
+    assert len(back) == len(data) and back == data
+    _note("cfg4: round trip ok (%.1f s)" % (time.time() - t0))

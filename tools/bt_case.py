@@ -16,9 +16,10 @@ data = bench.text_like_torch(mib << 20, 1, torch.device("cuda:0")).cpu().numpy()
 import numpy as np
 first = None
 for setting in sys.argv[2:] or ["1000000000", "1024"]:
-    wm, _, lm = setting.partition(",")
+    f = setting.split(",")
+    wm, lm = f[0], (f[1] if len(f) > 1 else f[0])
     os.environ["LRZGPU_BT_WAVE_MIN"] = wm
-    os.environ["LRZGPU_BT_GROUP_MIN"] = lm or wm
+    os.environ["LRZGPU_BT_GROUP_MIN"] = lm
     for rep in range(int(os.environ.get("BT_CASE_REPS", "2"))):
         L.lrzgpu_profile_reset()
         t0 = time.time()
