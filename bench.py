@@ -437,9 +437,21 @@ def main():
                     t.copy_(torch.frombuffer(bytearray(uid), dtype=torch.uint8))
                 dist.broadcast(t, src=0)
                 return bytes(t.cpu().numpy().tobytes())
-            comm, comm_close = SH.rccl_comm(L, rank, world, local_dev, bcast_id)
+            try:
+                comm, comm_close = SH.rccl_comm(L, rank, world, local_dev, bcast_id)
+                ok = 1
+            except Exception as e:  # (no librccl in the process, communicator refused ...): every rank must take the same way
+                sys.stderr.write("bench.py rank %d: C transport not available (%s)\n" % (rank, e))
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=comm_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if comm_close:
+                    comm_close()
+                    comm_close = None
+                transport = "torch"
             comm_keep = None
-        else:
+        if transport != "rccl-c":
             comm, comm_keep = SH.torch_comm(rank, world, dist, torch, comm_dev)
         if rank != 0:
             mine = {}
@@ -476,8 +488,20 @@ def main():
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     out = ctl = None
+    # per step (rank 0): wall seconds and the accumulated device milliseconds of the two heaviest kernels -- a drift over
+    # the steps of a long run (clocks, temperature) shows here, not only in the average
+    per_step = []
+    snap = Profile()
+    t_prev, r_prev, b_prev, rl_prev = t0, 0.0, 0.0, 0
     for _ in range(args.steps):
         out, ctl = one_step()
+        if rank == 0:
+            L.lrzgpu_profile_get(C.byref(snap))
+            t_now = time.perf_counter()
+            per_step.append({"s": round(t_now - t_prev, 3), "k_resolve_ms": round(snap.resolve_ms - r_prev, 1),
+                             "k_resolve_avg_launch_ms": round((snap.resolve_ms - r_prev) / max(1, snap.resolve_launches - rl_prev), 1),
+                             "k_bt_ms": round(snap.mf_bt_ms - b_prev, 1)})
+            t_prev, r_prev, b_prev, rl_prev = t_now, snap.resolve_ms, snap.mf_bt_ms, snap.resolve_launches
     fence()
     dt = time.perf_counter() - t0
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
@@ -556,6 +580,7 @@ def main():
                     "launches_per_step": round(launches / steps, 1),
                     "algorithmic_bytes_per_launch": int(alg_bytes / max(launches, 1)),
                     "per_kernel_ms_per_step": {k: round(v[0] / steps, 2) for k, v in kernels.items()},
+                    "per_step": per_step,
                     "per_kernel_GBps": {k: (round(v[2] / (v[0] * 1e-3) / 1e9, 3) if v[0] > 0 else 0.0)
                                         for k, v in kernels.items()},
                     # launches of one kernel run side by side (a resolver per chunk, a finder per GPU slot): the sums

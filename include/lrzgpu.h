@@ -81,9 +81,14 @@ typedef struct lrzgpu_control {
 	/* results (appended) */
 	uint8_t hash_full[64];      /* the whole digest of hash_code (hash_resblock keeps its first 16 bytes)       */
 	int fd_out;                 /* control->fd_out: where lrzgpu_write_1g() / lrzgpu_put_fdout() write (read side)  */
-	int backoff_would_apply;    /* lrzgpu_plan(): 1 when limit + overhead x threads exceeds what this host can give --
-	                               the reference would then shrink `limit` in 10 % steps (src/stream.c:1291-1305),
-	                               which this library does not model                                            */
+	int backoff_would_apply;    /* out: open_stream_out() probes malloc(limit + overhead x threads) and takes a tenth off
+	                               `limit` -- hence the block size -- for as long as the host refuses (retest_malloc,
+	                               src/stream.c:1290-1305).  malloc_probe == 0: the blocks are sized as if the first probe
+	                               succeeded and this says whether this host would have refused it (1 / 0);
+	                               malloc_probe == 1: the number of tenths really taken off                              */
+	int malloc_probe;           /* in: 1 = make that probe for real, like the reference (block sizes then depend on what
+	                               this process may allocate: address-space rlimit, overcommit policy); 0 (default) =
+	                               sizes are a function of the parameters alone                                          */
 } lrzgpu_control;
 
 void lrzgpu_control_init(lrzgpu_control *c); /* initialise_control() defaults, src/lrzip.c:1813-1857 */

@@ -23,7 +23,7 @@ class Control(C.Structure):
                 ("scan_slots", C.c_int), ("eof", C.c_int),
                 ("hash_code", C.c_int), ("filter_flag", C.c_int), ("delta", C.c_int), ("stdin_mode", C.c_int),
                 ("stdout_mode", C.c_int), ("hash_full", C.c_uint8 * 64), ("fd_out", C.c_int),
-                ("backoff_would_apply", C.c_int)]
+                ("backoff_would_apply", C.c_int), ("malloc_probe", C.c_int)]
 
 
 class ScanStats(C.Structure):
@@ -428,7 +428,7 @@ def lzma_compress(data: bytes, level=7, dict_size=1 << 25, fb=64, lc=3, lp=0, pb
 def make_control(level=7, rzip_level=0, threads=1, processors=1, ramsize=80 * 100 * 1048576, window=0, dict_size=0,
                  no_compress=False, lz4_test=True, threshold=100, nobemt=False, device=0, host_threads=0,
                  gpu_slots=0, verbose=0, zstd=False, zstd_level=0, scan_slots=0, hash_code=None, filter_flag=None,
-                 delta=0, stdin_mode=False, stdout_mode=False):
+                 delta=0, stdin_mode=False, stdout_mode=False, malloc_probe=False):
     c = Control()
     lib().lrzgpu_control_init(C.byref(c))
     c.compression_level = level
@@ -454,6 +454,7 @@ def make_control(level=7, rzip_level=0, threads=1, processors=1, ramsize=80 * 10
         c.delta = delta
     c.stdin_mode = 1 if stdin_mode else 0
     c.stdout_mode = 1 if stdout_mode else 0
+    c.malloc_probe = 1 if malloc_probe else 0
     return c
 
 

@@ -2553,7 +2553,7 @@ extern "C" int lrzgpu_plan(lrzgpu_control *control, int64_t st_size, int64_t *ch
 	control->dictSize_used = s.dict_size;
 	control->threads_used = s.threads;
 	control->st_size = st_size;
-	control->backoff_would_apply = host_would_refuse(s.malloc_test) ? 1 : 0;
+	control->backoff_would_apply = control->malloc_probe ? s.backoff_steps : (host_would_refuse(s.malloc_test) ? 1 : 0);
 	if (chunk_size)
 		*chunk_size = s.max_chunk < st_size ? s.max_chunk : st_size;
 	return 0;

@@ -1,4 +1,5 @@
 // stream_layer.cpp -- see stream_layer.h.  Host-only logic, no device code.
+#include <cstdlib>
 #include "stream_layer.h"
 
 #include <atomic>
@@ -148,10 +149,24 @@ int compute_sizing(const lrzgpu_control *c, int64_t st_size, Sizing *out, int64_
 		limit = st_size > STREAM_BUFSIZE ? st_size : STREAM_BUFSIZE;
 	else if (limit > chunk_limit)
 		limit = chunk_limit;
-	// (the reference shrinks `limit` by 10% steps while malloc(limit + overhead*threads) fails;
-	//  that host-dependent retry is not modelled: the allocation is assumed to succeed -- lrzgpu_plan() reports
-	//  when this host would refuse it)
+	// retest_malloc, src/stream.c:1290-1305: the reference asks the host for limit + overhead * threads bytes and takes a
+	// tenth off `limit` for as long as malloc() refuses -- so its block size depends on what the process may allocate
+	// (address-space rlimit, overcommit policy).  With control->malloc_probe the same probe is made here, the same
+	// steps, the same "cannot even get 100 MB" failure; without it the first probe is taken to succeed (sizes are then a
+	// function of the parameters alone; lrzgpu_plan() says when this host would have refused).  (The pointer is
+	// volatile: a malloc / free pair with no use in between is something compilers delete.)
 	s.malloc_test = limit + s.overhead * s.threads;
+	while (c->malloc_probe) {
+		void *volatile probe = malloc((size_t)(limit + s.overhead * s.threads));
+		if (probe) {
+			free(probe);
+			break;
+		}
+		limit = limit / 10 * 9;
+		s.backoff_steps++;
+		if (limit < 100000000)
+			return LRZGPU_E_NOMEM;
+	}
 	if (lzma && limit / s.threads > STREAM_BUFSIZE) {
 		int64_t a = s.overhead - (int64_t)s.dict_size;
 		s.stream_bufsize = round_up_page((limit > a ? limit : a) / s.threads);

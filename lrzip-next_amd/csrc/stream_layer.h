@@ -31,7 +31,8 @@ struct Sizing {
 	int64_t max_chunk = 0;    // rzip chunk size
 	int64_t max_mmap = 0;     // control->max_mmap: the chunk size of STDIN mode (src/rzip.c:1046, 1075)
 	int threshold = 100;
-	int64_t malloc_test = 0;  // limit + overhead * threads: what open_stream_out() tries to malloc (src/stream.c:1292)
+	int64_t malloc_test = 0;  // limit + overhead * threads: what open_stream_out() tries to malloc first (src/stream.c:1292)
+	int backoff_steps = 0;    // times a tenth was taken off `limit` because the host refused that (src/stream.c:1293-1303)
 };
 
 // Everything the reference derives from (flags, -p, -m, -w, file size) before the first chunk.  st_size is what

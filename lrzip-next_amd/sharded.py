@@ -77,10 +77,10 @@ def rccl_comm(lib, rank, world, device, bcast_id):
     if rank == 0:
         raw = (C.c_ubyte * 128)()
         rc = lib.lrzgpu_rccl_unique_id(raw)
-        if rc:
-            raise RuntimeError("lrzgpu_rccl_unique_id rc=%d" % rc)
-        uid = bytes(raw)
+        uid = bytes(raw) if rc == 0 else bytes(128)  # (all zero = "rank 0 has none": the others must not wait for ever)
     uid = bcast_id(uid)
+    if uid == bytes(128):
+        raise RuntimeError("rank 0 could not make a unique id")
     comm = ShardComm()
     rc = lib.lrzgpu_rccl_comm_create((C.c_ubyte * 128).from_buffer_copy(uid), rank, world, device, C.byref(comm))
     if rc:

@@ -346,6 +346,18 @@ static int make_plan(const lrzo_params *prm, i64 n, struct plan_out *po)
 			limit = n > STREAM_BUFSIZE ? n : STREAM_BUFSIZE;
 		else if (limit > chunk_limit)
 			limit = chunk_limit;
+		/* retest_malloc, src/stream.c:1290-1305: a tenth off `limit` for as long as the host refuses the allocation
+		 * (only when asked for: by default block sizes must not depend on the machine the tests run on) */
+		while (prm->malloc_probe) {
+			void *volatile probe = malloc((size_t)(limit + overhead * d.threads));
+			if (probe) {
+				free(probe);
+				break;
+			}
+			limit = limit / 10 * 9;
+			if (limit < 100000000)
+				return -2;
+		}
 		if (lzma_on && limit / d.threads > STREAM_BUFSIZE) {
 			i64 a = overhead - (i64)d.dict_size;
 			d.bufsize = round_up_page((limit > a ? limit : a) / d.threads);

@@ -135,6 +135,9 @@ typedef struct {
 	int filter_flag;           /* magic[16] value: 0 none, 1..8 BCJ, 128 + code for delta (src/lrzip.c:146-156); with a
 	                              filter the lz4 test is off (src/main.c:858-861) and lrzo_set_filter()'s converter
 	                              runs over every stream-1 block before its back end (src/stream.c:1587-1628) */
+	int malloc_probe;          /* 1: open_stream_out()'s retest_malloc (src/stream.c:1290-1305) made for real -- a tenth off
+	                              `limit` for as long as the host refuses limit + overhead * threads bytes; 0: the first
+	                              probe is taken to succeed (block sizes are a function of the parameters alone) */
 } lrzo_params;
 /* the converter for filter_flag: one stream-1 block in place, from pc 0 / fresh state (the tests bind the
  * reference's own Bra.c / Bra86.c / Delta.c from oracle/_ref here) */

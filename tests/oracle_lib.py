@@ -26,7 +26,8 @@ class Params(C.Structure):
                 ("threads", C.c_int), ("processors", C.c_int), ("ramsize", C.c_int64), ("window", C.c_int64),
                 ("lz4_test", C.c_int), ("threshold", C.c_int), ("nobemt", C.c_int), ("dict_size", C.c_uint32),
                 ("workers", C.c_int), ("verbose", C.c_int), ("zstd", C.c_int), ("zstd_level", C.c_int),
-                ("file_size", C.c_int64), ("stdin_mode", C.c_int), ("stdout_mode", C.c_int), ("filter_flag", C.c_int)]
+                ("file_size", C.c_int64), ("stdin_mode", C.c_int), ("stdout_mode", C.c_int), ("filter_flag", C.c_int),
+                ("malloc_probe", C.c_int)]
 
 
 class FileStats(C.Structure):

@@ -36,13 +36,15 @@ def test_every_block_started_early(B, O, forced, kind):
     """34 MiB in 10 MiB blocks (-p16): three whole blocks started at their first MiB and followed through ~10 finder
     runs each, and a short last block whose early start is withdrawn when the chunk ends (its length, hence the
     encoder's view of it, was a guess).  'random': the gate refuses every literal block AFTER its encoder started."""
-    n = (34 << 20) + 77 if kind != "phrases" else (21 << 20) + 5
+    # (a four-symbol alphabet and 50 repeated phrases make the slowest blocks there are for finder and parser alike: one
+    #  whole block + the short last one of those; three of the others)
+    n = (34 << 20) + 77 if kind not in ("phrases", "few") else (12 << 20) + 5
     data = datagen.KINDS[kind](n, seed=41)
     B.lib().lrzgpu_profile_reset()
     fs = _both(B, O, data, level=7, threads=16, processors=16)
     assert fs.stream_bufsize == 10 << 20
     p = _profile(B)
-    if kind in ("text", "random", "few"):  # (little is matched away: stream 1 really has those blocks)
+    if kind in ("text", "random"):  # (little is matched away: stream 1 really has those three blocks)
         assert p.early_s[2] >= 3 and p.early_s[3] >= 3 * 5, list(p.early_s)
 
 

@@ -3,6 +3,7 @@ import ctypes as C
 import hashlib
 import os
 import re
+import sys
 
 import pytest
 
@@ -80,11 +81,46 @@ def test_plan_equals_oracle_sizing_stdin_stdout(B, O, st_size):
 
 def test_plan_reports_the_malloc_backoff(B):
     """open_stream_out() probes malloc(limit + overhead x threads) and shrinks `limit` while it fails
-    (src/stream.c:1291-1305); the library does not model that and says when this host would refuse the probe."""
+    (src/stream.c:1290-1305); by default the library sizes the blocks as if the first probe succeeded and says when this
+    host would have refused it."""
     c, _ = B.plan(1 << 40, level=9, threads=256, processors=256, ramsize=1 << 60)  # an absurd -m: no host gives that
     assert c.backoff_would_apply == 1
     c, _ = B.plan(10 << 20, level=7, threads=1, processors=1, ramsize=80 * 100 << 20)
     assert c.backoff_would_apply == 0
+
+
+def test_malloc_backoff_under_an_address_space_limit(B, O):
+    """control->malloc_probe = 1, the probe for real: in a child process whose address space is capped (RLIMIT_AS) so that
+    the first probe of the plan is refused, the library and the oracle take the same tenths off `limit` and size the
+    blocks alike; without the cap the same plan takes no step."""
+    import subprocess
+    import textwrap
+    code = textwrap.dedent("""
+        import ctypes, os, resource, sys
+        sys.path.insert(0, %r)
+        from conftest import load_bindings
+        import oracle_lib as O
+        B = load_bindings()
+        O.build()
+        def both(cap):
+            if cap:
+                with open('/proc/self/statm') as f:
+                    vm = int(f.read().split()[0]) * os.sysconf('SC_PAGE_SIZE')
+                resource.setrlimit(resource.RLIMIT_AS, (vm + cap, vm + cap))
+            c, chunk = B.plan(4 << 30, level=7, threads=4, processors=8, ramsize=12 << 30, malloc_probe=True)
+            p = O.Params(); O.lib().lrzo_params_default(ctypes.byref(p))
+            p.compression_level, p.threads, p.processors, p.ramsize, p.malloc_probe = 7, 4, 8, 12 << 30, 1
+            fs = O.FileStats(); rc = O.lib().lrzo_plan(ctypes.byref(p), 4 << 30, ctypes.byref(fs))
+            return c.backoff_would_apply, c.stream_bufsize, fs.stream_bufsize, c.threads_used, fs.threads_used
+        free = both(0)
+        capped = both(3 << 30)
+        print(free, capped)
+        assert free[0] == 0 and free[1] == free[2]
+        assert capped[0] >= 1 and capped[1] == capped[2] and capped[3] == capped[4]
+        assert capped[1] <= free[1]
+    """ % os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
 
 
 def test_container_store_equals_oracle_no_compress(B, O):

@@ -1,5 +1,5 @@
 """Scan-only timing of the resolver with per-phase shader-clock counters (LRZGPU_RESOLVE_PROF=1).
-usage: python tools/resolve_prof.py [MiB]   -- the bench text, one chunk, rzip level 7"""
+usage: python tools/resolve_prof.py [MiB] [text|random]   -- the bench text (or seeded random bytes), one chunk, rzip level 7"""
 import ctypes as C
 import os
 import sys
@@ -13,7 +13,12 @@ import bench
 mib = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 B = bench.load_bindings()
 L = B.lib()
-data = bench.text_like_torch(mib << 20, 12345, "cuda:0").cpu().numpy().tobytes()
+kind = sys.argv[2] if len(sys.argv) > 2 else "text"
+if kind == "random":
+    import numpy as np
+    data = np.random.default_rng(5).integers(0, 256, size=mib << 20, dtype=np.uint8).tobytes()
+else:
+    data = bench.text_like_torch(mib << 20, 12345, "cuda:0").cpu().numpy().tobytes()
 L.lrzgpu_profile_reset()
 t0 = time.time()
 s0, s1, st, crc, vr = B.hash_search(data, level=7)
@@ -21,7 +26,7 @@ dt = time.time() - t0
 p = bench.Profile()
 L.lrzgpu_profile_get(C.byref(p))
 d = [int(v) for v in p.resolve_dbg]
-print("scan %d MiB: wall %.3f s, k_resolve %.1f ms in %d launches, lookups %d inserts %d" % (mib, dt, p.resolve_ms, p.resolve_launches, p.resolve_lookups, p.resolve_inserts))
+print("scan %d MiB %s: wall %.3f s, k_resolve %.1f ms in %d launches, lookups %d inserts %d" % (mib, kind, dt, p.resolve_ms, p.resolve_launches, p.resolve_lookups, p.resolve_inserts))
 names = ("batches", "committed", "serial_steps", "stop_complex", "stop_match", "stop_conflict", "stop_novictim", "stop_sweptrange")
 print(dict(zip(names, d[:8])))
 if os.environ.get("LRZGPU_RESOLVE_PROF") != "1":
