@@ -107,18 +107,6 @@ def test_cfg5_full_32gib_random(B):
         pos += u_len
 
 
-def test_cfg4_2gib_zstd_round_trip(B):
-    """cfg 4 beyond the oracle-compared size: 1.7 GiB tar (36 copies of a 48 MiB tree), --zstd --zstd-level 15 -w 7
-    => 4 chunks, host input."""
-    data = datagen.source_tree_tar(36, 48 << 20, seed=7)
-    ram = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
-    got, ctl = B.compress_buffer(data, level=7, threads=os.cpu_count(), processors=os.cpu_count(), ramsize=ram, window=7, zstd=True, zstd_level=15)
-    info = B.file_info(got)
-    assert info.chunks == -(-len(data) // (7 * 104857600)) and info.chunks >= 3
-    assert got[17] == (6 << 4) + 4 and got[18] == 15
-    assert B.decompress_buffer(got) == data
-
-
 def test_cfg4_full_10gib_zstd_round_trip(B):
     """cfg 4 at FULL size (BASELINE configs[3]): a 10 GiB tar of 40 copies of a 256 MiB synthetic source tree (a sixteenth of it generated line by line, the rest
     are alphabet permutations of those files), --zstd

@@ -40,6 +40,8 @@ def test_every_block_started_early(B, O, forced, kind):
     #  whole block + the short last one of those; three of the others)
     n = (34 << 20) + 77 if kind not in ("phrases", "few") else (12 << 20) + 5
     data = datagen.KINDS[kind](n, seed=41)
+    if kind in ("phrases", "few"):
+        forced.setenv("LRZGPU_EARLY_STEP", str(3 << 20))  # (a finder run on such a prefix takes seconds: four of them, not ten)
     B.lib().lrzgpu_profile_reset()
     fs = _both(B, O, data, level=7, threads=16, processors=16)
     assert fs.stream_bufsize == 10 << 20
