@@ -492,16 +492,18 @@ def main():
     # the steps of a long run (clocks, temperature) shows here, not only in the average
     per_step = []
     snap = Profile()
-    t_prev, r_prev, b_prev, rl_prev = t0, 0.0, 0.0, 0
+    t_prev, r_prev, b_prev, rl_prev, e_prev = t0, 0.0, 0.0, 0, 0.0
+    cpu_snap = (C.c_double * 8)()
     for _ in range(args.steps):
         out, ctl = one_step()
         if rank == 0:
             L.lrzgpu_profile_get(C.byref(snap))
+            L.lrzgpu_profile_cpu(cpu_snap, 0)
             t_now = time.perf_counter()
             per_step.append({"s": round(t_now - t_prev, 3), "k_resolve_ms": round(snap.resolve_ms - r_prev, 1),
                              "k_resolve_avg_launch_ms": round((snap.resolve_ms - r_prev) / max(1, snap.resolve_launches - rl_prev), 1),
-                             "k_bt_ms": round(snap.mf_bt_ms - b_prev, 1)})
-            t_prev, r_prev, b_prev, rl_prev = t_now, snap.resolve_ms, snap.mf_bt_ms, snap.resolve_launches
+                             "k_bt_ms": round(snap.mf_bt_ms - b_prev, 1), "encoders_cpu_s": round(cpu_snap[0] - e_prev, 1)})
+            t_prev, r_prev, b_prev, rl_prev, e_prev = t_now, snap.resolve_ms, snap.mf_bt_ms, snap.resolve_launches, cpu_snap[0]
     fence()
     dt = time.perf_counter() - t0
     ru1 = resource.getrusage(resource.RUSAGE_SELF)

@@ -810,7 +810,7 @@ struct Pipeline {
 						return pct;
 					compressible = pct != 0;
 				}
-				tw1 = now_s();
+				tw1 = tw2 = now_s();
 				if (compressible) {
 					unsigned long long total = 0;
 					int fr = run_finder(d_blk, (size_t)P, full ? 0 : (size_t)n, &total);

@@ -27,12 +27,12 @@ def short(name):
 RAW = "/tmp/lrzgpu_prof_raw"  # raw rocprofv3 output is hundreds of MiB: it never goes under gpurun_out/
 
 
-def run(args, tag):
+def run(args, tag, bench_extra=()):
     d = os.path.join(RAW, tag)
     shutil.rmtree(d, ignore_errors=True)
     os.makedirs(d, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
-    p = subprocess.run(["rocprofv3"] + args + ["-d", d, "-o", tag, "--output-format", "csv", "--"] + BENCH, cwd="/tmp", env=env,
+    p = subprocess.run(["rocprofv3"] + args + ["-d", d, "-o", tag, "--output-format", "csv", "--"] + BENCH + list(bench_extra), cwd="/tmp", env=env,
                        capture_output=True, text=True)
     line = [l for l in p.stdout.splitlines() if l.startswith("{")]
     print("rocprofv3", tag, "rc", p.returncode, "files", sum(len(f) for _, _, f in os.walk(d)), flush=True)
@@ -44,7 +44,9 @@ def run(args, tag):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    d, line = run(["--kernel-trace", "--stats"], TAG + "_kt")
+    # the kernel trace in the driver's command shape: several timed steps (its launch averages are what the driver's line
+    # is compared with); the counter passes take one step each
+    d, line = run(["--kernel-trace", "--stats"], TAG + "_kt", ["--steps", "3"])
     json.dump(line, open(os.path.join(OUT, TAG + "_bench_under_rocprof.json"), "w"), indent=1)
     for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
         rows = list(csv.reader(open(f)))
@@ -78,8 +80,9 @@ def main():
         f = totals[k]["FETCH_SIZE"] * (2 if k in STREAMING else 1)
         kernels[k] = {"launches": launches[k], "bytes_per_launch": (f + totals[k]["WRITE_SIZE"]) * 1024.0 / n,
                       "fetch_correction": 2 if k in STREAMING else 1}
-    # the BT walk is two kernels since round 3 (k_bt_wave: one wavefront per long bucket, k_bt: one lane per short one),
-    # launched together once per block: bench.py's "k_bt" is their sum per finder launch
+    # the BT walk is one launch per finder run since round 4 (k_bt_walk); bench.py calls it "k_bt"
+    if "k_bt_walk" in kernels:
+        kernels["k_bt"] = dict(kernels["k_bt_walk"])
     if "k_bt_wave" in kernels and "k_bt" in kernels:
         n = max(kernels["k_bt"]["launches"], 1)
         kernels["k_bt+k_bt_wave"] = {"launches": kernels["k_bt"]["launches"],
