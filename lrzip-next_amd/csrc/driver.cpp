@@ -1910,7 +1910,7 @@ int Run::run()
 	ctl->dictSize_used = P.sz.dict_size;
 	ctl->threads_used = P.sz.threads;
 	ctl->st_size = in.n;
-	speculate = !getenv("LRZGPU_NO_OVERLAP");
+	speculate = true; // (blocks are released to the back end while their chunk is still being scanned)
 	// early start of blocks.  LRZGPU_EARLY_START: 0 off, 1 (default) while encoders have nothing to
 	// do, 2 every block (tests); LRZGPU_EARLY_STEP: bytes of a block between two finder runs (default 1/16 of a block).
 	// None of it changes the output.
@@ -1927,7 +1927,7 @@ int Run::run()
 			step = 4096;
 		P.early_step = step;
 		P.early_first = step;
-		P.early_split = !getenv("LRZGPU_EARLY_NO_SPLIT");
+		P.early_split = true;
 	}
 
 	// the chunks of the file (src/rzip.c:1041: at least one pass, even for an empty input; STDIN mode: one more,

@@ -57,14 +57,12 @@ def test_levels_started_early(B, O, forced, level):
     _both(B, O, data, level=level, threads=16, processors=16)
 
 
-def test_step_sizes_and_no_split(B, O, forced):
+def test_step_sizes(B, O, forced):
     data = datagen.long_range((26 << 20) + 9, seed=43, base_frac=0.2, mutate_every=70001)
     for step, seg in ((4096, 1 << 16), (300000, 1 << 18), (5 << 20, 1 << 20)):
         forced.setenv("LRZGPU_EARLY_STEP", str(step))
         forced.setenv("LRZGPU_SEG_BYTES", str(seg))
         _both(B, O, data[:(12 << 20) + 3] if step == 4096 else data, level=7, threads=16, processors=16)
-    forced.setenv("LRZGPU_EARLY_NO_SPLIT", "1")
-    _both(B, O, data, level=7, threads=16, processors=16)
 
 
 def test_rollback_of_blocks_started_early(B, O, forced):
