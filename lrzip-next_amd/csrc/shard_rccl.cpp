@@ -18,6 +18,7 @@
 #include <rccl/rccl.h>
 
 #include <cstring>
+#include <ctime>
 #include <mutex>
 #include <new>
 
@@ -78,6 +79,7 @@ struct Transport {
 	uint8_t *stage[2] = {nullptr, nullptr};
 	hipEvent_t in_stage[2] = {nullptr, nullptr};  // the piece is in the staging buffer (copied in / received)
 	hipEvent_t out_stage[2] = {nullptr, nullptr}; // the piece has left it (sent / copied out)
+	hipEvent_t reduced = nullptr;                 // the all-reduce's result is on the device
 	int64_t *d_words = nullptr;
 	size_t d_words_cap = 0;
 	bool broken = false;
@@ -99,6 +101,8 @@ struct Transport {
 			if (out_stage[b])
 				(void)hipEventDestroy(out_stage[b]);
 		}
+		if (reduced)
+			(void)hipEventDestroy(reduced);
 		if (d_words)
 			(void)hipFree(d_words);
 		if (comm_stream)
@@ -116,6 +120,29 @@ struct Transport {
 		return -1;
 	}
 };
+
+// A send / receive whose peer never shows up must not hang the job for ever: waits on the communication streams give up
+// after this long, the communicator is aborted (which fails the peer's pending calls too) and the callback reports an
+// error -- the protocol then ends with LRZGPU_E_IO on this rank.
+constexpr double kPeerTimeoutSeconds = 600.0;
+hipError_t wait_event_bounded(hipEvent_t ev)
+{
+	timespec t0, t;
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	long ns = 30000;
+	for (;;) {
+		const hipError_t q = hipEventQuery(ev);
+		if (q != hipErrorNotReady)
+			return q;
+		clock_gettime(CLOCK_MONOTONIC, &t);
+		if ((double)(t.tv_sec - t0.tv_sec) + 1e-9 * (double)(t.tv_nsec - t0.tv_nsec) > kPeerTimeoutSeconds)
+			return hipErrorNotReady;
+		timespec ts{0, ns};
+		nanosleep(&ts, nullptr);
+		if (ns < 2000000)
+			ns += ns / 4;
+	}
+}
 
 #define HIPOK(x)                   \
 	do {                       \
@@ -146,7 +173,9 @@ int cb_allreduce(void *ctx, int64_t *vals, int count)
 	}
 	HIPOK(hipMemcpyAsync(t->d_words, vals, (size_t)count * 8, hipMemcpyHostToDevice, t->comm_stream));
 	NCCLOK(rccl().AllReduce(t->d_words, t->d_words, (size_t)count, ncclInt64, ncclSum, t->comm, t->comm_stream));
-	HIPOK(d2h_pageable(vals, t->d_words, (size_t)count * 8, t->comm_stream));
+	HIPOK(hipEventRecord(t->reduced, t->comm_stream));
+	HIPOK(wait_event_bounded(t->reduced)); // (sleeps; gives up when a rank never joins)
+	HIPOK(hipMemcpy(vals, t->d_words, (size_t)count * 8, hipMemcpyDeviceToHost));
 	return 0;
 }
 
@@ -194,8 +223,8 @@ int send_to(Transport *t, int dst, const void *buf, int64_t n, bool loop, void *
 			HIPOK(d2h_pageable((uint8_t *)loop_dst + o, t->stage[1], k, t->comm_stream));
 		}
 	}
-	if (!loop)
-		HIPOK(stream_wait(t->comm_stream));
+	if (!loop && np) // (the last piece's send: out_stage of its buffer; the one before it was waited for by the copy stream)
+		HIPOK(wait_event_bounded(t->out_stage[(np - 1) & 1]));
 	return 0;
 }
 
@@ -224,7 +253,7 @@ int cb_recv(void *ctx, int src, void *buf, int64_t n)
 			return -1;
 		// the destination is the caller's (rank 0 lays the .lrz out in malloc'd memory): sleep until the piece is
 		// there, then copy it -- a copy into pageable memory makes the thread spin for what is queued before it
-		HIPOK(event_wait(t->in_stage[b]));
+		HIPOK(wait_event_bounded(t->in_stage[b])); // (sleeps until the piece is there; gives up when the peer never sends)
 		HIPOK(hipMemcpyAsync(dst + o, t->stage[b], k, hipMemcpyDeviceToHost, t->copy_stream));
 		HIPOK(hipEventRecord(t->out_stage[b], t->copy_stream));
 		HIPOK(stream_wait(t->copy_stream));
@@ -284,6 +313,8 @@ extern "C" int lrzgpu_rccl_comm_create(const uint8_t id[LRZGPU_RCCL_ID_BYTES], i
 		};
 		if (hipStreamCreateWithFlags(&t->comm_stream, hipStreamNonBlocking) != hipSuccess ||
 		    hipStreamCreateWithFlags(&t->copy_stream, hipStreamNonBlocking) != hipSuccess)
+			return bail(LRZGPU_E_HIP);
+		if (hipEventCreateWithFlags(&t->reduced, hipEventDisableTiming) != hipSuccess)
 			return bail(LRZGPU_E_HIP);
 		for (int b = 0; b < 2; b++)
 			if (hipMalloc((void **)&t->stage[b], kPiece) != hipSuccess ||
