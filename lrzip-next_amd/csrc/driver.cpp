@@ -174,10 +174,10 @@ static bool tracing()
 
 // LRZGPU_TRACE=2: one line per block milestone (seconds since the run started) for timeline analysis
 static double g_trace_t0 = 0;
+static std::atomic<int> g_trace_events{0}; // read from the environment when a run starts (tests flip it inside one process)
 static bool tracing_events()
 {
-	static int t = (getenv("LRZGPU_TRACE") && atoi(getenv("LRZGPU_TRACE")) >= 2) ? 1 : 0;
-	return t != 0;
+	return g_trace_events.load(std::memory_order_relaxed) != 0;
 }
 #define TRACE_EVENT(what, j)                                                                                                        \
 	do {                                                                                                                        \
@@ -478,8 +478,10 @@ struct Pipeline {
 			// started early: an encoder has the block (or will take it from the queue) and finishes it either way
 			if (compressible)
 				j->full_ready = true;
-			else
+			else {
 				j->refused = true;
+				TRACE_EVENT("refused_late", j);
+			}
 			cv_rest.notify_all();
 			return 0;
 		}
@@ -1990,6 +1992,7 @@ int Run::run()
 
 	t0 = now_s();
 	g_trace_t0 = t0;
+	g_trace_events.store((getenv("LRZGPU_TRACE") && atoi(getenv("LRZGPU_TRACE")) >= 2) ? 1 : 0, std::memory_order_relaxed);
 	P.on_fail = [this] {
 		std::lock_guard<std::mutex> lk(mu);
 		cv.notify_all();

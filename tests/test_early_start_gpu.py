@@ -50,6 +50,24 @@ def test_every_block_started_early(B, O, forced, kind):
         assert p.early_s[2] >= 3 and p.early_s[3] >= 3 * 5, list(p.early_s)
 
 
+def test_gate_refuses_after_the_encoder_started(B, O, forced, capfd):
+    """The verdict of the lz4 gate is taken for granted when a block is started early, after a look at its first part:
+    blocks of 64 KiB of text followed by random bytes pass that look (lz4 saves 20 KB on the first MiB) and are refused
+    as a whole (20 KB saved, 40 KB of lz4's own overhead on 10 MiB of noise) -- with an encoder inside.  The block is
+    stored, like the oracle's; the trace shows that the late refusal really happened."""
+    forced.setenv("LRZGPU_TRACE", "2")
+    parts = []
+    for k in range(3):
+        parts.append(datagen.text_like(64 << 10, seed=70 + k))
+        parts.append(datagen.random_bytes((10 << 20) - (64 << 10), seed=80 + k))
+    parts.append(datagen.random_bytes((2 << 20) + 11, seed=90))
+    data = b"".join(parts)
+    fs = _both(B, O, data, level=7, threads=16, processors=16)
+    assert fs.stream_bufsize == 10 << 20
+    err = capfd.readouterr().err
+    assert " refused_late " in err, "no block was refused after its encoder had started"
+
+
 @pytest.mark.parametrize("level", [1, 3, 5, 6, 8, 9])
 def test_levels_started_early(B, O, forced, level):
     """HC5 lists + the greedy parser (levels 1-4) and the other dictionaries / fast-byte settings behind the same path."""
