@@ -785,7 +785,7 @@ struct Pipeline {
 				j->probed = true;
 				if (!d_probe.p && !d_probe.alloc(256, device))
 					return LRZGPU_E_NOMEM;
-				const int in_len = (int)(P < (int64_t)100 * 1048576 ? P : (int64_t)100 * 1048576);
+				const int in_len = (int)(P < (int64_t)256 * 1024 ? P : (int64_t)256 * 1024); // (a hint: a quarter MiB says enough, in a millisecond)
 				const int below = (int)((double)in_len * ((double)sz.threshold / 100.0));
 				Lz4Job q{d_blk, in_len, in_len + 1, below};
 				int res = 0;
