@@ -2086,8 +2086,7 @@ int scan_workspace_create(ScanWorkspace **out, int rzip_level, int64_t max_chunk
 	HIPCHK(hipMalloc(&w->state, sizeof(ScanState)));
 	HIPCHK(hipMalloc(&w->hx, 256 * 8));
 	{
-		const char *e = getenv("LRZGPU_RESOLVE_SERIAL");
-		w->batch_mode = (e && *e == '1') ? 0 : 1;
+		w->batch_mode = 1; // (bit 0: speculative batches; 0 = exact serial steps only, the debugging mode of round 1)
 		const char *pr = getenv("LRZGPU_RESOLVE_PROF"); // bit 1: per-phase cycle counters in the profile
 		if (pr && *pr == '1')
 			w->batch_mode |= 2;
