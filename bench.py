@@ -295,8 +295,13 @@ def file_to_file_leg(B, buf, n_bytes, fresh_ctl):
                 return {"error": rc}
             times.append(dt)
             size = os.path.getsize(dst)
+        h = hashlib.sha256()
+        with open(dst, "rb") as f:
+            for piece in iter(lambda: f.read(64 << 20), b""):
+                h.update(piece)
+        digest = h.hexdigest()
         return {"value": round(n_bytes / 1048576 / times[-1], 2), "unit": "MB/s (2^20 B/s)", "seconds": round(times[-1], 2),
-                "first_pass_seconds": round(times[0], 2), "output_bytes": size,
+                "first_pass_seconds": round(times[0], 2), "output_bytes": size, "image_sha256": digest,
                 "what": "lrzgpu_compress_file(fd of a %d-byte file on %s -> fd of a file on %s): pread + H2D of every chunk, "
                         "write() of every chunk image, magic rewritten at the end; second of two passes" % (n_bytes, best, best)}
     finally:
@@ -321,7 +326,8 @@ def cpu_baseline(buf, n_bytes, sample_bytes, ctl_kw, cores, desc):
                                 processors=ctl_kw["processors"], ramsize=ctl_kw["ramsize"], window=ctl_kw["window"],
                                 workers=cores, file_size=n_bytes)
     dt = time.time() - t0
-    return {"value": round(sample_bytes / 1048576 / dt, 2), "unit": "MB/s", "cores": cores, "kind": "port",
+    return {"image_sha256": hashlib.sha256(out).hexdigest(), "image_bytes": len(out),
+            "value": round(sample_bytes / 1048576 / dt, 2), "unit": "MB/s", "cores": cores, "kind": "port",
             "whole_file": bool(sample_bytes >= n_bytes),
             "sample": "the first %d bytes (%d whole rzip chunk(s)) of the IDENTICAL buffer (%s), identical flags and "
                       "block size (%d B, as for the whole file); oracle rzip/lz4/container restatement (one scan "
@@ -657,6 +663,21 @@ def main():
                                        "cpu_sample_is_whole_file": cpu.get("whole_file")}
         if verified is not None:
             line["round_trip_ok"] = verified
+        # byte-for-byte parity on the measured configuration itself: the image of the last timed step, the image the
+        # file-to-file leg wrote and the image the CPU path (oracle + the reference's LZMA build) made of the identical
+        # buffer with the identical flags -- compared by digest, at full size, in every run
+        if out is not None:
+            mine = hashlib.sha256(out.view() if hasattr(out, "view") else out).hexdigest()
+            par = {"gpu_image_sha256": mine, "gpu_image_bytes": len(out)}
+            if file_leg and file_leg.get("image_sha256"):
+                par["file_to_file_image_sha256"] = file_leg["image_sha256"]
+                par["file_to_file_identical_to_hbm_resident"] = file_leg["image_sha256"] == mine
+            if cpu and cpu.get("image_sha256") and cpu.get("whole_file"):
+                par["cpu_image_sha256"] = cpu["image_sha256"]
+                line["identical_to_cpu_baseline"] = cpu["image_sha256"] == mine and cpu["image_bytes"] == len(out)
+            else:
+                line["identical_to_cpu_baseline"] = None  # (the CPU leg compressed a sample of the file, or did not run)
+            line["parity"] = par
         print(json.dumps(line), flush=True)
     if world > 1:
         if comm_close:

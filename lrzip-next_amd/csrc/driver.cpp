@@ -774,6 +774,7 @@ struct Pipeline {
 			int64_t new_valid = from;
 			uint64_t new_words_at_valid = w_from;
 			bool compressible = true;
+			std::unique_ptr<RawBuf<uint32_t>> regrown; // the block's list array when this run outgrows the current one
 			double tw1 = now_s(), tw2 = tw1;
 			const double tw0 = tw1;
 			// The gate's verdict is taken for granted when a block is started early; on data it refuses (random bytes:
@@ -829,27 +830,28 @@ struct Pipeline {
 					} else
 						new_words_at_valid = words;
 					uint64_t copy_from = w_from;
+					uint32_t *pairs_dst = j->pairs.data();
+					bool pairs_pinned = j->pairs.pinned;
 					if (!j->pairs.p || words > j->pairs.n) {
-						// (first run, or the block turned out denser than its first part promised)
-						std::unique_ptr<RawBuf<uint32_t>> fresh(new RawBuf<uint32_t>());
+						// (first run, or the block turned out denser than its first part promised.)  An encoder may be
+						// reading the current array at this moment and takes the pointer under mu whenever it is told of new
+						// positions (rest_cb, take_enc): the new array is filled COMPLETELY, from word 0, before it is
+						// published together with `valid` in the locked section below -- never an array with holes.
+						if (j->pairs.p && tracing_events())
+							fprintf(stderr, "ev %.3f lists_regrown chunk %d stream 1 off %lld len %lld\n", now_s() - g_trace_t0, j->chunk->index, (long long)j->ref.off, (long long)P);
+						regrown.reset(new RawBuf<uint32_t>());
 						const double per = (double)words / (double)P;
 						size_t cap_words = full ? (size_t)words : (size_t)(per * 1.5 * (double)n) + ((size_t)4 << 20);
 						if (cap_words < words)
 							cap_words = (size_t)words;
-						fresh->alloc(cap_words, want_pinned);
+						regrown->alloc(cap_words, want_pinned);
 						copy_from = 0;
-						std::lock_guard<std::mutex> lk(mu); // (an encoder reads the pointer under mu: rest_cb)
-						std::swap(fresh->p, j->pairs.p);
-						std::swap(fresh->n, j->pairs.n);
-						std::swap(fresh->cap, j->pairs.cap);
-						std::swap(fresh->pinned, j->pairs.pinned);
-						if (fresh->p)
-							j->old_pairs.push_back(std::move(fresh));
+						pairs_dst = regrown->data();
+						pairs_pinned = regrown->pinned;
 					}
-					j->packed = pack;
 					// positions below `from` are final on the host and may be being read: only what lies behind is copied
 					if (d2h(j->counts.data() + from, j->counts.pinned, ws->counts + from, (size_t)(P - from), stage, s) != 0 ||
-					    (words > copy_from && d2h(j->pairs.data() + copy_from, j->pairs.pinned, ws->pool_out + copy_from, (size_t)(words - copy_from) * 4, stage, s) != 0))
+					    (words > copy_from && d2h(pairs_dst + copy_from, pairs_pinned, ws->pool_out + copy_from, (size_t)(words - copy_from) * 4, stage, s) != 0))
 						return LRZGPU_E_HIP;
 				}
 			}
@@ -859,6 +861,16 @@ struct Pipeline {
 				std::lock_guard<std::mutex> lk(mu);
 				n_early_stages++;
 				j->bytes_copied = have_bytes;
+				j->packed = pack;
+				if (regrown) { // complete: now it is the block's array (the outgrown one stays alive for whoever still reads it)
+					std::swap(regrown->p, j->pairs.p);
+					std::swap(regrown->n, j->pairs.n);
+					std::swap(regrown->cap, j->pairs.cap);
+					std::swap(regrown->pinned, j->pairs.pinned);
+					if (regrown->p)
+						j->old_pairs.push_back(std::move(regrown));
+					regrown.reset();
+				}
 				if (!j->cancelled) {
 					if (P > j->stage_done)
 						j->stage_done = P;
@@ -930,9 +942,23 @@ struct Pipeline {
 				return;
 			}
 			if (j->early) {
-				int er = early_stage(j);
+				// whichever way a run ends, the job must not stay marked "in a finder run": its encoder waits for that
+				// mark to clear before it lets go of the block's buffers (retire), and would wait for ever
+				auto left_the_gpu = [&] {
+					std::lock_guard<std::mutex> lk(mu);
+					j->in_gpu = false;
+					cv_rest.notify_all();
+				};
+				int er;
+				try {
+					er = early_stage(j);
+				} catch (...) {
+					left_the_gpu();
+					throw;
+				}
 				TRACE_EVENT("gpu_end", j);
 				if (er) {
+					left_the_gpu();
 					fail(er);
 					cleanup();
 					return;

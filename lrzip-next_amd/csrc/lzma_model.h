@@ -206,17 +206,25 @@ struct PriceTables {
 		       bit.bit(ctx[s >> 5], (s >> 4) & 1) + bit.bit(ctx[s >> 4], (s >> 3) & 1) + bit.bit(ctx[s >> 3], (s >> 2) & 1) +
 		       bit.bit(ctx[s >> 2], (s >> 1) & 1) + bit.bit(ctx[s >> 1], s & 1);
 	}
-	// literal after a match: while its bits agree with the byte at rep0 the tree is selected by that byte
+	// literal after a match: while its bits agree with the byte at rep0 the tree is selected by that byte.  All eight
+	// node indices are known from the two bytes: bit k (from the top) is coded in the matched half of the context
+	// while the k bits above it agree -- `agree` has bit 8 - k set then -- and in the plain tree after that.
 	inline uint32_t literal_matched(const Prob *ctx, unsigned sym, unsigned match_byte) const
 	{
+		unsigned x = (sym ^ match_byte) & 0xFF; // set bits: disagreements
+		x |= x >> 1;
+		x |= x >> 2;
+		x |= x >> 4;                                   // ... and everything below the first one
+		const unsigned agree = (~x & 0xFF) | 0x100;      // bit 8: nothing above the top bit; bit j: bits 7 .. j of the bytes agree
+		const unsigned s = sym | 0x100, mb = match_byte << 1;
 		uint32_t pr = 0;
-		unsigned offs = 0x100, s = sym | 0x100, mb = match_byte;
-		do {
-			mb <<= 1;
-			pr += bit.bit(ctx[offs + (mb & offs) + (s >> 8)], (s >> 7) & 1);
-			s <<= 1;
-			offs &= ~(mb ^ s);
-		} while (s < 0x10000);
+#define LRZ_ML(k)                                                                                       \
+	{                                                                                               \
+		const unsigned offs = (agree << (k)) & 0x100;                                           \
+		pr += bit.bit(ctx[offs + ((mb << (k)) & offs) + (s >> (8 - (k)))], (s >> (7 - (k))) & 1); \
+	}
+		LRZ_ML(0) LRZ_ML(1) LRZ_ML(2) LRZ_ML(3) LRZ_ML(4) LRZ_ML(5) LRZ_ML(6) LRZ_ML(7)
+#undef LRZ_ML
 		return pr;
 	}
 

@@ -108,6 +108,24 @@ inline uint32_t edge_code(uint64_t e) { return (uint32_t)e; }
 inline unsigned edge_len(uint64_t e) { return (unsigned)(e >> 32) & 0xFFFF; }
 inline unsigned edge_pre(uint64_t e) { return (unsigned)(e >> 48); }
 
+// How a node is entered (the edge into it) -> coder state and repeat distances there.  sel: 0 literal, 1..4 repeat
+// 0..3, 5 a fresh distance.  kinds: 0 repeat (two bytes or more), 1 short repeat (one byte at repeat 0), 2 literal
+// (kind of a literal is 1 + (len == 1) = 2: its length is always 1), 3 match, 4 compound (..., literal, repeat 0).
+alignas(16) constexpr uint8_t kEntryKind[8] = {1, 0, 0, 0, 0, 3, 0, 0};
+alignas(16) constexpr uint8_t kEntryState[5][16] = {
+	{8, 8, 8, 8, 8, 8, 8, 11, 11, 11, 11, 11},  // after_rep
+	{9, 9, 9, 9, 9, 9, 9, 11, 11, 11, 11, 11},  // after_short_rep
+	{0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 4, 5},       // after_literal
+	{7, 7, 7, 7, 7, 7, 7, 10, 10, 10, 10, 10},  // after_match
+	{8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8},       // ..., one literal, then a repeat
+};
+#define LRZ_SHUF4(a, b, c, d) {4 * a, 4 * a + 1, 4 * a + 2, 4 * a + 3, 4 * b, 4 * b + 1, 4 * b + 2, 4 * b + 3, 4 * c, 4 * c + 1, 4 * c + 2, 4 * c + 3, 4 * d, 4 * d + 1, 4 * d + 2, 4 * d + 3}
+alignas(16) constexpr uint8_t kEntryShuffle[6][16] = {
+	LRZ_SHUF4(0, 1, 2, 3), LRZ_SHUF4(0, 1, 2, 3), LRZ_SHUF4(1, 0, 2, 3), LRZ_SHUF4(2, 0, 1, 3), LRZ_SHUF4(3, 0, 1, 2),
+	{0x80, 0x80, 0x80, 0x80, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11}, // a fresh distance goes in front
+};
+#undef LRZ_SHUF4
+
 struct Step {
 	uint32_t len, code;
 };
@@ -318,24 +336,38 @@ template <int FORMAT> struct BlockEncoder {
 #endif
 
 	// ---- prices of the flag bits in front of a symbol ----------------------------------------------------------------
-	inline uint32_t price_short_rep(unsigned st, unsigned ps) const
+	// The model only changes between searches (the coder runs between them), and a search visits a thousand nodes in
+	// at most 12 x 4 (state, position state) combinations: the sums of flag-bit prices a node needs are computed once
+	// per search and combination, on first use (`flag_epoch`), and read as one line after that.
+	struct FlagPrices {
+		uint32_t literal;     // "a literal follows"
+		uint32_t match;       // "a match with a fresh distance follows", up to its length
+		uint32_t rep;         // "a repeat follows", before saying which
+		uint32_t short_rep;   // one byte at repeat 0, complete
+		uint32_t rep_long[4]; // repeat i of two bytes or more, up to its length
+	};
+	alignas(64) FlagPrices flag_price[kStates][kPosStatesMax];
+	uint32_t flag_tag[kStates][kPosStatesMax];
+	uint32_t flag_epoch = 0;
+	inline const FlagPrices &flags(unsigned st, unsigned ps)
 	{
-		return prices.bit.zero(model.is_rep0[st]) + prices.bit.zero(model.is_rep0_long[st][ps]);
-	}
-	inline uint32_t price_rep_choice(unsigned which, unsigned st, unsigned ps) const
-	{
-		if (which == 0)
-			return prices.bit.zero(model.is_rep0[st]) + prices.bit.one(model.is_rep0_long[st][ps]);
-		uint32_t pr = prices.bit.one(model.is_rep0[st]);
-		if (which == 1)
-			return pr + prices.bit.zero(model.is_rep1[st]);
-		return pr + prices.bit.one(model.is_rep1[st]) + prices.bit.bit(model.is_rep2[st], which - 2);
-	}
-	// everything of "a repeat-0 match follows" except its length
-	inline uint32_t price_rep0_after(unsigned st, unsigned ps) const
-	{
-		return prices.bit.one(model.is_match[st][ps]) + prices.bit.one(model.is_rep[st]) + prices.bit.zero(model.is_rep0[st]) +
-		       prices.bit.one(model.is_rep0_long[st][ps]);
+		FlagPrices &f = flag_price[st][ps];
+		if (__builtin_expect(flag_tag[st][ps] != flag_epoch, 0)) {
+			flag_tag[st][ps] = flag_epoch;
+			const Prob m = model.is_match[st][ps];
+			const uint32_t as_match = prices.bit.one(m), as_rep = as_match + prices.bit.one(model.is_rep[st]);
+			f.literal = prices.bit.zero(m);
+			f.match = as_match + prices.bit.zero(model.is_rep[st]);
+			f.rep = as_rep;
+			const uint32_t r0 = as_rep + prices.bit.zero(model.is_rep0[st]), rx = as_rep + prices.bit.one(model.is_rep0[st]);
+			f.short_rep = r0 + prices.bit.zero(model.is_rep0_long[st][ps]);
+			f.rep_long[0] = r0 + prices.bit.one(model.is_rep0_long[st][ps]);
+			f.rep_long[1] = rx + prices.bit.zero(model.is_rep1[st]);
+			const uint32_t ry = rx + prices.bit.one(model.is_rep1[st]);
+			f.rep_long[2] = ry + prices.bit.zero(model.is_rep2[st]);
+			f.rep_long[3] = ry + prices.bit.one(model.is_rep2[st]);
+		}
+		return f;
 	}
 	inline uint32_t price_literal(uint32_t pos, unsigned st, const uint8_t *p, unsigned match_byte) const
 	{
@@ -369,10 +401,10 @@ template <int FORMAT> struct BlockEncoder {
 		const unsigned end = equal_until(here, there, tail, limit);
 		const unsigned rep_len = end - x_len - 1;
 		const unsigned ps_lit = (position + x_len) & pos_mask;
-		uint32_t pr = price_x + prices.bit.zero(model.is_match[st_after_x][ps_lit]) +
+		uint32_t pr = price_x + flags(st_after_x, ps_lit).literal +
 			      prices.literal_matched(model.literal_context(position + x_len, here[x_len - 1]), here[x_len], there[x_len]);
 		const unsigned st_lit = after_literal(st_after_x), ps_rep = (ps_lit + 1) & pos_mask;
-		pr += price_rep0_after(st_lit, ps_rep) + prices.rep_len.row[ps_rep][rep_len];
+		pr += flags(st_lit, ps_rep).rep_long[0] + prices.rep_len.row[ps_rep][rep_len];
 		const unsigned node = cur + end;
 		relax(node, pr, edge(rep_len, code, x_len + 1));
 		return node;
@@ -430,13 +462,13 @@ template <int FORMAT> struct BlockEncoder {
 		const unsigned ps0 = position & pos_mask;
 		node_state[0] = (uint8_t)state;
 		memcpy(node_reps[0], reps, sizeof(reps));
+		flag_epoch++;
 		{
-			const Prob m = model.is_match[state][ps0];
-			cost[1] = prices.bit.zero(m) + price_literal(position, state, here, match_byte);
+			const FlagPrices &f = flags(state, ps0);
+			cost[1] = f.literal + price_literal(position, state, here, match_byte);
 			via[1] = edge(1, kLiteral);
-			const uint32_t as_match = prices.bit.one(m), as_rep = as_match + prices.bit.one(model.is_rep[state]);
 			if (match_byte == cur_byte && rep_len[0] == 0) {
-				relax(1, as_rep + price_short_rep(state, ps0), edge(1, 0));
+				relax(1, f.short_rep, edge(1, 0));
 				if (frontier < 2) {
 					const uint32_t code = edge_code(via[1]);
 					cost[1] = kPriceInfinite;
@@ -445,13 +477,13 @@ template <int FORMAT> struct BlockEncoder {
 			}
 			for (unsigned i = 0; i < kRepSlots; i++)
 				if (rep_len[i] >= 2)
-					relax_span(0, 2, rep_len[i], as_rep + price_rep_choice(i, state, ps0), prices.rep_len.row[ps0], i);
+					relax_span(0, 2, rep_len[i], f.rep_long[i], prices.rep_len.row[ps0], i);
 			// fresh distances: lengths up to rep_len[0] are never cheaper than the repeat, they are not tried
 			unsigned lo = rep_len[0] + 1;
 			if (lo < 2)
 				lo = 2;
 			if (lo <= main_len)
-				relax_matches(0, list, list.count, lo, main_len, as_match + prices.bit.zero(model.is_rep[state]), ps0, nullptr, 0, 0, 0, 0, &frontier);
+				relax_matches(0, list, list.count, lo, main_len, f.match, ps0, nullptr, 0, 0, 0, 0, &frontier);
 		}
 
 		// ---- expand node after node until the frontier is reached -----------------------------------------
@@ -484,55 +516,35 @@ template <int FORMAT> struct BlockEncoder {
 			}
 			position++;
 
-			// -- how this node was reached decides the coder state and the repeat distances here
+			// -- how this node was reached decides the coder state and the repeat distances here: looked up, not branched
+			// on (whether a node is entered by a literal, a repeat or a match is as unpredictable as the data)
 			const uint64_t e = via[cur];
 			const unsigned elen = edge_len(e), epre = edge_pre(e);
 			const uint32_t ecode = edge_code(e);
-			unsigned st;
-			uint32_t r[kRepSlots];
+			const unsigned origin = cur - elen - epre;
+			const unsigned sel = ecode + 1 < 5 ? ecode + 1 : 5; // 0 literal, 1 + i repeat i, 5 a fresh distance
+			const unsigned kind = epre ? 4u : kEntryKind[sel] + (elen == 1);
+			const unsigned st = kEntryState[kind][node_state[origin]];
 			{
-				unsigned origin = cur - elen;
-				if (elen == 1 && !epre) { // literal or short repeat: distances unchanged
-					st = node_state[origin];
-					st = ecode == 0 ? after_short_rep(st) : after_literal(st);
-					memcpy(r, node_reps[origin], sizeof(r));
-				} else {
-					if (epre) {
-						origin -= epre;
-						st = epre == 1 ? (ecode < kRepSlots ? 8u : 7u) : 8u; // ... literal, then a repeat (or, pre == 1, whatever `code` says)
-					} else {
-						st = node_state[origin];
-						st = ecode < kRepSlots ? after_rep(st) : after_match(st);
-					}
-					const uint32_t *o = node_reps[origin];
-					if (ecode < kRepSlots) { // move the used distance to the front
-						r[0] = o[ecode];
-						unsigned k = 1;
-						for (unsigned i = 0; i < kRepSlots; i++)
-							if (i != ecode)
-								r[k++] = o[i];
-					} else {
-						r[0] = ecode - kRepSlots + 1;
-						r[1] = o[0];
-						r[2] = o[1];
-						r[3] = o[2];
-					}
-				}
+				const __m128i o = _mm_load_si128((const __m128i *)node_reps[origin]);
+				const __m128i moved = _mm_shuffle_epi8(o, _mm_load_si128((const __m128i *)kEntryShuffle[sel]));
+				const uint32_t fresh_dist = sel == 5 ? ecode - kRepSlots + 1 : 0;
+				_mm_store_si128((__m128i *)node_reps[cur], _mm_or_si128(moved, _mm_cvtsi32_si128((int)fresh_dist)));
 			}
 			node_state[cur] = (uint8_t)st;
-			memcpy(node_reps[cur], r, sizeof(r));
+			const uint32_t *r = node_reps[cur];
 			LAP(2);
 
 			here = data + fetch_pos - 1;
 			const unsigned cb = here[0], mb = here[-(ptrdiff_t)r[0]];
 			const unsigned ps = position & pos_mask;
 			const uint32_t here_cost = cost[cur];
-			const Prob m = model.is_match[st][ps];
-			const uint32_t as_match = here_cost + prices.bit.one(m), as_rep = as_match + prices.bit.one(model.is_rep[st]);
+			const FlagPrices &f = flags(st, ps);
+			const uint32_t as_rep = here_cost + f.rep;
 
 			// -- literal.  Not priced when the next node already has an edge and the byte equals the repeat-0
 			// byte (a repeat will cover it), nor when the flag bit alone already costs more than the incumbent.
-			uint32_t lit_cost = here_cost + prices.bit.zero(m);
+			uint32_t lit_cost = here_cost + f.literal;
 			bool lit_priced = false, lit_won = false;
 			if (!((cost[cur + 1] < kPriceInfinite && mb == cb) || lit_cost > cost[cur + 1])) {
 				lit_cost += price_literal(position, st, here, mb);
@@ -547,7 +559,7 @@ template <int FORMAT> struct BlockEncoder {
 			if (last_was_literal(st) && mb == cb && as_rep < cost[cur + 1]) {
 				const uint64_t inc = via[cur + 1];
 				if (edge_len(inc) < 2 || edge_code(inc) != 0) {
-					const uint32_t c = as_rep + price_short_rep(st, ps);
+					const uint32_t c = here_cost + f.short_rep;
 					if (c < cost[cur + 1]) {
 						cost[cur + 1] = c;
 						via[cur + 1] = edge(1, 0);
@@ -576,21 +588,31 @@ template <int FORMAT> struct BlockEncoder {
 					const unsigned node = cur + end;
 					if (frontier < node)
 						frontier = node;
-					relax(node, lit_cost + price_rep0_after(st2, ps2) + prices.rep_len.row[ps2][end - 1], edge(end - 1, 0, 1));
+					relax(node, lit_cost + flags(st2, ps2).rep_long[0] + prices.rep_len.row[ps2][end - 1], edge(end - 1, 0, 1));
 				}
 			}
 
 			LAP(4);
 			// -- repeats
 			unsigned match_from = 2; // shortest fresh-distance length worth pricing
-			for (unsigned i = 0; i < kRepSlots; i++) {
+			// which of the four continue for two bytes: found for all four at once, then only those are visited
+			unsigned rep_hits;
+			{
+				uint16_t h, t0, t1, t2, t3;
+				memcpy(&h, here, 2);
+				memcpy(&t0, here - r[0], 2);
+				memcpy(&t1, here - r[1], 2);
+				memcpy(&t2, here - r[2], 2);
+				memcpy(&t3, here - r[3], 2);
+				rep_hits = (unsigned)(t0 == h) | (unsigned)(t1 == h) << 1 | (unsigned)(t2 == h) << 2 | (unsigned)(t3 == h) << 3;
+			}
+			for (; rep_hits; rep_hits &= rep_hits - 1) {
+				const unsigned i = (unsigned)__builtin_ctz(rep_hits);
 				const uint8_t *there = here - r[i];
-				if (!same2(here, there))
-					continue;
 				const unsigned len = equal_until(here, there, 2, room_nice);
 				if (frontier < cur + len)
 					frontier = cur + len;
-				const uint32_t base = as_rep + price_rep_choice(i, st, ps);
+				const uint32_t base = here_cost + f.rep_long[i];
 				relax_span(cur, 2, len, base, prices.rep_len.row[ps], i);
 				if (i == 0)
 					match_from = len + 1;
@@ -612,7 +634,7 @@ template <int FORMAT> struct BlockEncoder {
 			if (new_len >= match_from) {
 				if (frontier < cur + new_len)
 					frontier = cur + new_len;
-				relax_matches(cur, fresh, pairs, match_from, new_len, as_match + prices.bit.zero(model.is_rep[st]), ps, here, position, st, room_full, 1, &frontier);
+				relax_matches(cur, fresh, pairs, match_from, new_len, here_cost + f.match, ps, here, position, st, room_full, 1, &frontier);
 			}
 		}
 
@@ -634,10 +656,54 @@ template <int FORMAT> struct BlockEncoder {
 				  unsigned ps, const uint8_t *here, uint32_t position, unsigned st, uint32_t room_full, int compound,
 				  unsigned *frontier)
 	{
+		const uint32_t *len_row = prices.match_len.row[ps];
+#if LZMA_HAVE_AVX512
+		// The common shape -- at most four pairs, at most sixteen lengths, the list not clipped, no tail flag up -- as
+		// straight-line code: every length lo..hi is one lane; pair k takes the lanes up to its length that no
+		// shorter pair has taken (a pair beyond the list's end repeats the last one and finds no lane left), the
+		// lanes' distance prices and edge codes are merged under those masks, then ONE compare-and-store prices all
+		// of it.  The loop below does the same pair by pair; its trip count is a mispredicted branch per position.
+		if (PACKED && pairs <= 4 && hi - lo < 16 && hi == list.len(pairs - 1)) {
+			const unsigned last = pairs - 1;
+			const uint32_t w0 = list.w[0], w1 = list.w[last < 1 ? last : 1], w2 = list.w[last < 2 ? last : 2], w3 = list.w[last];
+			if (!compound || !((w0 | w1 | w2 | w3) >> 31)) {
+				const __m512i iota = _mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+				const __m512i lens = _mm512_add_epi32(_mm512_set1_epi32((int)lo), iota);
+				const __mmask16 live = _mm512_cmple_epu32_mask(lens, _mm512_set1_epi32((int)hi));
+				const __m512i ctx = _mm512_min_epu32(_mm512_sub_epi32(lens, _mm512_set1_epi32((int)kLenMin)), _mm512_set1_epi32((int)kLenToDistStates - 1));
+				__mmask16 open = live;
+				__m512i dist_price = _mm512_setzero_si512(), codes = _mm512_setzero_si512();
+				const uint8_t *src_base = data + fetch_pos - 2;
+				const uint32_t ws[4] = {w0, w1, w2, w3};
+				for (unsigned j = 0; j < 4; j++) { // (unrolled: constant trip count)
+					const uint32_t d = ws[j] & 0x1FFFFFFu;
+					const unsigned plen = ((ws[j] >> 25) & 63) + 2;
+					const bool near = d < kNearDistances;
+					const uint32_t *tab = near ? prices.near_dist[d] : prices.slot[dist_slot(near ? kNearDistances : d)];
+					const uint32_t add = near ? 0 : prices.align[d & (kAlignSize - 1)];
+					const __m128i d4 = _mm_add_epi32(_mm_load_si128((const __m128i *)tab), _mm_set1_epi32((int)add));
+					__builtin_prefetch(src_base + plen - d);
+					const __mmask16 mine = _mm512_mask_cmple_epu32_mask(open, lens, _mm512_set1_epi32((int)plen));
+					open = (__mmask16)(open & ~mine);
+					dist_price = _mm512_mask_permutexvar_epi32(dist_price, mine, ctx, _mm512_castsi128_si512(d4));
+					codes = _mm512_mask_set1_epi32(codes, mine, (int)(d + kRepSlots));
+				}
+				const __m512i cand = _mm512_add_epi32(_mm512_add_epi32(_mm512_set1_epi32((int)base), dist_price), _mm512_maskz_loadu_epi32(live, len_row + lo));
+				uint32_t *cp = cost + cur + lo;
+				const __mmask16 win = _mm512_mask_cmplt_epu32_mask(live, cand, _mm512_maskz_loadu_epi32(live, cp));
+				_mm512_mask_storeu_epi32(cp, win, cand);
+				uint64_t *vp = via + cur + lo;
+				const __m512i e_lo = _mm512_or_si512(_mm512_slli_epi64(_mm512_cvtepu32_epi64(_mm512_castsi512_si256(lens)), 32), _mm512_cvtepu32_epi64(_mm512_castsi512_si256(codes)));
+				const __m512i e_hi = _mm512_or_si512(_mm512_slli_epi64(_mm512_cvtepu32_epi64(_mm512_extracti64x4_epi64(lens, 1)), 32), _mm512_cvtepu32_epi64(_mm512_extracti64x4_epi64(codes, 1)));
+				_mm512_mask_storeu_epi64(vp, (__mmask8)win, e_lo);
+				_mm512_mask_storeu_epi64(vp + 8, (__mmask8)(win >> 8), e_hi);
+				return;
+			}
+		}
+#endif
 		unsigned k = 0;
 		while (lo > list.len(k) && k + 1 < pairs)
 			k++;
-		const uint32_t *len_row = prices.match_len.row[ps];
 		unsigned len = lo;
 		for (; k < pairs; k++) {
 			unsigned top = list.len(k);
@@ -659,11 +725,12 @@ template <int FORMAT> struct BlockEncoder {
 				relax_pair(cur, len, top, base, len_row, dist4, code);
 				len = top + 1;
 			}
-			if (compound) {
+			// the flag speaks for the pair's own length (a clipped last pair has to look at the bytes) and it says "no"
+			// for 999 pairs of 1000: nothing of the compound edge is computed for those
+			if (compound && !(PairView<FORMAT>::kFlagged && top == list.len(k) && !list.tail(k))) {
 				_mm_store_si128((__m128i *)dp, dist4);
 				const uint32_t price_x = base + len_row[top] + dp[len_dist_state(top)];
-				// the flag speaks for the pair's own length; a clipped last pair has to look at the bytes
-				const int known = PairView<FORMAT>::kFlagged && top == list.len(k) ? (int)list.tail(k) : -1;
+				const int known = PairView<FORMAT>::kFlagged && top == list.len(k) ? 1 : -1;
 				const unsigned node = try_literal_then_rep0(cur, here, position, top, d + 1, after_match(st), price_x, room_full, code, known);
 				if (*frontier < node)
 					*frontier = node;
@@ -892,6 +959,8 @@ template <int FORMAT> struct BlockEncoder {
 		for (unsigned k = 0; k < sizeof(cost) / sizeof(cost[0]); k++)
 			cost[k] = kPriceInfinite;
 		memset(via, 0, sizeof(via));
+		memset(flag_tag, 0, sizeof(flag_tag));
+		flag_epoch = 0;
 		refresh_all();
 		prices.rep_len.refresh(model.rep_len, prices.bit, 1u << model.pb, nice_len);
 	}

@@ -68,6 +68,31 @@ def test_gate_refuses_after_the_encoder_started(B, O, forced, capfd):
     assert " refused_late " in err, "no block was refused after its encoder had started"
 
 
+def test_list_array_outgrown_while_an_encoder_reads_it(B, O, forced, capfd):
+    """The host array of an early block's lists is sized from the density of its first finder run (x 1.5 + 4 M words).
+    Blocks that begin with a MiB holding few pairs (units of eight random bytes written twice: enough for the gate's
+    look at the first 256 KiB to say "compressible", nothing for rzip, 0.4 pairs per position) and go on as text
+    (2.3 pairs per position: 21 M words for the 9 MiB, against an array of ~10 M) outgrow it a few runs later, while the
+    encoder that was offered the block after the first run is reading the old array: the new one must be complete
+    before the encoder is handed it (it used to be swapped in empty and filled afterwards)."""
+    forced.setenv("LRZGPU_EARLY_STEP", str(1 << 19))
+    forced.setenv("LRZGPU_TRACE", "2")
+    parts = []
+    for k in range(3):
+        r = np.frombuffer(datagen.random_bytes(1 << 19, seed=300 + k), dtype=np.uint8).reshape(-1, 8)
+        head = np.concatenate([r, r], axis=1).tobytes()
+        parts.append(head)
+        parts.append(datagen.text_like((10 << 20) - len(head), seed=320 + k))
+    parts.append(datagen.text_like((3 << 20) + 17, seed=330))
+    data = b"".join(parts)
+    B.lib().lrzgpu_profile_reset()
+    fs = _both(B, O, data, level=7, threads=16, processors=16)
+    assert fs.stream_bufsize == 10 << 20
+    p = _profile(B)
+    assert p.early_s[2] >= 3 and p.early_s[3] >= 3 * 8, list(p.early_s)
+    assert " lists_regrown " in capfd.readouterr().err, "no block outgrew its list array"
+
+
 @pytest.mark.parametrize("level", [1, 3, 5, 6, 8, 9])
 def test_levels_started_early(B, O, forced, level):
     """HC5 lists + the greedy parser (levels 1-4) and the other dictionaries / fast-byte settings behind the same path."""
