@@ -194,9 +194,12 @@ struct PriceTables {
 	LenPrices match_len, rep_len;
 	// distance prices, the four length contexts of one slot / one near distance adjacent: the parser prices a
 	// pair for every length it covers with one 128-bit load (lengths 2, 3, 4 and "5 or more" differ only here)
-	alignas(16) uint32_t slot[kDistSlots][kLenToDistStates];
-	alignas(16) uint32_t near_dist[kNearDistances][kLenToDistStates];
-	uint32_t align[kAlignSize];
+	// Both live in ONE array of 16-byte rows -- row d for a near distance d, row kNearDistances + s for slot s -- so
+	// that "the row of this pair" is an index the parser can compute for four pairs at once, without a branch.
+	alignas(64) uint32_t dist_rows[kNearDistances + kDistSlots][kLenToDistStates];
+	uint32_t (*const near_dist)[kLenToDistStates] = dist_rows;
+	uint32_t (*const slot)[kLenToDistStates] = dist_rows + kNearDistances;
+	alignas(64) uint32_t align[kAlignSize];
 
 	// literal coded plainly: 8 tree levels, all node indices known from the symbol
 	inline uint32_t literal(const Prob *ctx, unsigned sym) const

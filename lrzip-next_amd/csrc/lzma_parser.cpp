@@ -349,25 +349,28 @@ template <int FORMAT> struct BlockEncoder {
 	alignas(64) FlagPrices flag_price[kStates][kPosStatesMax];
 	uint32_t flag_tag[kStates][kPosStatesMax];
 	uint32_t flag_epoch = 0;
-	inline const FlagPrices &flags(unsigned st, unsigned ps)
+	__attribute__((always_inline)) inline const FlagPrices &flags(unsigned st, unsigned ps)
+	{
+		if (__builtin_expect(flag_tag[st][ps] != flag_epoch, 0))
+			fill_flags(st, ps);
+		return flag_price[st][ps];
+	}
+	__attribute__((noinline)) void fill_flags(unsigned st, unsigned ps)
 	{
 		FlagPrices &f = flag_price[st][ps];
-		if (__builtin_expect(flag_tag[st][ps] != flag_epoch, 0)) {
-			flag_tag[st][ps] = flag_epoch;
-			const Prob m = model.is_match[st][ps];
-			const uint32_t as_match = prices.bit.one(m), as_rep = as_match + prices.bit.one(model.is_rep[st]);
-			f.literal = prices.bit.zero(m);
-			f.match = as_match + prices.bit.zero(model.is_rep[st]);
-			f.rep = as_rep;
-			const uint32_t r0 = as_rep + prices.bit.zero(model.is_rep0[st]), rx = as_rep + prices.bit.one(model.is_rep0[st]);
-			f.short_rep = r0 + prices.bit.zero(model.is_rep0_long[st][ps]);
-			f.rep_long[0] = r0 + prices.bit.one(model.is_rep0_long[st][ps]);
-			f.rep_long[1] = rx + prices.bit.zero(model.is_rep1[st]);
-			const uint32_t ry = rx + prices.bit.one(model.is_rep1[st]);
-			f.rep_long[2] = ry + prices.bit.zero(model.is_rep2[st]);
-			f.rep_long[3] = ry + prices.bit.one(model.is_rep2[st]);
-		}
-		return f;
+		flag_tag[st][ps] = flag_epoch;
+		const Prob m = model.is_match[st][ps];
+		const uint32_t as_match = prices.bit.one(m), as_rep = as_match + prices.bit.one(model.is_rep[st]);
+		f.literal = prices.bit.zero(m);
+		f.match = as_match + prices.bit.zero(model.is_rep[st]);
+		f.rep = as_rep;
+		const uint32_t r0 = as_rep + prices.bit.zero(model.is_rep0[st]), rx = as_rep + prices.bit.one(model.is_rep0[st]);
+		f.short_rep = r0 + prices.bit.zero(model.is_rep0_long[st][ps]);
+		f.rep_long[0] = r0 + prices.bit.one(model.is_rep0_long[st][ps]);
+		f.rep_long[1] = rx + prices.bit.zero(model.is_rep1[st]);
+		const uint32_t ry = rx + prices.bit.one(model.is_rep1[st]);
+		f.rep_long[2] = ry + prices.bit.zero(model.is_rep2[st]);
+		f.rep_long[3] = ry + prices.bit.one(model.is_rep2[st]);
 	}
 	inline uint32_t price_literal(uint32_t pos, unsigned st, const uint8_t *p, unsigned match_byte) const
 	{
@@ -525,18 +528,21 @@ template <int FORMAT> struct BlockEncoder {
 			const unsigned sel = ecode + 1 < 5 ? ecode + 1 : 5; // 0 literal, 1 + i repeat i, 5 a fresh distance
 			const unsigned kind = epre ? 4u : kEntryKind[sel] + (elen == 1);
 			const unsigned st = kEntryState[kind][node_state[origin]];
+			uint32_t r0; // repeat 0 here, straight from the register (the byte at that distance decides the node's first branch)
 			{
 				const __m128i o = _mm_load_si128((const __m128i *)node_reps[origin]);
 				const __m128i moved = _mm_shuffle_epi8(o, _mm_load_si128((const __m128i *)kEntryShuffle[sel]));
 				const uint32_t fresh_dist = sel == 5 ? ecode - kRepSlots + 1 : 0;
-				_mm_store_si128((__m128i *)node_reps[cur], _mm_or_si128(moved, _mm_cvtsi32_si128((int)fresh_dist)));
+				const __m128i mine = _mm_or_si128(moved, _mm_cvtsi32_si128((int)fresh_dist));
+				_mm_store_si128((__m128i *)node_reps[cur], mine);
+				r0 = (uint32_t)_mm_cvtsi128_si32(mine);
 			}
 			node_state[cur] = (uint8_t)st;
 			const uint32_t *r = node_reps[cur];
 			LAP(2);
 
 			here = data + fetch_pos - 1;
-			const unsigned cb = here[0], mb = here[-(ptrdiff_t)r[0]];
+			const unsigned cb = here[0], mb = here[-(ptrdiff_t)r0];
 			const unsigned ps = position & pos_mask;
 			const uint32_t here_cost = cost[cur];
 			const FlagPrices &f = flags(st, ps);
@@ -578,7 +584,7 @@ template <int FORMAT> struct BlockEncoder {
 
 			// -- literal, then repeat-0
 			if (!lit_won && lit_priced && mb != cb && room_full > 2) {
-				const uint8_t *there = here - r[0];
+				const uint8_t *there = here - r0;
 				if (same2(here + 1, there + 1)) {
 					unsigned limit = nice_len + 1;
 					if (limit > room_full)
@@ -600,7 +606,7 @@ template <int FORMAT> struct BlockEncoder {
 			{
 				uint16_t h, t0, t1, t2, t3;
 				memcpy(&h, here, 2);
-				memcpy(&t0, here - r[0], 2);
+				memcpy(&t0, here - r0, 2);
 				memcpy(&t1, here - r[1], 2);
 				memcpy(&t2, here - r[2], 2);
 				memcpy(&t3, here - r[3], 2);
@@ -664,31 +670,47 @@ template <int FORMAT> struct BlockEncoder {
 		// lanes' distance prices and edge codes are merged under those masks, then ONE compare-and-store prices all
 		// of it.  The loop below does the same pair by pair; its trip count is a mispredicted branch per position.
 		if (PACKED && pairs <= 4 && hi - lo < 16 && hi == list.len(pairs - 1)) {
-			const unsigned last = pairs - 1;
-			const uint32_t w0 = list.w[0], w1 = list.w[last < 1 ? last : 1], w2 = list.w[last < 2 ? last : 2], w3 = list.w[last];
-			if (!compound || !((w0 | w1 | w2 | w3) >> 31)) {
-				const __m512i iota = _mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-				const __m512i lens = _mm512_add_epi32(_mm512_set1_epi32((int)lo), iota);
+			// the (at most four) words of the list as one vector; lanes beyond the list are zero and inert: length 2, no
+			// lane left for them (the last real pair has taken everything up to hi)
+			const __m128i wv = _mm_maskz_loadu_epi32((__mmask8)((1u << pairs) - 1), list.w);
+			if (!compound || !_mm_movemask_ps(_mm_castsi128_ps(wv))) {
+				const __m512i lens = _mm512_add_epi32(_mm512_set1_epi32((int)lo), _mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15));
 				const __mmask16 live = _mm512_cmple_epu32_mask(lens, _mm512_set1_epi32((int)hi));
 				const __m512i ctx = _mm512_min_epu32(_mm512_sub_epi32(lens, _mm512_set1_epi32((int)kLenMin)), _mm512_set1_epi32((int)kLenToDistStates - 1));
-				__mmask16 open = live;
-				__m512i dist_price = _mm512_setzero_si512(), codes = _mm512_setzero_si512();
-				const uint8_t *src_base = data + fetch_pos - 2;
-				const uint32_t ws[4] = {w0, w1, w2, w3};
-				for (unsigned j = 0; j < 4; j++) { // (unrolled: constant trip count)
-					const uint32_t d = ws[j] & 0x1FFFFFFu;
-					const unsigned plen = ((ws[j] >> 25) & 63) + 2;
-					const bool near = d < kNearDistances;
-					const uint32_t *tab = near ? prices.near_dist[d] : prices.slot[dist_slot(near ? kNearDistances : d)];
-					const uint32_t add = near ? 0 : prices.align[d & (kAlignSize - 1)];
-					const __m128i d4 = _mm_add_epi32(_mm_load_si128((const __m128i *)tab), _mm_set1_epi32((int)add));
-					__builtin_prefetch(src_base + plen - d);
-					const __mmask16 mine = _mm512_mask_cmple_epu32_mask(open, lens, _mm512_set1_epi32((int)plen));
-					open = (__mmask16)(open & ~mine);
-					dist_price = _mm512_mask_permutexvar_epi32(dist_price, mine, ctx, _mm512_castsi128_si512(d4));
-					codes = _mm512_mask_set1_epi32(codes, mine, (int)(d + kRepSlots));
-				}
-				const __m512i cand = _mm512_add_epi32(_mm512_add_epi32(_mm512_set1_epi32((int)base), dist_price), _mm512_maskz_loadu_epi32(live, len_row + lo));
+				// per pair, for all four at once: distance, length, edge code, the row of its distance prices (a near
+				// distance has its own row; a far one the row of its slot = 2 * floor(log2 d) + the bit below the top
+				// one, and the price of its low four bits on top)
+				const __m128i dv = _mm_and_si128(wv, _mm_set1_epi32(0x1FFFFFF));
+				const __m128i plenv = _mm_add_epi32(_mm_and_si128(_mm_srli_epi32(wv, 25), _mm_set1_epi32(63)), _mm_set1_epi32((int)kLenMin));
+				const __mmask8 far = _mm_cmpge_epu32_mask(dv, _mm_set1_epi32((int)kNearDistances));
+				const __m128i top = _mm_sub_epi32(_mm_set1_epi32(31), _mm_lzcnt_epi32(dv));
+				const __m128i below = _mm_and_si128(_mm_srlv_epi32(dv, _mm_sub_epi32(top, _mm_set1_epi32(1))), _mm_set1_epi32(1));
+				const __m128i far_row = _mm_add_epi32(_mm_add_epi32(_mm_slli_epi32(top, 1), below), _mm_set1_epi32((int)kNearDistances));
+				const __m128i row_off = _mm_slli_epi32(_mm_mask_mov_epi32(dv, far, far_row), 4); // bytes into dist_rows
+				const __m512i plen16 = _mm512_castsi128_si512(plenv), code16 = _mm512_castsi128_si512(_mm_add_epi32(dv, _mm_set1_epi32((int)kRepSlots)));
+				const __m512i low16 = _mm512_maskz_permutexvar_epi32((__mmask16)far, _mm512_castsi128_si512(_mm_and_si128(dv, _mm_set1_epi32((int)kAlignSize - 1))),
+										  _mm512_load_si512((const void *)prices.align));
+				// pair j takes the lanes up to its length that pair j - 1 has not taken (lengths increase along the list):
+				// four independent compares, not a chain through "what is still open"; the three per-lane quantities are
+				// picked per pair under those masks and merged pairwise (short dependency chains: the node's edges
+				// cannot be priced before this is through, and the next node cannot retire before this one)
+				const __m128i row_off_x = row_off;
+				const char *rows = (const char *)prices.dist_rows;
+				const __mmask16 le0 = _mm512_mask_cmple_epu32_mask(live, lens, _mm512_permutexvar_epi32(_mm512_set1_epi32(0), plen16));
+				const __mmask16 le1 = _mm512_mask_cmple_epu32_mask(live, lens, _mm512_permutexvar_epi32(_mm512_set1_epi32(1), plen16));
+				const __mmask16 le2 = _mm512_mask_cmple_epu32_mask(live, lens, _mm512_permutexvar_epi32(_mm512_set1_epi32(2), plen16));
+				const __mmask16 le3 = _mm512_mask_cmple_epu32_mask(live, lens, _mm512_permutexvar_epi32(_mm512_set1_epi32(3), plen16));
+				const __mmask16 m0 = le0, m1 = (__mmask16)(le1 & ~le0), m2 = (__mmask16)(le2 & ~(le1 | le0)), m3 = (__mmask16)(le3 & ~(le2 | le1 | le0));
+#define LRZ_ROW(j) _mm512_castsi128_si512(_mm_load_si128((const __m128i *)(rows + (uint32_t)_mm_extract_epi32(row_off_x, j))))
+				const __m512i dist_price = _mm512_or_si512(
+					_mm512_or_si512(_mm512_maskz_permutexvar_epi32(m0, ctx, LRZ_ROW(0)), _mm512_maskz_permutexvar_epi32(m1, ctx, LRZ_ROW(1))),
+					_mm512_or_si512(_mm512_maskz_permutexvar_epi32(m2, ctx, LRZ_ROW(2)), _mm512_maskz_permutexvar_epi32(m3, ctx, LRZ_ROW(3))));
+#undef LRZ_ROW
+				// the lane's pair: 0..3 (a lane no pair takes is not live)
+				const __m512i which = _mm512_mask_set1_epi32(_mm512_mask_set1_epi32(_mm512_maskz_set1_epi32(m1, 1), m2, 2), m3, 3);
+				const __m512i codes = _mm512_permutexvar_epi32(which, code16);
+				const __m512i low_price = _mm512_permutexvar_epi32(which, low16);
+				const __m512i cand = _mm512_add_epi32(_mm512_add_epi32(_mm512_set1_epi32((int)base), dist_price), _mm512_add_epi32(low_price, _mm512_maskz_loadu_epi32(live, len_row + lo)));
 				uint32_t *cp = cost + cur + lo;
 				const __mmask16 win = _mm512_mask_cmplt_epu32_mask(live, cand, _mm512_maskz_loadu_epi32(live, cp));
 				_mm512_mask_storeu_epi32(cp, win, cand);

@@ -1,6 +1,7 @@
 // rzip_resolve_mw.h -- K2 on NW wavefronts (included by rzip_scan.hip, inside namespace lrzgpu).
 //
-// k_resolve is bound by the instruction issue of ONE wavefront: a round costs ~5000 instructions
+// The one-wavefront resolver of rounds 1 and 2 (tools/experiments/resolver_one_wavefront.hip.inc) is bound by the
+// instruction issue of ONE wavefront: a round costs ~5000 instructions
 // whatever the number of lanes it commits.  Here the same round runs on NW wavefronts of one
 // workgroup (their own SIMDs) over a window of 64 * NW candidates, lane gi = 64 * wave + lane in
 // candidate order:
@@ -13,7 +14,7 @@
 //   * the automaton itself (masks, hash_count, sweep pointer, lazy match, records) lives in wave 0,
 //     which publishes what the others need at the start of a round and makes every exact serial step;
 //   * the window only moves through LDS when a round stops early; a full commit empties it.
-// Bit-exact by the same argument as k_resolve: a prefix of the window is committed only if every lane
+// Bit-exact by the same argument as on one wavefront: a prefix of the window is committed only if every lane
 // in it was simulated against a table that no earlier lane of the round writes into its read interval.
 // Twins are predicted inside a wave (a pair across two waves takes the conflict path).
 #pragma once

@@ -12,8 +12,10 @@
 //                      workgroup prefix sum.  HBM-bound: 1 B read per position.
 //      k_tile_scan /   exclusive scan of the per-tile counts and the packed, position-ordered
 //      k_compact_cands candidate list of the segment (64 candidates per resolver load at any density).
-//   K2 k_resolve       one wavefront.  The exact hash-table automaton over the candidates, as a
-//                      speculative in-order window: up to 64 candidates, one per lane, are simulated
+//   K2 k_resolve_mw<4> one workgroup of four wavefronts (rzip_resolve_mw.h; the one-wavefront kernel it
+//                      grew out of: tools/experiments/resolver_one_wavefront.hip.inc).  The exact
+//                      hash-table automaton over the candidates, as a
+//                      speculative in-order window: 256 candidates, one per lane, are simulated
 //                      against the table as it stands (walks over one rank byte and one fingerprint
 //                      byte per slot, 64 slots per step, 8 slots per SWAR operation; twins with the
 //                      same tag on top of their predecessor's predicted insert), the longest prefix
@@ -60,10 +62,7 @@ constexpr int A1_MAX_STEPS = 8192; // slots a speculative walk may cover (longer
 constexpr int MAX_EQS = 32;  // round-robin eviction handled in the batch up to this max_chain_len
 constexpr int MAX_HITS = 24; // tag hits one speculative lookup may verify (more -> serial path)
 // the 8-wavefront resolver trades both for window: 160 KB of LDS hold 512 candidates with these (levels <= 7 only)
-constexpr int MAX_EQS_W8 = 16;
-constexpr int MAX_HITS_W8 = 16;
 constexpr int CF_BITS = 13; // conflict filter: 16-bit write counters per hashed 8-slot granule (<= 320 writes per round)
-constexpr int CF_WORDS = (1 << CF_BITS) / 2;
 
 typedef unsigned long long u64;
 typedef long long i64;
@@ -749,7 +748,7 @@ struct Resolver {
 };
 
 // Per-lane speculative simulation of one automaton step against the table as it stands at the
-// start of a batch (see k_resolve).  Everything it would read lies in [lo, hi]; everything it
+// start of a round (see k_resolve_mw).  Everything it would read lies in [lo, hi]; everything it
 // would write is listed in w_*.
 struct LaneSim {
 	bool complex_;   // must take the serial path (victim round-robin, wrap, deep displacement, ...)
@@ -1175,639 +1174,6 @@ __device__ __forceinline__ void simulate_lanes(const Resolver &R, const Slot *__
 				L.complex_ = true; // deeper than the write list allows
 		}
 }
-
-__global__ void __launch_bounds__(64) k_resolve(const uint8_t *__restrict__ buf, Slot *__restrict__ tbl, ScanState *__restrict__ st,
-						i64 seg_lo, int ntiles, const uint32_t *__restrict__ cand_rel,
-						const u64 *__restrict__ cand_tag, const uint32_t *__restrict__ tile_count,
-						MatchRec *__restrict__ records, int batch_mode, const uint32_t *__restrict__ tile_base,
-						const uint32_t *__restrict__ comp_rel, const u64 *__restrict__ comp_tag, uint32_t comp_cap,
-						uint8_t *__restrict__ rank_bytes, uint8_t *__restrict__ fp_bytes)
-{
-	__shared__ u64 stk_t[64];
-	__shared__ i64 stk_off[64];
-	__shared__ i64 stk_h[64];
-	__shared__ uint32_t vict[64];
-	__shared__ i64 ring_pos[256];
-	__shared__ u64 ring_tag[256];
-	__shared__ i64 hit_lds[MAX_HITS * 64];
-	__shared__ uint32_t eqs_lds[MAX_EQS * 64]; // per window ticket: slots of the first equal tags of the insert walk
-	__shared__ uint32_t cf_bits[CF_WORDS]; // all zero between rounds
-
-	Resolver R;
-	R.buf = buf;
-	R.tbl = tbl;
-	R.rk = rank_bytes;
-	R.fpa = fp_bytes;
-	R.lane = threadIdx.x;
-	R.hmask = ((u64)1 << st->hash_bits) - 1;
-	R.end = st->end;
-	R.last_match = st->last_match;
-	R.tag_mask = st->tag_mask;
-	R.min_mask = st->min_mask;
-	R.hash_count = st->hash_count;
-	R.hash_limit = st->hash_limit;
-	R.clean_ptr = st->clean_ptr;
-	R.victim_round = st->victim_round;
-	R.max_chain = st->max_chain_len;
-	R.tag_hits = st->tag_hits;
-	R.tag_misses = st->tag_misses;
-	R.stk_t = stk_t;
-	R.stk_off = stk_off;
-	R.stk_h = stk_h;
-	R.hint_p = st->hint_p;
-	R.hint_op = st->hint_op;
-	R.hint_len = st->hint_len;
-	R.allow_abort = true;
-	R.aborted = false;
-	R.ext_p = R.ext_op = R.ext_done = 0;
-	for (int k = threadIdx.x; k < CF_WORDS; k += 64)
-		cf_bits[k] = 0;
-
-	i64 p_skip = st->p_skip;
-	i64 cur_p = st->cur_p, cur_ofs = st->cur_ofs, cur_len = st->cur_len;
-	i64 n_rec = st->n_records;
-	const i64 rec_cap = st->rec_cap;
-	i64 inserts = st->inserts, lookups = st->lookups;
-	int error = st->error;
-	u64 sink = 0;
-	i64 miss_acc = 0; // tag_misses of committed batch lanes, per lane
-	i64 dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-	u64 tclk = __builtin_amdgcn_s_memtime();
-	const bool prof = (batch_mode & 2) != 0; // per-phase cycle laps cost ~2 SMEM round trips each: opt-in
-	auto lap = [&](int slot) {
-		if (!prof)
-			return;
-		const u64 now = __builtin_amdgcn_s_memtime();
-		dbg[slot] += (i64)(now - tclk);
-		tclk = now;
-	};
-	const int lane = threadIdx.x;
-	const u64 lane_bit = 1ull << lane;
-	const u64 lanes_below = lane_bit - 1;
-	const i64 tbl_size = (i64)R.hmask + 1;
-
-	// One exact automaton step at candidate (P, T): the serial path.
-	auto serial_step = [&](i64 P, u64 T) {
-		dbg[2]++;
-		// After an emission the reference resumes at last_match + 1 (src/rzip.c:685-687); when the
-		// emitted match ends BEFORE P -- the emission was delayed until this candidate -- P itself
-		// is examined a second time (it is the only candidate in (last_match, P]).
-		bool again;
-		R.allow_abort = true; // only the first examination of P can be replayed by a relaunch
-		do {
-			again = false;
-			i64 offset = 0, reverse = 0;
-			lookups++;
-			const i64 hits0 = R.tag_hits, misses0 = R.tag_misses;
-			i64 mlen = R.lookup(T, P, &offset, &reverse);
-			if (R.aborted) {
-				// nothing of this candidate has been applied yet: resume at P with the extent known
-				lookups--;
-				dbg[2]--;
-				R.tag_hits = hits0;
-				R.tag_misses = misses0;
-				if (P - 1 > p_skip)
-					p_skip = P - 1;
-				error = 3;
-				return;
-			}
-			R.allow_abort = false;
-
-			if ((T & R.tag_mask) == R.tag_mask) {
-				inserts++;
-				R.hash_count++;
-				R.insert(T, P);
-				if (R.hash_count > R.hash_limit)
-					R.tag_mask = R.clean_one();
-			}
-			if (mlen > cur_len) {
-				cur_p = P - reverse;
-				cur_len = mlen;
-				cur_ofs = offset;
-			}
-			if ((cur_len >= GREAT_MATCH || P >= cur_p + MINIMUM_MATCH) && cur_len >= MINIMUM_MATCH) {
-				if (n_rec >= rec_cap) {
-					error = 1;
-					return;
-				}
-				if (lane == 0) {
-					MatchRec r;
-					r.p = cur_p;
-					r.ofs = cur_ofs;
-					r.len = cur_len;
-					records[n_rec] = r;
-				}
-				n_rec++;
-				R.last_match = cur_p + cur_len;
-				p_skip = R.last_match;
-				cur_p = R.last_match;
-				cur_len = 0;
-				again = P > p_skip && P <= R.end && (T & R.min_mask) == R.min_mask;
-			}
-		} while (again);
-	};
-
-	// ---- candidate stream: compacted (pos, tag) queue in LDS, refilled from the K1 tiles ----
-	int tile = 0;
-	uint32_t tb0 = 0;
-	int ring_head = 0, ring_cnt = 0;
-	// packed candidate list of the segment (K1c); the per-tile lists remain the fallback when a
-	// pathological segment has more candidates than the packed buffers hold
-	const uint32_t ctotal = tile_base[ntiles];
-	const bool packed = ctotal <= comp_cap;
-	uint32_t cpos = 0;
-	i64 skip_seen = p_skip;
-	auto refill_ring = [&]() {
-		if (packed) {
-			if (p_skip != skip_seen) { // a match was emitted: jump over the candidates inside it
-				skip_seen = p_skip;
-				if (p_skip >= seg_lo) {
-					const i64 t = (p_skip + 1 - seg_lo) / TILE;
-					const uint32_t c0 = t < ntiles ? tile_base[t] : ctotal;
-					if (c0 > cpos)
-						cpos = c0;
-				}
-			}
-			while (ring_cnt <= 192 && cpos < ctotal) {
-				i64 pos = -1;
-				u64 tag = 0;
-				if (cpos + lane < ctotal) {
-					pos = seg_lo + (i64)comp_rel[cpos + lane];
-					tag = comp_tag[cpos + lane];
-				}
-				const bool ok = pos > p_skip && (tag & R.min_mask) == R.min_mask;
-				const u64 m = __ballot(ok);
-				if (ok) {
-					const int slot = (ring_head + ring_cnt + __popcll(m & lanes_below)) & 255;
-					ring_pos[slot] = pos;
-					ring_tag[slot] = tag;
-				}
-				ring_cnt += __popcll(m);
-				cpos += 64;
-			}
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-			return;
-		}
-		while (ring_cnt <= 192 && tile < ntiles) {
-			const uint32_t cnt = tile_count[tile];
-			if (tb0 >= cnt || seg_lo + (i64)(tile + 1) * TILE - 1 <= p_skip) { // exhausted / inside a match
-				tile++;
-				tb0 = 0;
-				continue;
-			}
-			const size_t base = (size_t)tile * TILE;
-			i64 pos = -1;
-			u64 tag = 0;
-			if (tb0 + lane < cnt) {
-				pos = seg_lo + (i64)cand_rel[base + tb0 + lane];
-				tag = cand_tag[base + tb0 + lane];
-			}
-			const bool ok = pos > p_skip && (tag & R.min_mask) == R.min_mask;
-			const u64 m = __ballot(ok);
-			if (ok) {
-				const int slot = (ring_head + ring_cnt + __popcll(m & lanes_below)) & 255;
-				ring_pos[slot] = pos;
-				ring_tag[slot] = tag;
-			}
-			ring_cnt += __popcll(m);
-			tb0 += 64;
-		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-	};
-
-	// ---- in-order window of up to 64 candidates, one per lane (lane order = candidate order) ----
-	int wcount = 0;
-	i64 w_pos = -1;
-	u64 w_tag = 0;
-	bool w_simd = false;
-	int w_ticket = 0; // stable id of the window entry (index into eqs_lds), travels with the shifts
-	int next_ticket = 0;
-	LaneSim L;
-	L.complex_ = L.match = L.ins = L.victim = false;
-	L.twin = L.tw_over = false;
-	L.tw_kind = 0;
-	L.k0 = -1;
-	L.tw_slot = 0;
-	L.dec = L.misses = L.nw = 0;
-	L.lo = L.hi = 0;
-	for (int k = 0; k < 4; k++) {
-		L.w_slot[k] = 0;
-		L.w_t[k] = 0;
-		L.w_off[k] = 0;
-	}
-	auto shift_window = [&](int c) { // drop the first c lanes
-		if (c <= 0)
-			return;
-		const int src = (lane + c) & 63;
-		w_pos = (i64)bcast64((u64)w_pos, src);
-		w_tag = bcast64(w_tag, src);
-		w_simd = __shfl((int)w_simd, src) != 0;
-		w_ticket = __shfl(w_ticket, src);
-		L.victim = __shfl((int)L.victim, src) != 0;
-		L.complex_ = __shfl((int)L.complex_, src) != 0;
-		L.match = __shfl((int)L.match, src) != 0;
-		L.ins = __shfl((int)L.ins, src) != 0;
-		L.twin = __shfl((int)L.twin, src) != 0;
-		L.tw_over = __shfl((int)L.tw_over, src) != 0;
-		L.tw_kind = __shfl(L.tw_kind, src);
-		L.k0 = __shfl(L.k0, src);
-		L.tw_slot = __shfl(L.tw_slot, src);
-		L.dec = __shfl(L.dec, src);
-		L.misses = __shfl(L.misses, src);
-		L.nw = __shfl(L.nw, src);
-		L.lo = __shfl(L.lo, src);
-		L.hi = __shfl(L.hi, src);
-#pragma unroll
-		for (int k = 0; k < 4; k++) {
-			L.w_slot[k] = __shfl(L.w_slot[k], src);
-			L.w_t[k] = bcast64(L.w_t[k], src);
-			L.w_off[k] = (i64)bcast64((u64)L.w_off[k], src);
-		}
-		wcount -= c;
-		if (lane >= wcount)
-			w_simd = false;
-	};
-
-	int poor_rounds = 0, serial_left = 0;
-	while (!error) {
-		lap(13);
-		refill_ring();
-		// top up the window from the queue
-		{
-			int k = 64 - wcount;
-			if (k > ring_cnt)
-				k = ring_cnt;
-			if (k > 0) {
-				if (lane >= wcount && lane < wcount + k) {
-					const int slot = (ring_head + lane - wcount) & 255;
-					w_pos = ring_pos[slot];
-					w_tag = ring_tag[slot];
-					w_simd = false;
-					w_ticket = (next_ticket + lane - wcount) & 63;
-				}
-				next_ticket = (next_ticket + k) & 63;
-				ring_head = (ring_head + k) & 255;
-				ring_cnt -= k;
-				wcount += k;
-			}
-		}
-		if (wcount == 0)
-			break;
-
-		const bool has = lane < wcount;
-		const bool alive = has && w_pos > p_skip && (w_tag & R.min_mask) == R.min_mask;
-
-		// ---- serial path: pending lazy match, batching disabled, or batching not paying off ----
-		// (inputs whose tags collapse onto a few buckets -- 4-symbol alphabets, long runs -- make
-		// every lane conflict with its predecessor; a failed round costs more than a serial step)
-		if (!(batch_mode & 1) || cur_len > 0 || serial_left > 0) {
-			if (serial_left > 0)
-				serial_left--;
-			const i64 P = (i64)bcast64((u64)w_pos, 0);
-			const u64 T = bcast64(w_tag, 0);
-			const bool a0 = __shfl((int)alive, 0) != 0;
-			shift_window(1);
-			if (a0)
-				serial_step(P, T);
-			w_simd = false; // the table changed in ways the sims did not see
-			continue;
-		}
-
-		const u64 better = mask_up(R.min_mask);
-		// the sweep of clean_one_from_hash() continues at clean_ptr: fetch its next 128 slots now so
-		// that the round trip overlaps the simulations (nothing writes the table before phase D)
-		const bool may_clean = R.hash_count + 64 > R.hash_limit;
-		uint32_t pre0 = 0, pre1 = 0; // rank bytes
-		if (may_clean) {
-			const i64 q0 = R.clean_ptr + lane;
-			if (q0 < tbl_size)
-				pre0 = R.rk[q0];
-			if (q0 + 64 < tbl_size)
-				pre1 = R.rk[q0 + 64];
-		}
-		lap(8);
-
-		// Phase A/B: lanes without a valid simulation run one against the table as it stands.
-		// The three sub-phases are wave-convergent so that every dependent HBM round trip is
-		// shared by all simulating lanes: (A1) lookup walk in 8-slot chunks, (A2) verification of
-		// tag hits, (A3) the displacement chain of the insert, one level at a time.
-		const bool need_sim = alive && !w_simd;
-		if (__ballot(need_sim)) {
-			simulate_lanes<MAX_HITS, MAX_EQS>(R, tbl, buf, tbl_size, better, lane, alive, need_sim, w_tag, w_pos, w_ticket, hit_lds, eqs_lds, 64, L, lap);
-			if (need_sim)
-				w_simd = true;
-			lap(15);
-		}
-
-
-		lap(9);
-		// Phase C: in-order commit of the longest conflict-free prefix, computed in parallel.
-		// hash_count saturates at hash_limit: every insert that pushes it over triggers exactly
-		// one clean (src/rzip.c:665-671).
-		const bool live = alive; // dead lanes (inside a match / mask tightened) commit as no-ops
-		const int x = (live && L.ins && !L.dec && !L.complex_ && !L.match) ? 1 : 0;
-		const int px = x + __popcll(__ballot(x != 0) & lanes_below); // inclusive prefix count
-		const i64 hc_before = R.hash_count + (px - x) < R.hash_limit ? R.hash_count + (px - x) : R.hash_limit;
-		const bool cleans = x && hc_before + 1 > R.hash_limit;
-		const u64 clean_m = __ballot(cleans);
-		const int kth = __popcll(clean_m & lanes_below);
-		const int want = __popcll(clean_m);
-		// round-robin evictions: victim_round advances by one per eviction (src/rzip.c:332-341)
-		const bool evicts = live && L.victim && !L.complex_ && !L.match;
-		const u64 evict_m = __ballot(evicts);
-		if (evicts) {
-			const uint32_t r = (uint32_t)((R.victim_round + __popcll(evict_m & lanes_below)) % (i64)R.max_chain);
-			L.w_slot[0] = eqs_lds[r * 64 + w_ticket];
-		}
-
-		// victim list: the next `want` entries the sweep would delete, in sweep order
-		const int vic_nb1 = __popcll(better) + 1;
-		int nv = 0;
-		i64 scan_end = R.clean_ptr;
-		if (want) {
-			i64 ptr = R.clean_ptr;
-			int rounds = 0;
-			while (nv < want && ptr < tbl_size && rounds < 512) {
-				const i64 q = ptr + lane;
-				bool cand = false;
-				if (q < tbl_size) {
-					const uint32_t rv = (may_clean && rounds == 0) ? pre0 : (may_clean && rounds == 1) ? pre1 : (uint32_t)R.rk[q];
-					cand = rv != 0 && rv < (uint32_t)vic_nb1; // occupied and due for cleaning
-				}
-				const u64 m = __ballot(cand);
-				const int r = nv + __popcll(m & lanes_below);
-				if (cand && r < 64)
-					vict[r] = (uint32_t)q;
-				nv += __popcll(m);
-				ptr += 64;
-				rounds++;
-			}
-			scan_end = ptr < tbl_size ? ptr : tbl_size;
-			if (nv > 64)
-				nv = 64;
-		}
-		lap(10);
-		uint32_t my_vict = 0xFFFFFFFFu;
-		int sub = 0; // diagnostics: what kind of conflict (counted in dbg[8..15] when the cycle laps are off)
-		int why = 0; // 3 complex, 4 match, 5 conflict, 6 no victim, 7 swept range
-		bool stop = false;
-		if (live && L.complex_) {
-			stop = true;
-			why = 3;
-		} else if (live && L.match) {
-			stop = true;
-			why = 4;
-		}
-		if (cleans) {
-			if (kth < nv)
-				my_vict = vict[kth];
-			else if (!stop) {
-				stop = true; // sweep wrap / no victim in reach: serial path
-				why = 6;
-			}
-		}
-		// the first clean of a chunk switches tag_mask from the initial mask to `better`
-		// (src/rzip.c:669-671): lanes after it were simulated with the old insert mask
-		if (R.tag_mask != better && clean_m && live && !stop && lane > __ffsll((long long)clean_m) - 1) {
-			stop = true;
-			why = 3;
-		}
-		// an insert landing inside the swept range could change what the sweep meets
-		if (live && want && !stop)
-			for (int k = 0; k < 4; k++)
-				if (k < L.nw && (i64)L.w_slot[k] >= R.clean_ptr && (i64)L.w_slot[k] < scan_end) {
-					stop = true;
-					why = 7;
-				}
-		// twin successors: did the predecessor's simulation make exactly the predicted insert?
-		const bool tw_live = live && L.twin && !L.complex_ && !L.match;
-		if (__ballot(tw_live)) {
-			const uint32_t p_slot = __shfl_up(L.w_slot[0], 1);
-			const int p_nw = __shfl_up(L.nw, 1), p_k0 = __shfl_up(L.k0, 1);
-			const int p_ok = __shfl_up((int)(live && L.ins && !L.complex_ && !L.match && !L.victim && !stop), 1);
-			if (tw_live && !stop && !(lane > 0 && p_ok && p_nw >= 1 && p_slot == L.tw_slot && p_k0 == L.tw_kind)) {
-				stop = true;
-				why = 5; // re-simulated as the first lane of the next round
-				sub = lane == 0 ? 1 : !p_ok ? 2 : p_slot != L.tw_slot ? 3 : 4;
-			}
-		}
-		// conflicts: the EARLIEST lane whose write (insert, displacement or clean) lies inside my
-		// read interval (at 8-slot granule resolution).  Filter first: every writer counts its written
-		// granules into a small LDS table of hashed counters, every reader looks up the granules of
-		// its interval (minus its own writes); the few lanes that see a foreign write get the exact
-		// answer from the writers' registers.
-		// granule of the filter: clusters (and so read intervals) grow with the tag mask
-		int gsh = __popcll(R.min_mask) - 2;
-		gsh = gsh < 3 ? 3 : gsh > 16 ? 16 : gsh;
-		uint32_t wr[5], wh[5];
-#pragma unroll
-		for (int k = 0; k < 5; k++) {
-			wr[k] = 0xFFFFFFFFu;
-			if (live) {
-				if (k < 4) {
-					if (k < L.nw)
-						wr[k] = L.w_slot[k];
-				} else
-					wr[k] = my_vict;
-			}
-			wh[k] = wr[k] != 0xFFFFFFFFu ? ((wr[k] >> gsh) * 2654435761u) >> (32 - CF_BITS) : 0xFFFFFFFFu;
-		}
-#pragma unroll
-		for (int k = 0; k < 5; k++)
-			if (wh[k] != 0xFFFFFFFFu)
-				__hip_atomic_fetch_add(&cf_bits[wh[k] >> 1], 1u << (16 * (wh[k] & 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-		const bool reads = live && !L.complex_ && !L.match; // lanes that stop anyway need no conflict test
-		const uint32_t r_lo = L.lo & ~7u, r_hi = L.hi | 7u;
-		// a twin successor expects exactly one foreign write in its interval: its predecessor's insert
-		const uint32_t tw_h = tw_live && !stop ? ((L.tw_slot >> gsh) * 2654435761u) >> (32 - CF_BITS) : 0xFFFFFFFFu;
-		bool flagged = false;
-		if (reads) {
-			const uint32_t g1 = L.hi >> gsh;
-			uint32_t expect = tw_h != 0xFFFFFFFFu ? 1u : 0u; // not yet seen
-			for (uint32_t g = L.lo >> gsh; g <= g1; g += 2) {
-				uint32_t acc = 0;
-#pragma unroll
-				for (uint32_t u = 0; u < 2; u++) {
-					const bool dup = u && g + u > g1; // second probe past the interval: skip
-					const uint32_t gg = dup ? g : g + u;
-					const uint32_t hb = (gg * 2654435761u) >> (32 - CF_BITS);
-					uint32_t cnt = (cf_bits[hb >> 1] >> (16 * (hb & 1))) & 0xFFFFu;
-#pragma unroll
-					for (int q = 0; q < 5; q++)
-						cnt -= wh[q] == hb;
-					if (!dup && expect && hb == tw_h && cnt) {
-						cnt--;
-						expect = 0;
-					}
-					acc |= dup ? 0 : cnt;
-				}
-				if (acc)
-					flagged = true;
-			}
-		}
-		int first_conf = 64;
-		{
-			const u64 tw_live_m = __ballot(tw_live);
-			u64 fm = __ballot(flagged);
-			int budget = 16;
-			while (fm) {
-				const int k = __ffsll((long long)fm) - 1;
-				fm &= fm - 1;
-				if (budget-- <= 0) { // too many suspects: call the rest conflicting (they re-simulate)
-					if (flagged && lane >= k)
-						first_conf = 0;
-					break;
-				}
-				const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)r_lo, k), khi = (uint32_t)__builtin_amdgcn_readlane((int)r_hi, k);
-				const bool k_twin = (tw_live_m >> k) & 1; // its predecessor's insert is already part of its simulation
-				bool hit = false;
-#pragma unroll
-				for (int q = 0; q < 5; q++)
-					hit |= wr[q] != 0xFFFFFFFFu && wr[q] >= klo && wr[q] <= khi && !(q == 0 && k_twin && lane == k - 1);
-				const u64 hm = __ballot(hit && lane < k);
-				if (lane == k && hm)
-					first_conf = __ffsll((long long)hm) - 1;
-			}
-		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll
-		for (int k = 0; k < 5; k++)
-			if (wh[k] != 0xFFFFFFFFu)
-				cf_bits[wh[k] >> 1] = 0;
-		const bool conflict = first_conf < 64;
-		lap(11);
-		if (!stop && conflict)
-			why = 5;
-		const u64 bad = __ballot(live && (stop || conflict));
-		int f = bad ? __ffsll((long long)bad) - 1 : 64;
-		if (f > wcount)
-			f = wcount;
-		dbg[0]++;
-		const int why_f = f < 64 ? __shfl(why, f) : 0;
-		if (f < wcount && why_f >= 3 && why_f <= 7)
-			dbg[why_f]++;
-		if (!prof && f < wcount && why_f == 5) {
-			// 8: twin arrived as lane 0, 9: twin's predecessor not committable, 10: predecessor wrote elsewhere,
-			// 11: other kind of stop than predicted, 12: write of the SAME tag by the lane before (unpredicted twin),
-			// 13: write of the same tag further back, 14: unrelated write in the interval, 15: suspects over budget
-			const int sub_f = __shfl(sub, f);
-			const int fc = __shfl(first_conf, f);
-			int code = 7 + sub_f;
-			if (sub_f == 0) {
-				const u64 tf = bcast64(w_tag, f);
-				const u64 tc = bcast64(w_tag, fc < 64 ? fc : 0);
-				code = fc >= 64 ? 15 : tf != tc ? 14 : fc == f - 1 ? 12 : 13;
-			}
-			dbg[code]++;
-		}
-		const bool committed = lane < f && live;
-		if (f < 4 && f < wcount) {
-			if (++poor_rounds >= 8) {
-				poor_rounds = 0;
-				serial_left = 256;
-			}
-		} else
-			poor_rounds = 0;
-
-		// Phase D: apply the committed prefix
-		// (a twin that replaces its predecessor's entry: two lanes, one slot -- the later store is the only one made)
-		const bool nxt_over = __shfl_down((int)(lane < f && live && L.twin && L.tw_over), 1) != 0 && lane < 63;
-		if (committed) {
-			for (int k = 0; k < 4; k++)
-				if (k < L.nw && !(k == 0 && nxt_over))
-					R.store_slot(L.w_slot[k], L.w_t[k], L.w_off[k]);
-			if (cleans)
-				R.store_slot(my_vict, 0, 0);
-		}
-		{
-			const u64 cm = __ballot(committed);
-			const int n_commit = __popcll(cm);
-			if (committed)
-				miss_acc += L.misses; // per lane, summed when the kernel ends
-			const int my_ins = __popcll(__ballot(committed && L.ins));
-			const int my_x = __popcll(__ballot(committed && x));
-			lookups += n_commit;
-			dbg[1] += n_commit;
-			inserts += my_ins;
-			const i64 hc = R.hash_count + my_x;
-			R.hash_count = hc < R.hash_limit ? hc : R.hash_limit;
-			R.victim_round = (R.victim_round + __popcll(evict_m & cm)) % (i64)R.max_chain;
-			const u64 cc = clean_m & cm;
-			if (cc) {
-				const int last = 63 - __clzll((long long)cc);
-				R.clean_ptr = (i64)__shfl(my_vict, last);
-				if (R.tag_mask != better)
-					w_simd = false; // the insert mask changed: every kept simulation is stale
-				R.tag_mask = better; // clean_one_from_hash() returns better_than_min
-			}
-		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
-		lap(12);
-		// simulations that read something a committed lane has just written are stale
-		if (first_conf < f)
-			w_simd = false;
-		if (f < wcount) {
-			if (why_f == 5) {
-				// conflict only: lane f re-simulates against the updated table next round
-				if (lane == f)
-					w_simd = false;
-				shift_window(f);
-			} else {
-				// complex / real match / sweep wrap / swept range: exact serial step (progress)
-				const i64 P = (i64)bcast64((u64)w_pos, f);
-				const u64 T = bcast64(w_tag, f);
-				shift_window(f + 1);
-				serial_step(P, T);
-				w_simd = false;
-			}
-		} else {
-			shift_window(f);
-		}
-	}
-
-#pragma unroll
-	for (int d = 32; d >= 1; d >>= 1)
-		miss_acc += (i64)bcast64((u64)miss_acc, lane ^ d);
-	R.tag_misses += miss_acc;
-	if (lane == 0) {
-		st->p_skip = p_skip;
-		st->last_match = R.last_match;
-		st->cur_p = cur_p;
-		st->cur_ofs = cur_ofs;
-		st->cur_len = cur_len;
-		st->tag_mask = R.tag_mask;
-		st->min_mask = R.min_mask;
-		st->hash_count = R.hash_count;
-		st->clean_ptr = R.clean_ptr;
-		st->victim_round = R.victim_round;
-		st->n_records = n_rec;
-		st->error = error;
-		st->ext_p = R.ext_p;
-		st->ext_op = R.ext_op;
-		st->ext_done = R.ext_done;
-		st->inserts = inserts;
-		st->lookups = lookups;
-		st->tag_hits = R.tag_hits;
-		st->tag_misses = R.tag_misses;
-		for (int k = 0; k < 16; k++)
-			st->dbg[k] += dbg[k];
-	}
-	// keep the prefetch loads observable
-	u64 any = sink;
-#pragma unroll
-	for (int d = 32; d >= 1; d >>= 1)
-		any ^= bcast64(any, lane ^ d);
-	if (lane == 0 && any == 0x9E3779B97F4A7C15ull)
-		st->sink = any;
-}
-
 #include "rzip_resolve_mw.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -2087,16 +1453,10 @@ int scan_workspace_create(ScanWorkspace **out, int rzip_level, int64_t max_chunk
 	HIPCHK(hipMalloc(&w->hx, 256 * 8));
 	{
 		w->batch_mode = 1; // (bit 0: speculative batches; 0 = exact serial steps only, the debugging mode of round 1)
-		const char *pr = getenv("LRZGPU_RESOLVE_PROF"); // bit 1: per-phase cycle counters in the profile
-		if (pr && *pr == '1')
+		const char *pr = getenv("LRZGPU_TRACE"); // bit 1: per-phase cycle counters in the profile (trace level 3)
+		if (pr && atoi(pr) >= 3)
 			w->batch_mode |= 2;
-		// bits 4..7: wavefronts of the resolver workgroup (1 = k_resolve, 2 / 4 / 8 = k_resolve_mw)
-		int nw = 4;
-		if (const char *e = getenv("LRZGPU_RESOLVE_WAVES"))
-			nw = atoi(e);
-		nw = nw >= 8 ? 8 : nw >= 4 ? 4 : nw >= 2 ? 2 : 1;
-		if ((w->batch_mode & 1) && nw > 1)
-			w->batch_mode |= nw << 4;
+		w->batch_mode |= 4 << 4; // (bits 4..7: the wavefronts of the resolver workgroup -- four, k_resolve_mw<4>)
 	}
 	w->seg_cap = (size_t)1 << 28; // up to 256 Mi positions per segment
 	if ((int64_t)w->seg_cap > max_chunk + TILE)
@@ -2193,14 +1553,7 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 		t1.stop();
 		EventTimer t2(s);
 		{
-			int nw = (w->batch_mode >> 4) & 15;
-			if (nw == 8 && chain > (unsigned)MAX_EQS_W8)
-				nw = 4; // (levels 8 and 9: the round-robin eviction needs the longer lists)
-			auto kern = nw == 8   ? k_resolve_mw<8, MAX_HITS_W8, MAX_EQS_W8>
-				    : nw == 4 ? k_resolve_mw<4, MAX_HITS, MAX_EQS>
-				    : nw == 2 ? k_resolve_mw<2, MAX_HITS, MAX_EQS>
-					      : k_resolve;
-			hipLaunchKernelGGL(kern, dim3(1), dim3(nw > 1 ? 64 * nw : 64), 0, s, d_chunk, (Slot *)w->table, w->state, (i64)seg_lo,
+			hipLaunchKernelGGL((k_resolve_mw<4, MAX_HITS, MAX_EQS>), dim3(1), dim3(256), 0, s, d_chunk, (Slot *)w->table, w->state, (i64)seg_lo,
 					   ntiles, (const uint32_t *)w->cand_rel, (const u64 *)w->cand_tag, (const uint32_t *)w->tile_count, w->records,
 					   w->batch_mode, (const uint32_t *)w->tile_base, (const uint32_t *)w->comp_rel, (const u64 *)w->comp_tag,
 					   (uint32_t)w->comp_cap, w->rank_bytes, w->fp_bytes);

@@ -97,20 +97,3 @@ def test_headline_shape(B, O, mib):
     data = bench.make_cfg2(n, 1, torch.device("cuda:0"), "alnum")[:n].cpu().numpy().tobytes()
     st = _check(B, O, data, level=7)
     assert st.match_bytes > (n // 2) - (8 << 20) and st.minimum_tag_mask >= 0x3f
-
-
-@pytest.mark.parametrize("waves", [1, 2, 8])
-def test_resolver_wavefront_counts(B, O, monkeypatch, waves):
-    """The resolver runs on 4 wavefronts by default (k_resolve_mw<4>, a window of 256 candidates); the same round
-    on 2 wavefronts and the single-wavefront k_resolve must produce the same bytes and the same statistics.
-    (The count is read when a scan workspace is created: parked ones are released around the test.)"""
-    B.lib().lrzgpu_trim()
-    monkeypatch.setenv("LRZGPU_RESOLVE_WAVES", str(waves))
-    try:
-        _check(B, O, datagen.text_like(14 * 1048576 + 3, seed=61), level=7)      # table fill, first clean, sweeps, twins
-        _check(B, O, datagen.long_range(6 * 1048576, seed=62, base_frac=0.5, mutate_every=50021), level=7)  # matches, lazy matching
-        _check(B, O, datagen.KINDS["few"](2 * 1048576 + 11, seed=63), level=4)      # collapsed tag space: serial mode, evictions
-        pat = (b"0123456789abcdefghijklmnopqrstu" * 40 + b"XYZ") * 1500
-        _check(B, O, pat, level=7, victim_round=5)                                  # round-robin victims
-    finally:
-        B.lib().lrzgpu_trim()

@@ -71,6 +71,7 @@ static int open_counter(const Counter &c)
 
 // ---- sampling: IP every `period` events of one hardware counter, this thread ----------------------------------------
 struct Sampler {
+	bool ibs_raw = false; // the IBS registers of every sample are kept too (latencies, cache misses, mispredicts)
 	int fd = -1;
 	void *ring = nullptr;
 	size_t ring_bytes = 0;
@@ -80,16 +81,45 @@ struct Sampler {
 		memset(&a, 0, sizeof a);
 		a.type = PERF_TYPE_HARDWARE;
 		a.size = sizeof a;
-		a.config = !strcmp(what, "instructions") ? PERF_COUNT_HW_INSTRUCTIONS : !strcmp(what, "branch-misses") ? PERF_COUNT_HW_BRANCH_MISSES : PERF_COUNT_HW_CPU_CYCLES;
-		a.sample_period = period;
-		a.sample_type = PERF_SAMPLE_IP;
-		a.exclude_kernel = 1;
-		a.exclude_hv = 1;
+		a.config = !strcmp(what, "instructions") ? PERF_COUNT_HW_INSTRUCTIONS : !strcmp(what, "branch-misses") ? PERF_COUNT_HW_BRANCH_MISSES :
+			   !strcmp(what, "cache-misses") ? PERF_COUNT_HW_CACHE_MISSES : PERF_COUNT_HW_CPU_CYCLES;
+		if (!strcmp(what, "l1d-misses")) {
+			a.type = PERF_TYPE_HW_CACHE;
+			a.config = PERF_COUNT_HW_CACHE_L1D | (PERF_COUNT_HW_CACHE_OP_READ << 8) | (PERF_COUNT_HW_CACHE_RESULT_MISS << 16);
+		}
+		bool ibs = false;
+		if (!strcmp(what, "ibs-op") || !strcmp(what, "ibs-cycles")) {
+			// AMD instruction based sampling: the sampled op's own address, no skid.  ibs-op counts dispatched ops
+			// (an instruction-weighted profile), ibs-cycles counts cycles.
+			FILE *t = fopen("/sys/bus/event_source/devices/ibs_op/type", "r");
+			int ty = -1;
+			if (!t || fscanf(t, "%d", &ty) != 1 || ty < 0) {
+				fprintf(stderr, "no ibs_op PMU here\n");
+				return false;
+			}
+			fclose(t);
+			a.type = (uint32_t)ty;
+			a.config = !strcmp(what, "ibs-op") ? (1ull << 19) : 0;
+			a.sample_period = (period + 15) & ~15ull;
+			ibs = true;
+			ibs_raw = true;
+		}
+		if (!strncmp(what, "raw:", 4)) { // raw:<hex event code of this CPU's PMU>
+			a.type = PERF_TYPE_RAW;
+			a.config = strtoull(what + 4, nullptr, 16);
+		}
+		if (!a.sample_period)
+			a.sample_period = period;
+		a.sample_type = PERF_SAMPLE_IP | (ibs_raw ? PERF_SAMPLE_RAW : 0);
+		a.exclude_kernel = ibs ? 0 : 1; // (the IBS PMU takes no privilege filter)
+		a.exclude_hv = ibs ? 0 : 1;
 		a.disabled = 1;
 		a.precise_ip = 0;
 		fd = (int)syscall(SYS_perf_event_open, &a, 0, -1, -1, 0);
-		if (fd < 0)
+		if (fd < 0) {
+			perror("perf_event_open (sampling)");
 			return false;
+		}
 		ring_bytes = (size_t)(1 + 4096) * 4096; // 16 MiB of samples
 		ring = mmap(nullptr, ring_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
 		if (ring == MAP_FAILED) {
@@ -110,26 +140,57 @@ struct Sampler {
 		auto *meta = (perf_event_mmap_page *)ring;
 		const uint64_t head = meta->data_head, size = ring_bytes - 4096;
 		const uint8_t *base = (const uint8_t *)ring + 4096;
-		std::map<uint64_t, uint64_t> hist;
+		// per address: samples, and from the IBS registers of each sampled op (AMD PPR, IbsOpData / IbsOpData3): cycles
+		// from tagging to retirement, from completion to retirement (waiting for OLDER ops), loads that missed L1 and
+		// their miss latency, mispredicted branches
+		struct Acc {
+			uint64_t n = 0, tag_ret = 0, comp_ret = 0, dc_miss = 0, dc_lat = 0, br_misp = 0;
+		};
+		std::map<uint64_t, Acc> hist;
 		uint64_t pos = head > size ? head - size : 0, n = 0; // (an overrun keeps the newest)
+		auto rd = [&](uint64_t at, void *dst, size_t len) {
+			for (size_t k = 0; k < len; k++)
+				((uint8_t *)dst)[k] = base[(at + k) % size];
+		};
 		while (pos + sizeof(perf_event_header) <= head) {
 			perf_event_header h;
-			for (size_t k = 0; k < sizeof h; k++)
-				((uint8_t *)&h)[k] = base[(pos + k) % size];
+			rd(pos, &h, sizeof h);
 			if (!h.size)
 				break;
 			if (h.type == PERF_RECORD_SAMPLE && h.size >= sizeof h + 8) {
 				uint64_t ip = 0;
-				for (size_t k = 0; k < 8; k++)
-					((uint8_t *)&ip)[k] = base[(pos + sizeof h + k) % size];
-				hist[ip]++;
+				rd(pos + sizeof h, &ip, 8);
+				Acc &a = hist[ip];
+				a.n++;
 				n++;
+				if (ibs_raw && h.size >= sizeof h + 8 + 4 + 4 + 5 * 8) {
+					uint32_t rsz = 0;
+					rd(pos + sizeof h + 8, &rsz, 4);
+					uint64_t regs[5]; // IbsOpCtl, IbsOpRip, IbsOpData, IbsOpData2, IbsOpData3 (after the 4-byte capability word)
+					if (rsz >= 4 + sizeof regs) {
+						rd(pos + sizeof h + 8 + 4 + 4, regs, sizeof regs);
+						const uint64_t d1 = regs[2], d3 = regs[4];
+						a.comp_ret += d1 & 0xFFFF;
+						a.tag_ret += (d1 >> 16) & 0xFFFF;
+						a.br_misp += (d1 >> 36) & 1;
+						if ((d3 & 1) && ((d3 >> 7) & 1)) { // a load that missed the data cache
+							a.dc_miss++;
+							a.dc_lat += (d3 >> 32) & 0xFFFF;
+						}
+					}
+				}
 			}
 			pos += h.size;
 		}
 		FILE *f = fopen(path, "w");
-		for (auto &kv : hist)
-			fprintf(f, "%llx %llu\n", (unsigned long long)kv.first, (unsigned long long)kv.second);
+		for (auto &kv : hist) {
+			const Acc &a = kv.second;
+			if (ibs_raw)
+				fprintf(f, "%llx %llu %llu %llu %llu %llu %llu\n", (unsigned long long)kv.first, (unsigned long long)a.n, (unsigned long long)a.tag_ret,
+					(unsigned long long)a.comp_ret, (unsigned long long)a.dc_miss, (unsigned long long)a.dc_lat, (unsigned long long)a.br_misp);
+			else
+				fprintf(f, "%llx %llu\n", (unsigned long long)kv.first, (unsigned long long)a.n);
+		}
 		fclose(f);
 		fprintf(stderr, "%llu samples -> %s%s\n", (unsigned long long)n, path, head > size ? " (ring overran: raise PV_PERIOD)" : "");
 	}
@@ -167,7 +228,7 @@ int main(int argc, char **argv)
 				std::vector<uint8_t> out(d.size() + d.size() / 3 + 4096);
 				int fd[kNC];
 				for (int k = 0; k < kNC; k++) {
-					fd[k] = open_counter(kCounters[k]);
+					fd[k] = getenv("PV_SAMPLE") ? -1 : open_counter(kCounters[k]);
 					if (fd[k] >= 0)
 						ioctl(fd[k], PERF_EVENT_IOC_ENABLE, 0);
 				}

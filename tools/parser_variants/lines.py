@@ -4,7 +4,7 @@ source line (addr2line; the innermost inlined frame) and per function."""
 import collections, subprocess, sys
 binary, samples = sys.argv[1], sys.argv[2]
 floor = float(sys.argv[3]) if len(sys.argv) > 3 else 0.4
-rows = [l.split() for l in open(samples)]
+rows = [l.split()[:2] for l in open(samples)]
 addrs = [r[0] for r in rows]
 cnt = [int(r[1]) for r in rows]
 out = subprocess.run(["addr2line", "-e", binary, "-f", "-C"] + addrs, capture_output=True, text=True).stdout.splitlines()

@@ -1,4 +1,4 @@
-"""Scan-only timing of the resolver with per-phase shader-clock counters (LRZGPU_RESOLVE_PROF=1).
+"""Scan-only timing of the resolver with per-phase shader-clock counters (LRZGPU_TRACE=3; RESOLVE_LAPS=0 in the environment of this tool: conflict kinds instead).
 usage: python tools/resolve_prof.py [MiB] [text|random]   -- the bench text (or seeded random bytes), one chunk, rzip level 7"""
 import ctypes as C
 import os
@@ -6,7 +6,9 @@ import sys
 import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("LRZGPU_RESOLVE_PROF", "1")
+LAPS = os.environ.get("RESOLVE_LAPS", "1") == "1"
+if LAPS:
+    os.environ["LRZGPU_TRACE"] = "3"
 import torch
 import bench
 
@@ -29,15 +31,12 @@ d = [int(v) for v in p.resolve_dbg]
 print("scan %d MiB %s: wall %.3f s, k_resolve %.1f ms in %d launches, lookups %d inserts %d" % (mib, kind, dt, p.resolve_ms, p.resolve_launches, p.resolve_lookups, p.resolve_inserts))
 names = ("batches", "committed", "serial_steps", "stop_complex", "stop_match", "stop_conflict", "stop_novictim", "stop_sweptrange")
 print(dict(zip(names, d[:8])))
-if os.environ.get("LRZGPU_RESOLVE_PROF") != "1":
+if not LAPS:
     print("conflict kinds:", dict(zip(("twin@lane0", "pred not committable", "pred wrote elsewhere", "pred other kind", "same tag lane-1", "same tag earlier", "unrelated write", "over budget/first_conf=0"), d[8:])))
     sys.exit(0)
 cyc = d[8:]
 tot = sum(cyc) or 1
-if os.environ.get("LRZGPU_RESOLVE_WAVES", "4") != "1":
-    lab = ("8 refill+publish", "9 top-up+simulate", "10 prefix+sweep", "11 filter reads+suspects", "12 table writes", "13 bookkeeping+serial+shift", "14 stops+filter writes", "15 filter reads")
-else:
-  lab = ("8 prefetch-sweep", "9 simulate(A1)+commit-prep", "10 victims", "11 conflicts", "12 apply", "13 tail/shift/serial", "14 A2 verify", "15 A3 displacement")
+lab = ("8 refill+publish", "9 top-up+simulate", "10 prefix+sweep", "11 filter reads+suspects", "12 table writes", "13 bookkeeping+serial+shift", "14 stops+filter writes", "15 filter reads")
 print("  (mw: lap 7 = suspects publish + barrier: %d ticks)" % d[7])
 for n, c in zip(lab, cyc):
     print("  %-28s %12d ticks  %5.1f %%  %8.1f per batch" % (n, c, 100.0 * c / tot, c / max(d[0], 1)))
