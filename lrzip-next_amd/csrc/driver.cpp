@@ -1382,12 +1382,19 @@ struct Run {
 	void fail(int e) { P.fail(e); } // (P.on_fail wakes this run's waiters)
 
 	// ---- readers: chunk bytes into HBM ---------------------------------------------------------------------
-	// Reader t of n brings in the chunks t, t + n, ... of this run, each in file order.  With the input in HBM already
-	// one reader hands out views; a file or a host buffer is read by as many readers as there are scanners: one thread
-	// moves ~6 GB/s out of the page cache through its two pinned pieces, and a scanner can only start on a chunk that
-	// is there completely (a match may run to the chunk's end) -- read one after the other, the eighth chunk of the
-	// headline file was ready 2.7 s after the first, and its scan that much later.
+	// With the input in HBM already one reader hands out views (or device-to-device copies).  A file or a host buffer
+	// is read by as many readers as there are scanners, ALL of them on the same chunk: reader t of n takes the pieces
+	// t, t + n, ... of every chunk, in file order.  One thread moves ~6 GB/s out of the page cache through its two
+	// pinned pieces, and a scanner can only start on a chunk that is there completely (a match may run to the chunk's
+	// end): read by one thread, the eighth chunk of the headline file was ready 2.7 s after the first -- and its scan
+	// that much later; read by eight, chunk k is ready 45 ms after chunk k - 1.
 	int n_readers = 1;
+	struct ReadState { // per chunk of `mine`, guarded by mu
+		int arrived = 0; // readers that have their pieces of the chunk in HBM
+		int rc = 0;
+		bool allocated = false;
+	};
+	std::vector<ReadState> read_state;
 	void reader_main(int t)
 	{
 		if (hipSetDevice(P.device) != hipSuccess) {
@@ -1397,7 +1404,11 @@ struct Run {
 		hipStream_t s = nullptr;
 		RawBuf<uint8_t> stage_buf[2]; // pinned, from the pool (a run after the first finds them there)
 		uint8_t *stage[2] = {nullptr, nullptr};
+		hipEvent_t done[2] = {nullptr, nullptr};
 		auto cleanup = [&] {
+			for (int q = 0; q < 2; q++)
+				if (done[q])
+					(void)hipEventDestroy(done[q]);
 			if (s)
 				StreamPool::get().give(s);
 		};
@@ -1405,46 +1416,55 @@ struct Run {
 			fail(LRZGPU_E_HIP);
 			return;
 		}
-		for (size_t m = (size_t)t; m < mine.size(); m += (size_t)n_readers) {
+		const bool pieces = !in.dev && !in.dev_chunks; // host memory or a file: through pinned pieces
+		if (pieces) {
+			stage_buf[0].alloc(STAGE_BYTES, true);
+			stage_buf[1].alloc(STAGE_BYTES, true);
+			stage[0] = stage_buf[0].data();
+			stage[1] = stage_buf[1].data();
+			if (hipEventCreateWithFlags(&done[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&done[1], hipEventDisableTiming) != hipSuccess) {
+				fail(LRZGPU_E_HIP);
+				cleanup();
+				return;
+			}
+		}
+		bool used[2] = {false, false};
+		int k = 0;
+		for (size_t m = 0; m < mine.size(); m++) {
 			ChunkCtx *cc = chunks[(size_t)mine[m]].get();
+			int rc = 0;
 			{
-				// at most scan_slots + 1 chunks ahead of the committer hold input copies
+				// at most scan_slots + 1 chunks ahead of the committer hold input copies; the first reader to arrive
+				// sets the chunk's buffer up for all of them
 				std::unique_lock<std::mutex> lk(mu);
 				cv.wait(lk, [&] { return P.err || m < committed + (size_t)scan_slots + 1; });
 				if (P.err)
 					break;
+				ReadState &rs = read_state[m];
+				if (!rs.allocated) {
+					rs.allocated = true;
+					const bool interior = in.dev && ((uintptr_t)(in.dev + cc->offset) & 15) == 0 && cc->offset + cc->size < in.n;
+					if (interior)
+						cc->d_in = in.dev + cc->offset; // interior chunk of a resident buffer: readable past its end
+					else if (in.dev_chunks && !in.dev_chunks[cc->index] && cc->size)
+						rs.rc = LRZGPU_E_PARAM; // a chunk this run was asked for but not given
+					else if (!cc->in_buf.alloc((size_t)cc->size + 256, P.device))
+						rs.rc = LRZGPU_E_NOMEM;
+					else
+						cc->d_in = cc->in_buf.p;
+				}
+				rc = rs.rc;
 			}
-			int rc = 0;
-			const bool interior = in.dev && ((uintptr_t)(in.dev + cc->offset) & 15) == 0 && cc->offset + cc->size < in.n;
-			if (interior) {
-				cc->d_in = in.dev + cc->offset; // interior chunk of a resident buffer: readable past its end
-			} else if (in.dev_chunks && !in.dev_chunks[cc->index] && cc->size) {
-				rc = LRZGPU_E_PARAM; // a chunk this run was asked for but not given
-			} else if (!cc->in_buf.alloc((size_t)cc->size + 256, P.device)) {
-				rc = LRZGPU_E_NOMEM;
-			} else {
-				cc->d_in = cc->in_buf.p;
-				hipError_t e = hipSuccess;
-				if (in.dev || in.dev_chunks) {
+			hipError_t e = hipSuccess;
+			if (!rc && cc->in_buf.p) {
+				if (!pieces) {
 					// (a chunk handed over on its own has no readable bytes behind its end: it is copied next to padding)
 					const uint8_t *from = in.dev ? in.dev + cc->offset : in.dev_chunks[cc->index];
 					if (cc->size)
 						e = hipMemcpyAsync(cc->in_buf.p, from, (size_t)cc->size, hipMemcpyDeviceToDevice, s);
 				} else {
-					// host memory or a file: through two pinned pieces, copy/pread of piece k+1 under the DMA of piece k
-					if (!stage[0]) {
-						stage_buf[0].alloc(STAGE_BYTES, true);
-						stage_buf[1].alloc(STAGE_BYTES, true);
-						stage[0] = stage_buf[0].data();
-						stage[1] = stage_buf[1].data();
-					}
-					hipEvent_t done[2] = {nullptr, nullptr};
-					for (int k = 0; k < 2 && !rc; k++)
-						if (hipEventCreateWithFlags(&done[k], hipEventDisableTiming) != hipSuccess)
-							rc = LRZGPU_E_HIP;
-					int k = 0;
-					bool used[2] = {false, false};
-					for (int64_t o = 0; o < cc->size && !rc; o += (int64_t)STAGE_BYTES, k ^= 1) {
+					// copy / pread of this reader's next piece under the DMA of its last one
+					for (int64_t o = (int64_t)t * (int64_t)STAGE_BYTES; o < cc->size && !rc; o += (int64_t)n_readers * (int64_t)STAGE_BYTES, k ^= 1) {
 						const size_t len = (size_t)(cc->size - o < (int64_t)STAGE_BYTES ? cc->size - o : (int64_t)STAGE_BYTES);
 						if (used[k] && event_wait(done[k]) != hipSuccess) {
 							rc = LRZGPU_E_HIP;
@@ -1461,14 +1481,8 @@ struct Run {
 							rc = LRZGPU_E_HIP;
 						used[k] = true;
 					}
-					for (int q = 0; q < 2; q++)
-						if (done[q]) {
-							if (used[q])
-								(void)event_wait(done[q]);
-							(void)hipEventDestroy(done[q]);
-						}
 				}
-				if (!rc && e == hipSuccess)
+				if (!rc && e == hipSuccess && t == 0)
 					e = hipMemsetAsync(cc->in_buf.p + cc->size, 0, 256, s);
 				if (!rc && (e != hipSuccess || stream_wait(s) != hipSuccess))
 					rc = LRZGPU_E_HIP;
@@ -1478,8 +1492,12 @@ struct Run {
 				break;
 			}
 			std::lock_guard<std::mutex> lk(mu);
-			cc->input_ready = true;
-			cv.notify_all();
+			if (++read_state[m].arrived == n_readers) {
+				cc->input_ready = true;
+				cv.notify_all();
+				if (tracing())
+					fprintf(stderr, "lrzgpu reader: chunk %d (%lld bytes) in HBM at %.3f s\n", cc->index, (long long)cc->size, now_s() - t0);
+			}
 		}
 		cleanup();
 	}
@@ -2059,7 +2077,8 @@ int Run::run()
 	std::vector<std::thread> side;
 	if (want_md5)
 		side.emplace_back([this] { P.guarded([this] { md5_main(); }, 3); });
-	n_readers = (in.dev || in.dev_chunks) ? 1 : (int)std::max<size_t>(1, std::min<size_t>({(size_t)scan_slots, mine.size(), (size_t)8}));
+	n_readers = (in.dev || in.dev_chunks) ? 1 : std::max(1, std::min(scan_slots, 8));
+	read_state.assign(mine.size(), ReadState());
 	for (int t = 0; t < n_readers; t++)
 		side.emplace_back([this, t] { P.guarded([this, t] { reader_main(t); }, 4); });
 	for (int k = 0; k < scan_slots; k++)
