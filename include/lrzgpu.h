@@ -25,6 +25,8 @@ extern "C" {
 #define LRZGPU_E_INTERNAL (-105)
 #define LRZGPU_E_FORMAT (-106) /* not a .lrz this library can read, or a failed CRC/MD5/size check */
 #define LRZGPU_E_PEER (-107)   /* sharded run: another rank failed (that rank returns its own error) */
+#define LRZGPU_E_BLOCK_TOO_LARGE (-108) /* the plan's LZMA block (stream_bufsize) needs a finder workspace beyond this
+                                          device: see lrzgpu_max_block_bytes(); returned before any work is done */
 
 /* rzip_control.flags bits this path reads (src/include/lrzip_private.h:257-370) */
 #define LRZGPU_FLAG_NO_COMPRESS (1u << 5)  /* FLAG_NO_COMPRESS, -n */
@@ -450,6 +452,11 @@ int lrzgpu_file_info(const uint8_t *lrz, int64_t n, lrzgpu_info *info);
  * block after block, file after file); this returns all of it to the system. */
 void lrzgpu_trim(void); /* parked buffers, workspaces and streams back to the system */
 int lrzgpu_device_count(void);
+/* The largest LZMA block (stream_bufsize of lrzgpu_plan()) a run on `device` can take: the match finder keeps ~142 B per
+ * block byte resident (the reference's: 11.5 B per dictionary byte on the host, src/util.c:108-131).  ~1.9 GB on a 288 GB
+ * part; the reference sizes a block as max(limit, overhead - dict) / threads (src/stream.c:1316-1323): -p1 / -p2 on a
+ * multi-GB file can exceed that, and such a run returns LRZGPU_E_BLOCK_TOO_LARGE at once. */
+int64_t lrzgpu_max_block_bytes(int device);
 const char *lrzgpu_version(void);
 
 #ifdef __cplusplus

@@ -135,11 +135,35 @@ extern "C" void lrzgpu_profile_cpu(double out[8], int reset)
 	}
 }
 
+constexpr double kMinPoolPerPos = 4; // list-pool entries per block byte below which no finder workspace is made
+
 extern "C" void lrzgpu_trim(void)
 {
 	WorkspacePool::get().trim();
 	DevicePool::get().trim();
 	HostPool::get().trim();
+}
+
+// The largest LZMA block (control->stream_bufsize, what lrzgpu_plan() reports) a run on `device` can take: the match
+// finder needs ~110 B of sort keys, links and tree nodes plus its list pools per block byte, all of it resident for the
+// walk (the reference's finder: ~11.5 B per dictionary byte on the host, src/util.c:108-131), so the device's memory
+// bounds the block -- beside one chunk's input, its literal stream and a scan workspace.  <= 0: no such device.
+extern "C" int64_t lrzgpu_max_block_bytes(int device)
+{
+	int cur = 0;
+	if (hipGetDevice(&cur) != hipSuccess || hipSetDevice(device) != hipSuccess)
+		return 0;
+	size_t free_b = 0, total = 0;
+	const hipError_t e = hipMemGetInfo(&free_b, &total);
+	(void)hipSetDevice(cur);
+	if (e != hipSuccess)
+		return 0;
+	// workspace(n) + 2 n (the block's chunk is at least the block: input + literal stream) + scan workspace + margin <= total
+	const double per_byte = 110.0 + 8.0 * kMinPoolPerPos + 2.0;
+	const double room = (double)total - (double)DeviceBudget::margin() - (double)((size_t)4 << 30) - (double)((size_t)64 << 20);
+	const double n = room / per_byte;
+	const double cap = 4294967295.0 - 65536.0; // (and the 32-bit positions of the format's encoder)
+	return n <= 0 ? 0 : (int64_t)(n < cap ? n : cap);
 }
 
 // lrzgpu_trim() plus the parked streams: for a caller that is about to exit (profilers want every queue closed).
@@ -253,6 +277,8 @@ struct ChunkCtx {
 	std::vector<Job *> file_order;          // the chunk's blocks in the order the reference writes them
 	// guarded by Run::mu
 	bool input_ready = false, scanned = false;
+	bool hash_holds = false;     // the whole-input hash reads the chunk from in_buf: the copy stays until it has
+	bool release_wanted = false; // ... and goes then, if the committer has asked for that meanwhile
 	double t_scanned = 0;
 };
 
@@ -313,6 +339,7 @@ struct Pipeline {
 	int device = 0;
 	int filter_flag = 0, filter_delta = 0; // control->filter_flag / delta: every literal block through this filter first
 	int n_gpu_workers = 2, n_encoders = 1;
+	double mf_per_pos = 16; // list-pool entries per block byte the finder workspaces start with (less for blocks that only fit so)
 	std::atomic<int> err{0};          // first failure; read by every thread of the run
 	std::function<void()> on_fail;    // wakes the run's own waiters (reader, scanners, committer)
 
@@ -706,7 +733,7 @@ struct Pipeline {
 		double ws_per_pos = 0;
 		DevBuf d_stage, d_scratch, d_probe;
 		uint8_t *stage[2] = {nullptr, nullptr};
-		double per_pos = 16;
+		double per_pos = mf_per_pos;
 		const size_t bufsize = (size_t)sz.stream_bufsize;
 		const bool want_pinned = true; // lists and block bytes land in pinned host buffers from the pool
 		auto cleanup = [&] {
@@ -748,7 +775,10 @@ struct Pipeline {
 					per_pos = ws_per_pos * 3;
 					continue;
 				}
-				return LRZGPU_E_INTERNAL;
+				if (tracing())
+					fprintf(stderr, "lrzgpu finder: run on %zu bytes (block %zu) failed with %d (pool %.1f entries per byte, attempt %d)\n", n, block_n, r,
+						ws_per_pos, attempt);
+				return r == -4 ? LRZGPU_E_NOMEM : LRZGPU_E_INTERNAL;
 			}
 		};
 		// ---- one finder run of an early block: the prefix that is there, or the whole block ----
@@ -1506,6 +1536,100 @@ struct Run {
 	// control->hash_code names another of hashes[] (src/main.c:64-79) ---------------------------------------
 	uint8_t digest[64] = {0};
 	const int hash_code = ctl->hash_code; // control->hash_code, src/rzip.c:943-950, 1195-1219
+	// the hash of bytes that are in HBM: down in pinned pieces, piece k + 1 on its way while piece k is hashed (no host
+	// CPU but the hashing itself: the DMA engine moves them)
+	struct DeviceHashFeed {
+		static constexpr size_t kPiece = (size_t)32 << 20;
+		RawBuf<uint8_t> stage[2];
+		hipStream_t s = nullptr;
+		size_t pending = 0; // bytes of the piece on its way (in stage[k ^ 1] once waited for)
+		int k = 0;
+		double t_hash = 0, t_wait = 0;
+		int open(int device)
+		{
+			if (hipSetDevice(device) != hipSuccess)
+				return LRZGPU_E_HIP;
+			stage[0].alloc(kPiece, true);
+			stage[1].alloc(kPiece, true);
+			return make_stream(&s) == hipSuccess ? 0 : LRZGPU_E_HIP;
+		}
+		// hashes what was on its way, after asking for the next piece (d == nullptr: nothing more to ask for)
+		int step(Hasher &m, const uint8_t *d, size_t len)
+		{
+			if (pending && stream_wait_timed() != 0)
+				return LRZGPU_E_HIP;
+			const size_t have = pending;
+			const int from = k;
+			pending = 0;
+			if (d && len) {
+				k ^= 1;
+				if (hipMemcpyAsync(stage[k].data(), d, len, hipMemcpyDeviceToHost, s) != hipSuccess)
+					return LRZGPU_E_HIP;
+				pending = len;
+			}
+			if (have) {
+				const double ta = now_s();
+				m.update(stage[from].data(), have);
+				t_hash += now_s() - ta;
+			}
+			return 0;
+		}
+		int stream_wait_timed()
+		{
+			const double ta = now_s();
+			const hipError_t e = stream_wait(s);
+			t_wait += now_s() - ta;
+			return e == hipSuccess ? 0 : -1;
+		}
+		int range(Hasher &m, const uint8_t *d, int64_t n, const std::atomic<int> &err)
+		{
+			for (int64_t o = 0; o < n && !err.load(); o += (int64_t)kPiece) {
+				const int rc = step(m, d + o, (size_t)(n - o < (int64_t)kPiece ? n - o : (int64_t)kPiece));
+				if (rc)
+					return rc;
+			}
+			return 0;
+		}
+		int drain(Hasher &m) { return step(m, nullptr, 0); }
+		void close()
+		{
+			if (s) {
+				(void)stream_wait(s);
+				StreamPool::get().give(s);
+				s = nullptr;
+			}
+		}
+	};
+	// the hash of a range of the input file where the page cache holds it, through a mapping that moves along the file;
+	// what cannot be mapped is read
+	int hash_file_range(Hasher &m, int64_t from, int64_t n)
+	{
+		const size_t window = (size_t)256 << 20, piece = (size_t)32 << 20;
+		const long pg = sysconf(_SC_PAGESIZE);
+		std::vector<uint8_t> buf;
+		for (int64_t o = 0; o < n && !P.error();) {
+			const size_t len = (size_t)(n - o < (int64_t)window ? n - o : (int64_t)window);
+			const int64_t file_off = in.fd_base + from + o, aligned = file_off / pg * pg;
+			const size_t lead = (size_t)(file_off - aligned);
+			void *mp = mmap(nullptr, len + lead, PROT_READ, MAP_SHARED, in.fd, (off_t)aligned);
+			if (mp != MAP_FAILED) {
+				(void)madvise(mp, len + lead, MADV_SEQUENTIAL);
+				for (size_t q = 0; q < len && !P.error(); q += piece)
+					m.update((const uint8_t *)mp + lead + q, len - q < piece ? len - q : piece);
+				munmap(mp, len + lead);
+			} else {
+				buf.resize(piece);
+				for (size_t q = 0; q < len && !P.error(); q += piece) {
+					const size_t l2 = len - q < piece ? len - q : piece;
+					if (pread_all(in.fd, buf.data(), l2, file_off + (int64_t)q) != 0)
+						return LRZGPU_E_IO;
+					m.update(buf.data(), l2);
+				}
+			}
+			o += (int64_t)len;
+		}
+		return 0;
+	}
 	void md5_main()
 	{
 		std::unique_ptr<Hasher> hasher = make_hasher(hash_code);
@@ -1514,80 +1638,61 @@ struct Run {
 			return;
 		}
 		Hasher &m = *hasher;
+		int rc = 0;
 		if (in.host) {
 			m.update(in.host, (size_t)in.n);
 		} else if (in.n) {
-			const size_t piece = (size_t)32 << 20;
-			uint8_t *stage[2] = {nullptr, nullptr};
-			hipStream_t s = nullptr;
-			int rc = 0;
+			DeviceHashFeed feed;
+			bool feed_open = false;
 			if (in.dev) {
-				if (hipSetDevice(P.device) != hipSuccess)
-					rc = LRZGPU_E_HIP;
-				else if (hipHostMalloc((void **)&stage[0], piece, hipHostMallocDefault) != hipSuccess ||
-					 hipHostMalloc((void **)&stage[1], piece, hipHostMallocDefault) != hipSuccess || make_stream(&s) != hipSuccess)
-					rc = LRZGPU_E_NOMEM;
-				// piece k+1 comes down while piece k is hashed
-				size_t prev = 0;
-				int k = 0;
-				double t_hash = 0, t_wait = 0;
-				for (int64_t o = 0; (o < in.n || prev) && !rc; o += (int64_t)piece, k ^= 1) {
-					size_t len = 0;
-					if (o < in.n) {
-						len = (size_t)(in.n - o < (int64_t)piece ? in.n - o : (int64_t)piece);
-						if (hipMemcpyAsync(stage[k], in.dev + o, len, hipMemcpyDeviceToHost, s) != hipSuccess)
-							rc = LRZGPU_E_HIP;
-					}
-					const double ta = now_s();
-					if (prev)
-						m.update(stage[k ^ 1], prev);
-					const double tb = now_s();
-					if (!rc && stream_wait(s) != hipSuccess)
-						rc = LRZGPU_E_HIP;
-					t_hash += tb - ta;
-					t_wait += now_s() - tb;
-					prev = len;
-					if (P.error())
-						break;
-				}
-				if (tracing())
-					fprintf(stderr, "lrzgpu hash thread: %.2f s hashing, %.2f s waiting for the next piece from the device\n", t_hash, t_wait);
-				for (int q = 0; q < 2; q++)
-					if (stage[q])
-						(void)hipHostFree(stage[q]);
-				if (s)
-					StreamPool::get().give(s);
+				rc = feed.open(P.device);
+				feed_open = true;
+				if (!rc)
+					rc = feed.range(m, in.dev, in.n, P.err);
 			} else {
-				// a file: hashed where the page cache holds it, through a mapping that moves along the file (the readers
-				// have just brought the same pages in; a second pread of the whole input was a 16 GiB memcpy on the one
-				// thread whose speed is a floor of the run).  What cannot be mapped is read.
-				const size_t window = (size_t)256 << 20;
-				const long pg = sysconf(_SC_PAGESIZE);
-				std::vector<uint8_t> buf;
-				for (int64_t o = 0; o < in.n && !rc;) {
-					const size_t len = (size_t)(in.n - o < (int64_t)window ? in.n - o : (int64_t)window);
-					const int64_t file_off = in.fd_base + o, aligned = file_off / pg * pg;
-					const size_t lead = (size_t)(file_off - aligned);
-					void *mp = mmap(nullptr, len + lead, PROT_READ, MAP_SHARED, in.fd, (off_t)aligned);
-					if (mp != MAP_FAILED) {
-						(void)madvise(mp, len + lead, MADV_SEQUENTIAL);
-						for (size_t q = 0; q < len && !P.error(); q += piece)
-							m.update((const uint8_t *)mp + lead + q, len - q < piece ? len - q : piece);
-						munmap(mp, len + lead);
-					} else {
-						buf.resize(piece);
-						for (size_t q = 0; q < len && !rc && !P.error(); q += piece) {
-							const size_t l2 = len - q < piece ? len - q : piece;
-							if (pread_all(in.fd, buf.data(), l2, file_off + (int64_t)q) != 0)
-								rc = LRZGPU_E_IO;
-							else
-								m.update(buf.data(), l2);
-						}
+				// a file.  The readers bring every chunk of this run into HBM for its scan: the hash takes it from there
+				// (the chunk's copy stays until the hash has passed it), like an input that was in HBM from the start --
+				// hashing out of the page cache, mapped or read, costs this thread the page faults or the memcpy of the
+				// whole input, and this thread's speed is a floor of the run.  Chunks of the file that are not this
+				// run's are hashed from the file.
+				for (size_t c = 0; c < chunks.size() && !rc && !P.error(); c++) {
+					ChunkCtx *cc = chunks[c].get();
+					if (!cc->hash_holds) {
+						if (feed_open)
+							rc = feed.drain(m);
+						if (!rc)
+							rc = hash_file_range(m, cc->offset, cc->size);
+						continue;
 					}
-					o += (int64_t)len;
-					if (P.error())
-						break;
+					{
+						std::unique_lock<std::mutex> lk(mu);
+						cv.wait(lk, [&] { return P.err || cc->input_ready; });
+						if (P.err)
+							break;
+					}
+					if (!feed_open) {
+						rc = feed.open(P.device);
+						feed_open = true;
+					}
+					if (!rc)
+						rc = feed.range(m, cc->d_in, cc->size, P.err);
+					if (!rc)
+						rc = feed.drain(m); // (the chunk's last piece is on the host before the copy may go)
+					std::lock_guard<std::mutex> lk(mu);
+					cc->hash_holds = false;
+					if (cc->release_wanted) {
+						cc->in_buf.release();
+						cc->d_in = nullptr;
+					}
 				}
+			}
+			if (feed_open) {
+				if (!rc)
+					rc = feed.drain(m);
+				if (tracing())
+					fprintf(stderr, "lrzgpu hash thread: %.2f s hashing, %.2f s waiting for the next piece from the device; done at %.2f s\n", feed.t_hash,
+						feed.t_wait, now_s() - t0);
+				feed.close();
 			}
 			if (rc) {
 				fail(rc);
@@ -2043,9 +2148,23 @@ int Run::run()
 		// of scan workspace
 		in_flight = (size_t)(scan_slots + (in.dev ? 0 : 1)) * (2 * in_flight + ((size_t)4 << 30));
 		const size_t avail = DeviceBudget::free_now() + WorkspacePool::get().idle_bytes + DevicePool::get().idle_bytes;
-		const size_t per_ws = WorkspacePool::mf_bytes((size_t)P.sz.stream_bufsize, 16.0);
+		size_t per_ws = WorkspacePool::mf_bytes((size_t)P.sz.stream_bufsize, P.mf_per_pos);
 		if (avail != ~(size_t)0 && per_ws > ((size_t)1 << 30)) { // (small blocks: nothing to bound)
 			const size_t room = avail > in_flight + DeviceBudget::margin() ? avail - in_flight - DeviceBudget::margin() : 0;
+			// One workspace must fit.  Its list pools are sized for 16 entries per block byte (text needs ~5, and a
+			// finder run that outgrows its pool is repeated with a larger one): a block too large for that gets what
+			// fits, down to 4 entries per byte; below that the block is beyond this device -- said now, not as an
+			// out-of-memory error minutes into the run (the ceiling: lrzgpu_max_block_bytes()).
+			while (per_ws > room && P.mf_per_pos > kMinPoolPerPos) {
+				P.mf_per_pos = P.mf_per_pos > 8 ? P.mf_per_pos - 4 : P.mf_per_pos - 2;
+				per_ws = WorkspacePool::mf_bytes((size_t)P.sz.stream_bufsize, P.mf_per_pos);
+			}
+			if (per_ws > room) {
+				if (ctl->verbose || getenv("LRZGPU_TRACE"))
+					fprintf(stderr, "lrzgpu: blocks of %lld bytes need a match-finder workspace of %zu MiB; %zu MiB are free beside the chunks in flight\n",
+						(long long)P.sz.stream_bufsize, per_ws >> 20, room >> 20);
+				return LRZGPU_E_BLOCK_TOO_LARGE;
+			}
 			size_t fit = room / per_ws;
 			if (fit < 1)
 				fit = 1;
@@ -2073,6 +2192,9 @@ int Run::run()
 	const bool want_md5 = !sel || sel->with_md5;
 	if (in.dev_chunks && (want_md5 || !sel))
 		return LRZGPU_E_PARAM; // the whole-input hash needs the whole input (checked before any thread exists)
+	if (want_md5 && !in.host && !in.dev && !in.dev_chunks)
+		for (int k : mine)
+			chunks[(size_t)k]->hash_holds = true; // a file: the hash reads this run's chunks from their copies in HBM (md5_main)
 	P.start();
 	std::vector<std::thread> side;
 	if (want_md5)
@@ -2142,8 +2264,16 @@ int Run::run()
 			}
 		}
 		t_scan_last = cc->t_scanned;
-		cc->in_buf.release(); // no rescan can be asked for any more
-		cc->d_in = nullptr;
+		{
+			// no rescan can be asked for any more: the input copy goes (now, or when the hash has passed it)
+			std::lock_guard<std::mutex> lk(mu);
+			if (cc->hash_holds)
+				cc->release_wanted = true;
+			else {
+				cc->in_buf.release();
+				cc->d_in = nullptr;
+			}
+		}
 		// wait for every block of the chunk (discarded early ones included: they reference its buffers)
 		{
 			std::unique_lock<std::mutex> lk(P.mu);

@@ -718,9 +718,10 @@ __device__ __forceinline__ void bt_group_body(const uint32_t block, StagedWindow
 	const uint32_t k0 = have ? seg_start_sorted[bucket] : 0;
 	const uint32_t L = have ? seg_len_sorted[bucket] : 0;
 	const uint32_t cyc_size = dict + 1;
-	// slot (x, side) = word 8 * x + side of the node array, x = sorted index
-	auto word_at = [&](uint32_t idx) -> uint32_t * { return reinterpret_cast<uint32_t *>(node) + idx; };
-	auto node_at = [&](uint32_t x) -> BtNode * { return reinterpret_cast<BtNode *>(word_at(8 * x)); };
+	// slot (x, side) = 2 * x + side, x = sorted index: son word `side` of node x (a word index into the node array would
+	// leave 32 bits at 2^29 positions; blocks go up to lrzgpu_max_block_bytes())
+	auto word_at = [&](uint32_t slot) -> uint32_t * { return reinterpret_cast<uint32_t *>(node + (slot >> 1)) + (slot & 1); };
+	auto node_at = [&](uint32_t x) -> BtNode * { return node + x; };
 	uint32_t stage_base = 0, stage_end = 0, stage_prev = 0; // group-uniform: the window, and the position before it
 	uint32_t pd_c2 = 0, pd_c3 = 0, pd_bytes = 0;            // the walk's h2 / h3 candidates
 	// The next window of a group is fetched AHEAD, one level of its chain of dependent loads (place -> prefix and h2 / h3
@@ -849,8 +850,8 @@ __device__ __forceinline__ void bt_group_body(const uint32_t block, StagedWindow
 						state = W_FINISH;
 					} else {
 						me.son0 = me.son1 = kPending;
-						slot0 = 8 * self + 1; // ptr0 = &son1, ptr1 = &son0
-						slot1 = 8 * self;
+						slot0 = 2 * self + 1; // ptr0 = &son1, ptr1 = &son0
+						slot1 = 2 * self;
 						len0 = len1 = 0;
 						max_len = 3;
 						cv = cut;
@@ -937,7 +938,7 @@ __device__ __forceinline__ void bt_group_body(const uint32_t block, StagedWindow
 				} else {
 					const uint32_t next = n_side ? s1 : s0;
 					if (next != kPending) {
-						const uint32_t taken = 8 * x + n_side; // &x.son1 (smaller) / &x.son0
+						const uint32_t taken = 2 * x + n_side; // &x.son1 (smaller) / &x.son0
 						if (n_side) {
 							st_coh(word_at(slot1), cur_ref);
 							slot1 = taken;

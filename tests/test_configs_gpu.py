@@ -2,6 +2,7 @@
 the whole GPU suite inside minutes and are compared byte for byte with the oracle; the full-size cfg 5 (32 GiB of
 noise) and a 2.5 GiB cfg 4 run as property tests -- block types, sizes, CRC/MD5 and a round trip through the
 library's decoder (tools/full_configs.sh: the 10 GiB cfg 4 and the full 32 GiB decode, log under profiles/)."""
+import ctypes as C
 import hashlib
 import os
 
@@ -133,3 +134,29 @@ def test_cfg4_full_10gib_zstd_round_trip(B):
     back = B.decompress_buffer(got)
     assert len(back) == len(data) and back == data
     _note("cfg4: round trip ok (%.1f s)" % (time.time() - t0))
+
+
+def test_block_beyond_the_device_is_refused_at_once(B):
+    """The reference sizes an LZMA block as max(limit, overhead - dict) / threads (src/stream.c:1316-1323): with -p1 a
+    3 GiB file is ONE 3 GiB block.  The GPU match finder keeps ~142 B per block byte resident, so a block has a
+    ceiling on a given device (lrzgpu_max_block_bytes: ~1.9 GB on 288 GB); a plan above it is refused with
+    LRZGPU_E_BLOCK_TOO_LARGE before anything is scanned -- not with an out-of-memory error minutes into the run."""
+    import time
+    import torch
+    L = B.lib()
+    L.lrzgpu_max_block_bytes.restype = C.c_int64
+    L.lrzgpu_max_block_bytes.argtypes = [C.c_int]
+    ceiling = L.lrzgpu_max_block_bytes(0)
+    total = torch.cuda.get_device_properties(0).total_memory
+    assert (total - (12 << 30)) // 160 < ceiling < total // 130, (ceiling, total)
+    if total >= 250 << 30:
+        assert ceiling > int(1.2 * (1 << 30))  # the block of the reference's defaults on a 64 GB, 8-core host and a multi-GB file
+    n = 3 << 30
+    ram = 64 << 30
+    plan, _ = B.plan(n, level=7, threads=1, processors=1, ramsize=ram)
+    assert plan.stream_bufsize == n > ceiling
+    buf = torch.zeros(n + 256, dtype=torch.uint8, device="cuda")
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match="rc=-108"):
+        B.compress_device(buf.data_ptr(), n, level=7, threads=1, processors=1, ramsize=ram, host_threads=4)
+    assert time.time() - t0 < 5.0
