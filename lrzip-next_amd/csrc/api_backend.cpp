@@ -13,6 +13,7 @@
 #include "../../include/lrzgpu.h"
 #include "common.h"
 #include "lz4_gate.h"
+#include "rzip_census.h"
 #include "lzma_enc.h"
 #include "lzma_mf.h"
 #include "filters.h"
@@ -110,6 +111,31 @@ extern "C" int lrzgpu_lz4_compresses_dev(const void *d_buf, int64_t s_len, int t
 		return r;
 	});
 	return err ? err : v;
+}
+
+// the duplicate census of the scan (rzip_census.hip) on its own: 1 = no 31-byte window of s_buf[0..s_len) occurs twice
+// (exact), 0 = some may; stats (may be NULL) = sample anchors, equal neighbours in the sample, all anchors, equal neighbours
+extern "C" int lrzgpu_census(const uint8_t *s_buf, int64_t s_len, int device, int64_t stats[4])
+{
+	int rc = select_device(device);
+	if (rc)
+		return rc;
+	if (s_len < 0)
+		return LRZGPU_E_PARAM;
+	ThreadBuffers &tb = thread_buffers();
+	if (!tb.ensure(device, (size_t)s_len + 16))
+		return LRZGPU_E_NOMEM;
+	if (s_len && (hipMemcpyAsync(tb.block.p, s_buf, (size_t)s_len, hipMemcpyHostToDevice, tb.s) != hipSuccess || stream_wait(tb.s) != hipSuccess))
+		return LRZGPU_E_HIP;
+	CensusStats cs;
+	const int v = duplicate_census(tb.block.p, s_len, device, tb.s, &cs);
+	if (stats) {
+		stats[0] = cs.sample_anchors;
+		stats[1] = cs.sample_equal;
+		stats[2] = cs.anchors;
+		stats[3] = cs.equal;
+	}
+	return v < 0 ? LRZGPU_E_HIP : v;
 }
 
 extern "C" int lrzgpu_lz4_compresses(const uint8_t *s_buf, int64_t s_len, int threshold, int device)

@@ -1785,6 +1785,11 @@ struct Run {
 		return 0;
 	}
 
+	static bool census_allowed()
+	{
+		const char *e = getenv("LRZGPU_CENSUS"); // 0: every chunk through the resolver (tests compare both ways)
+		return !(e && *e == '0');
+	}
 	int scan_chunk(Scanner &S, ChunkCtx *cc, int64_t vr_in)
 	{
 		const int64_t chunk_size = cc->size, bufsize = P.sz.stream_bufsize;
@@ -1921,7 +1926,9 @@ struct Run {
 
 		ScanResult sr;
 		int64_t vr = vr_in;
-		int r = scan_chunk_device(S.sw, cc->d_in, chunk_size, P.sz.rzip_level, &vr, &sr, F.ms, progress);
+		// (the file's last chunk: nobody needs the victim_round it ends with, so it may skip the resolver when it holds
+		// no repeat at all -- rzip_census.hip)
+		int r = scan_chunk_device(S.sw, cc->d_in, chunk_size, P.sz.rzip_level, &vr, &sr, F.ms, progress, cc->last && census_allowed());
 		if (r)
 			return r < -50 ? r : (r == -4 ? LRZGPU_E_NOMEM : LRZGPU_E_INTERNAL);
 		{

@@ -1445,15 +1445,15 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 		// buckets of at least long_min positions get a wavefront each, those of at least mid_min eight lanes (k_bt_group),
 		// the rest one lane (k_bt); read per call: tests force 1 (every bucket through the pipelined kernels) and a huge
 		// value (none) inside one process
-		auto env_u32 = [](const char *name, uint32_t dflt) {
-			if (const char *e = getenv(name)) {
-				const long v = atol(e);
-				return (uint32_t)(v < 1 ? 1 : (v > 0x7FFFFFFF ? 0x7FFFFFFF : v));
-			}
-			return dflt;
-		};
-		const uint32_t long_min = env_u32("LRZGPU_BT_WAVE_MIN", 4096);
-		uint32_t mid_min = env_u32("LRZGPU_BT_GROUP_MIN", 512);
+		// LRZGPU_BT_MIN=<wave>[,<group>]
+		uint32_t long_min = 4096, mid_min = 512;
+		if (const char *e = getenv("LRZGPU_BT_MIN")) {
+			auto clip = [](long v) { return (uint32_t)(v < 1 ? 1 : (v > 0x7FFFFFFF ? 0x7FFFFFFF : v)); };
+			char *rest = nullptr;
+			long_min = clip(strtol(e, &rest, 10));
+			if (rest && *rest == ',')
+				mid_min = clip(strtol(rest + 1, nullptr, 10));
+		}
 		if (mid_min > long_min)
 			mid_min = long_min;
 		hipLaunchKernelGGL(k_seg_len, dim3(g), dim3(256), 0, s, w->seg_start, d_nseg, n4, w->seg_len, long_min, mid_min, d_nlong);

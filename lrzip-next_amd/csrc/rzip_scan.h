@@ -80,8 +80,11 @@ void scan_workspace_destroy(ScanWorkspace *w);
 typedef std::function<int(const ScanState &h, int64_t scanned_upto)> ScanProgressFn;
 
 // Scans d_chunk[0..chunk_size) (device). victim_round in/out.
+// census: the caller has no use for the victim_round the chunk ends with (it is the file's last): a chunk in which no
+// 31-byte window occurs twice (rzip_census.hip) is not put through the table automaton at all -- no match can come of
+// it; the records stay empty and *victim_round is left as it came in.
 int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_size, int rzip_level,
-		      int64_t *victim_round, ScanResult *res, hipStream_t s, const ScanProgressFn &progress = nullptr);
+		      int64_t *victim_round, ScanResult *res, hipStream_t s, const ScanProgressFn &progress = nullptr, bool census = false);
 
 // literal gather: dst[dst_off + k] = src[src_off + k] for each run (device pointers)
 struct CopyRun {

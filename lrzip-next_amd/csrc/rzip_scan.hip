@@ -41,6 +41,7 @@
 #include "profile.h"
 #include "common.h"
 #include "rzip_scan.h"
+#include "rzip_census.h"
 
 namespace lrzgpu {
 
@@ -1500,7 +1501,7 @@ void scan_workspace_destroy(ScanWorkspace *w)
 }
 
 int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_size, int rzip_level,
-		      int64_t *victim_round, ScanResult *res, hipStream_t s, const ScanProgressFn &progress)
+		      int64_t *victim_round, ScanResult *res, hipStream_t s, const ScanProgressFn &progress, bool census)
 {
 	unsigned mb, freq, chain;
 	rzip_level_params(rzip_level, &mb, &freq, &chain);
@@ -1525,6 +1526,40 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 	const int64_t end = h.end;
 	int64_t p_skip = 0;
 	uint64_t min_mask = h.min_mask;
+	if (census && end > 0 && ((uintptr_t)d_chunk & 15) == 0) {
+		// incompressible data: no 31-byte window occurs twice, so no candidate can become a match -- the automaton is
+		// not run (its table, its statistics and the victim_round it would end with are of no use to anyone here)
+		int dev = 0;
+		(void)hipGetDevice(&dev);
+		CensusStats cs;
+		EventTimer tc(s);
+		const int verdict = duplicate_census(d_chunk, chunk_size, dev, s, &cs);
+		tc.stop();
+		HIPCHK(stream_wait(s));
+		if (verdict < 0)
+			return -5;
+		if (getenv("LRZGPU_TRACE"))
+			fprintf(stderr, "lrzgpu scan: census of %lld bytes in %.1f ms: sample %lld anchors / %lld equal, all %lld anchors / %lld equal: %s\n",
+				(long long)chunk_size, tc.ms(), (long long)cs.sample_anchors, (long long)cs.sample_equal, (long long)cs.anchors, (long long)cs.equal,
+				verdict == 1 ? "no 31-byte window occurs twice, the resolver is not run" : "the resolver runs");
+		{
+			ProfileStore &ps = ProfileStore::get();
+			std::lock_guard<std::mutex> lk(ps.mu);
+			ps.p.tag_scan_ms += tc.ms_noted(ps, PK_TAG_SCAN); // (booked with the other all-CU streaming kernel of the scan)
+			ps.p.tag_scan_launches++;
+			ps.p.tag_scan_positions += verdict == 1 ? chunk_size : chunk_size / 64;
+		}
+		if (verdict == 1) {
+			p_skip = end; // every candidate "examined": nothing left for the loop below
+			h.p_skip = end;
+			HIPCHK(hipMemcpyAsync(w->state, &h, sizeof(h), hipMemcpyHostToDevice, s));
+			if (progress) {
+				int pr = progress(h, p_skip);
+				if (pr)
+					return pr;
+			}
+		}
+	}
 	while (p_skip + 1 <= end) {
 		const int64_t seg_lo = p_skip + 1;
 		// size the segment for ~2M candidates under the current mask

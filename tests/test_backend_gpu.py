@@ -197,16 +197,15 @@ def test_mf_stream_in_btbuf_format(B, O):
 
 @pytest.mark.parametrize("wave_min,group_min", [("1", "1"), ("1000000000", "1"), ("2000", "16"), ("1000000000", "1000000000")])
 def test_match_lists_with_forced_bucket_kernels(B, O, wave_min, group_min, monkeypatch):
-    """The three BT kernels on the same data.  LRZGPU_BT_WAVE_MIN=1 sends EVERY bucket through the pipelined kernel with
+    """The three BT kernels on the same data.  LRZGPU_BT_MIN=1 (wave minimum) sends EVERY bucket through the pipelined kernel with
     one wavefront per bucket (k_bt_group<64>: walks of one bucket in flight together, pending-slot marks, the 64-wide run
-    path); LRZGPU_BT_GROUP_MIN=1 under a huge wave minimum sends every bucket through the same kernel with EIGHT lanes
+    path); a group minimum of 1 (LRZGPU_BT_MIN=<huge>,1) under a huge wave minimum sends every bucket through the same kernel with EIGHT lanes
     per bucket, eight buckets per wavefront (k_bt_group<8>: group-masked ballots, a staged window per group, runs of one
     byte value eight at a time, groups of one wavefront finishing at different times); 2000 / 16 mixes all three; two
     huge values send every bucket through the lane-per-bucket kernel (k_bt).  A 5000-word vocabulary gives buckets of
     10^4..10^5 positions, a two-symbol alphabet long walks with full-length agreements, runs the bulk path, a small
     dictionary the window cut-off inside walks."""
-    monkeypatch.setenv("LRZGPU_BT_WAVE_MIN", wave_min)
-    monkeypatch.setenv("LRZGPU_BT_GROUP_MIN", group_min)
+    monkeypatch.setenv("LRZGPU_BT_MIN", "%s,%s" % (wave_min, group_min))
     if True:
         rng = np.random.default_rng(11)
         cases = [

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Match finder alone on one block of the bench text (GPU): k_bt / k_bt_group timing per cut-over, pipeline statistics.
-Arguments: MiB, then settings "WAVE_MIN" or "WAVE_MIN,GROUP_MIN" (LRZGPU_BT_WAVE_MIN: buckets from this length on get a
-wavefront; LRZGPU_BT_GROUP_MIN: from this length on eight lanes; below: one lane); the lists of every setting are
+Arguments: MiB, then settings "WAVE_MIN" or "WAVE_MIN,GROUP_MIN" (LRZGPU_BT_MIN=wave,group: buckets from this length on get a
+wavefront; from this length on eight lanes; below: one lane); the lists of every setting are
 compared with the first one's."""
 import ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,8 +18,7 @@ first = None
 for setting in sys.argv[2:] or ["1000000000", "1024"]:
     f = setting.split(",")
     wm, lm = f[0], (f[1] if len(f) > 1 else f[0])
-    os.environ["LRZGPU_BT_WAVE_MIN"] = wm
-    os.environ["LRZGPU_BT_GROUP_MIN"] = lm
+    os.environ["LRZGPU_BT_MIN"] = "%s,%s" % (wm, lm)
     for rep in range(int(os.environ.get("BT_CASE_REPS", "2"))):
         L.lrzgpu_profile_reset()
         t0 = time.time()

@@ -2,8 +2,8 @@
 # k_bt_wave cut-over sweep on the headline workload (1 timed step each after 1 warm-up, no CPU leg)
 mkdir -p gpurun_out
 for m in ${SWEEP:-4096 1024 1000000000}; do
-  echo "== LRZGPU_BT_WAVE_MIN=$m"
-  LRZGPU_BT_WAVE_MIN=$m timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-file-leg > gpurun_out/bt_$m.json 2> gpurun_out/bt_$m.err
+  echo "== LRZGPU_BT_MIN=$m"
+  LRZGPU_BT_MIN=$m timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-file-leg > gpurun_out/bt_$m.json 2> gpurun_out/bt_$m.err
   python - <<PY
 import json
 try:

@@ -25,10 +25,10 @@ for kind in ("phrases", "few", "text"):
             ("batches", "committed", "serial_steps", "stop_complex", "stop_match", "stop_conflict", "stop_novictim", "stop_sweptrange"),
             [int(v) for v in p.resolve_dbg[:8]]))), flush=True)
     for wm in ("1000000000", "4096"):
-        os.environ["LRZGPU_BT_WAVE_MIN"] = wm
+        os.environ["LRZGPU_BT_MIN"] = wm
         L.lrzgpu_profile_reset()
         t0 = time.time()
         gc, gp = B.lzma_match_lists(data, dict_size=1 << 27, fb=64, cut=48, per_pos=110)
         p = bench.Profile(); L.lrzgpu_profile_get(C.byref(p))
         print("   lists alone wave_min %s: %.2f s, k_bt %.0f ms, wave dbg %s" % (wm, time.time() - t0, p.mf_bt_ms, list(p.mf_wave_dbg)), flush=True)
-    os.environ.pop("LRZGPU_BT_WAVE_MIN")
+    os.environ.pop("LRZGPU_BT_MIN")
