@@ -289,8 +289,9 @@ void lrzgpu_hash_index(uint64_t out[256]);
 /* The scan's duplicate census on its own (csrc/rzip_census.hip): 1 = no 31-byte window of s_buf[0..s_len) occurs twice --
  * exactly: no rzip match (MINIMUM_MATCH 31, src/rzip.c:431-461) can exist in such a chunk, and the whole-file entry
  * points do not run the table automaton on the file's last chunk then --, 0 = some may.  stats (may be NULL): anchors
- * and equal neighbours of the 1/64 sample, anchors and equal neighbours of the full pass. */
-int lrzgpu_census(const uint8_t *s_buf, int64_t s_len, int device, int64_t stats[4]);
+ * and equal values of the 1/64 sample, anchors and equal values of the full pass, and how many of the latter were chance
+ * (equal 8-byte values whose surroundings differ: looked at, cleared). */
+int lrzgpu_census(const uint8_t *s_buf, int64_t s_len, int device, int64_t stats[5]);
 
 /* ---- lz4 gate ---------------------------------------------------------------------------------
  * static int lz4_compresses(rzip_control*, uchar *s_buf, i64 s_len) -- src/stream.c:2325-2380.

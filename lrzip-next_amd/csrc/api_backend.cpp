@@ -114,8 +114,8 @@ extern "C" int lrzgpu_lz4_compresses_dev(const void *d_buf, int64_t s_len, int t
 }
 
 // the duplicate census of the scan (rzip_census.hip) on its own: 1 = no 31-byte window of s_buf[0..s_len) occurs twice
-// (exact), 0 = some may; stats (may be NULL) = sample anchors, equal neighbours in the sample, all anchors, equal neighbours
-extern "C" int lrzgpu_census(const uint8_t *s_buf, int64_t s_len, int device, int64_t stats[4])
+// (exact), 0 = some may; stats (may be NULL) = sample anchors, equal neighbours in the sample, all anchors, equal values among them, those of them that were chance
+extern "C" int lrzgpu_census(const uint8_t *s_buf, int64_t s_len, int device, int64_t stats[5])
 {
 	int rc = select_device(device);
 	if (rc)
@@ -134,6 +134,7 @@ extern "C" int lrzgpu_census(const uint8_t *s_buf, int64_t s_len, int device, in
 		stats[1] = cs.sample_equal;
 		stats[2] = cs.anchors;
 		stats[3] = cs.equal;
+		stats[4] = cs.cleared;
 	}
 	return v < 0 ? LRZGPU_E_HIP : v;
 }

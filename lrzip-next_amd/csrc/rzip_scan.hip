@@ -1539,8 +1539,8 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 		if (verdict < 0)
 			return -5;
 		if (getenv("LRZGPU_TRACE"))
-			fprintf(stderr, "lrzgpu scan: census of %lld bytes in %.1f ms: sample %lld anchors / %lld equal, all %lld anchors / %lld equal: %s\n",
-				(long long)chunk_size, tc.ms(), (long long)cs.sample_anchors, (long long)cs.sample_equal, (long long)cs.anchors, (long long)cs.equal,
+			fprintf(stderr, "lrzgpu scan: census of %lld bytes in %.1f ms: sample %lld anchors / %lld equal, all %lld anchors / %lld equal (%lld of them chance): %s\n",
+				(long long)chunk_size, tc.ms(), (long long)cs.sample_anchors, (long long)cs.sample_equal, (long long)cs.anchors, (long long)cs.equal, (long long)cs.cleared,
 				verdict == 1 ? "no 31-byte window occurs twice, the resolver is not run" : "the resolver runs");
 		{
 			ProfileStore &ps = ProfileStore::get();

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 def _census(B, data):
     f = B.lib().lrzgpu_census
     f.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.POINTER(C.c_int64)]
-    st = (C.c_int64 * 4)()
+    st = (C.c_int64 * 5)()
     v = f(bytes(data), len(data), 0, st)
     assert v in (0, 1), v
     return v, list(st)
@@ -42,6 +42,22 @@ def test_verdict_on_plain_cases(B):
     assert _census(B, rnd[:31] + rnd[:31])[0] == 0
     assert _census(B, bytes(1 << 20))[0] == 0                       # every position an anchor: no room for them, "maybe"
     assert _census(B, datagen.text_like(4 << 20, seed=3))[0] == 0    # (the sample says so)
+
+
+def test_equal_values_that_are_chance_are_cleared(B):
+    """Two anchors with the same 8 bytes whose surroundings differ (eight zero bytes in noise: the smallest value there is,
+    an anchor for certain): the sort finds the pair, the look at the bytes around the two positions clears it -- and with
+    30 equal bytes around them still, with 31 no more."""
+    rnd = bytearray(datagen.random_bytes((6 << 20) + 5, seed=77))
+    d = bytearray(rnd)
+    d[1000003:1000011] = bytes(8)
+    d[5000017:5000025] = bytes(8)
+    v, st = _census(B, d)
+    assert v == 1 and st[3] >= 1 and st[4] == st[3], st
+    for before, total, want in ((0, 30, 1), (11, 30, 1), (22, 30, 1), (0, 31, 0), (11, 31, 0), (23, 31, 0), (5, 40, 0)):
+        e = bytearray(d)
+        e[5000017 - before:5000017 - before + total] = e[1000003 - before:1000003 - before + total]
+        assert _census(B, e)[0] == want, (before, total)
 
 
 @pytest.mark.parametrize("gap", [0, 1, 5, 100, 4097, 3 << 20])
