@@ -334,8 +334,8 @@ int duplicate_census(const uint8_t *d_chunk, int64_t n, int device, hipStream_t 
 		return r == -2 ? 0 : r;
 	st->sample_anchors = (int64_t)anchors;
 	st->sample_equal = (int64_t)dups;
-	if (r == 1 || dups)
-		return 0;
+	if (r == 1 || dups > (unsigned long long)kMaxSuspects)
+		return 0; // (a few equal values may be chance: the full pass looks at them)
 	// all of them
 	const unsigned long long cap = (unsigned long long)(n / 8) + 65536;
 	uint64_t suspects[kMaxSuspects];

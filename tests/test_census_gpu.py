@@ -60,8 +60,8 @@ def test_equal_values_that_are_chance_are_cleared(B):
         assert _census(B, e)[0] == want, (before, total)
 
 
-@pytest.mark.parametrize("gap", [0, 1, 5, 100, 4097, 3 << 20])
-@pytest.mark.parametrize("length", [31, 32, 38, 64, 1000])
+@pytest.mark.parametrize("gap", [0, 1, 100, 3 << 20])
+@pytest.mark.parametrize("length", [31, 32, 64, 1000])
 def test_one_repeat_is_seen(B, gap, length):
     """Noise with ONE stretch of `length` bytes copied `gap` bytes behind itself -- at every alignment the copy has to be
     seen: all its 31-byte windows are repeats, and each holds an anchor at the same relative place as its original."""
