@@ -23,6 +23,7 @@ def forced(monkeypatch):
     monkeypatch.setenv("LRZGPU_EARLY_START", "2")
     monkeypatch.setenv("LRZGPU_EARLY_STEP", str(1 << 20))
     monkeypatch.setenv("LRZGPU_SEG_BYTES", str(1 << 20))  # scan progress (and with it a new piece of the block) every MiB
+    monkeypatch.setenv("LRZGPU_CENSUS", "0")  # (noise would skip the scan, and its blocks would be there whole at once)
     return monkeypatch
 
 
