@@ -194,6 +194,10 @@ int lrzgpu_shard_protocol(lrzgpu_control *control, int64_t n, const lrzgpu_shard
  * itself). */
 #define LRZGPU_RCCL_ID_BYTES 128
 int lrzgpu_rccl_available(void);
+/* Take ncclGetUniqueId / CommInitRank / AllReduce / Send / Recv / Group* / CommAbort / CommDestroy from this shared object
+ * instead of librccl.so.1 (an RCCL build under another name; tests/stubs/nccl_stub.cpp: an in-process stand-in with which
+ * two ranks are two threads on one GPU).  Only before the first other lrzgpu_rccl_* call of the process. */
+int lrzgpu_rccl_use_library(const char *path);
 int lrzgpu_rccl_unique_id(uint8_t id[LRZGPU_RCCL_ID_BYTES]);
 int lrzgpu_rccl_comm_create(const uint8_t id[LRZGPU_RCCL_ID_BYTES], int rank, int world, int device, lrzgpu_shard_comm *comm);
 int lrzgpu_rccl_comm_destroy(lrzgpu_shard_comm *comm);

@@ -21,6 +21,7 @@
 #include <ctime>
 #include <mutex>
 #include <new>
+#include <string>
 
 #include "../../include/lrzgpu.h"
 #include "common.h"
@@ -42,16 +43,24 @@ struct Rccl {
 	ncclResult_t (*GroupEnd)() = nullptr;
 	bool ok = false;
 };
+std::string &library_override()
+{
+	static std::string path;
+	return path;
+}
 Rccl &rccl()
 {
 	static Rccl r;
 	static std::once_flag once;
 	std::call_once(once, [] {
-		for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-			r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-			if (r.h)
-				break;
-		}
+		if (!library_override().empty())
+			r.h = dlopen(library_override().c_str(), RTLD_NOW | RTLD_LOCAL);
+		else
+			for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+				r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+				if (r.h)
+					break;
+			}
 		if (!r.h)
 			return;
 		auto sym = [&](const char *s) { return dlsym(r.h, s); };
@@ -273,6 +282,16 @@ template <typename F> int guard(F &&f)
 }
 
 } // namespace
+
+// The nccl* entry points from another shared object than librccl.so.1 (a build under another name; tests: an in-process
+// stand-in that lets two ranks be two threads of one process on one GPU).  Before the first lrzgpu_rccl_* call only.
+extern "C" int lrzgpu_rccl_use_library(const char *path)
+{
+	if (!path || !*path)
+		return LRZGPU_E_PARAM;
+	library_override() = path;
+	return rccl().ok && rccl().h && library_override() == path ? 0 : LRZGPU_E_NODEVICE;
+}
 
 extern "C" int lrzgpu_rccl_available(void)
 {
