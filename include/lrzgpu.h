@@ -189,8 +189,8 @@ int lrzgpu_shard_protocol(lrzgpu_control *control, int64_t n, const lrzgpu_shard
  * the other ranks (MPI_Bcast, a file, a TCP store), every rank creates its communicator on its own device.  RCCL is
  * taken from the process at run time (dlopen librccl.so.1); without it these return LRZGPU_E_NODEVICE.  A failed call
  * aborts the communicator (ncclCommAbort), which fails the peers' pending calls: the abortable transport the protocol
- * asks for; a wait for a peer that never shows up (its all-reduce, its send, its receive) gives up after ten minutes
- * the same way.  lrzgpu_rccl_loopback: self test of the staging / send / receive path on one rank (grouped send + receive to
+ * asks for; a wait for a peer that never shows up gives up the same way: after ten minutes in a send or a receive,
+ * after an hour in the all-reduce (where a rank that is through waits for the slowest one to compress, or redo, a chunk).  lrzgpu_rccl_loopback: self test of the staging / send / receive path on one rank (grouped send + receive to
  * itself). */
 #define LRZGPU_RCCL_ID_BYTES 128
 int lrzgpu_rccl_available(void);

@@ -218,6 +218,10 @@ static int sharded(lrzgpu_control *control, CompressSource src, int64_t n, const
 {
 	if (!control || n < 0 || !comm_ok(comm))
 		return LRZGPU_E_PARAM;
+	// the malloc() probe of open_stream_out (control->malloc_probe) sizes blocks by what THIS process may allocate: ranks
+	// under different limits would lay the one file out differently -- not in a sharded run
+	if (control->malloc_probe)
+		return LRZGPU_E_PARAM;
 	return guard([&] {
 		OwnCompressor oc{control, src};
 		oc.src.n = n;

@@ -134,7 +134,10 @@ struct Transport {
 // after this long, the communicator is aborted (which fails the peer's pending calls too) and the callback reports an
 // error -- the protocol then ends with LRZGPU_E_IO on this rank.
 constexpr double kPeerTimeoutSeconds = 600.0;
-hipError_t wait_event_bounded(hipEvent_t ev)
+// ... and the all-reduce is where a rank that is through waits for the slowest one (a whole chunk compressed, or redone
+// after a wrong victim_round guess): six times that
+constexpr double kReduceTimeoutSeconds = 3600.0;
+hipError_t wait_event_bounded(hipEvent_t ev, double patience = kPeerTimeoutSeconds)
 {
 	timespec t0, t;
 	clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -144,7 +147,7 @@ hipError_t wait_event_bounded(hipEvent_t ev)
 		if (q != hipErrorNotReady)
 			return q;
 		clock_gettime(CLOCK_MONOTONIC, &t);
-		if ((double)(t.tv_sec - t0.tv_sec) + 1e-9 * (double)(t.tv_nsec - t0.tv_nsec) > kPeerTimeoutSeconds)
+		if ((double)(t.tv_sec - t0.tv_sec) + 1e-9 * (double)(t.tv_nsec - t0.tv_nsec) > patience)
 			return hipErrorNotReady;
 		timespec ts{0, ns};
 		nanosleep(&ts, nullptr);
@@ -183,7 +186,7 @@ int cb_allreduce(void *ctx, int64_t *vals, int count)
 	HIPOK(hipMemcpyAsync(t->d_words, vals, (size_t)count * 8, hipMemcpyHostToDevice, t->comm_stream));
 	NCCLOK(rccl().AllReduce(t->d_words, t->d_words, (size_t)count, ncclInt64, ncclSum, t->comm, t->comm_stream));
 	HIPOK(hipEventRecord(t->reduced, t->comm_stream));
-	HIPOK(wait_event_bounded(t->reduced)); // (sleeps; gives up when a rank never joins)
+	HIPOK(wait_event_bounded(t->reduced, kReduceTimeoutSeconds)); // (sleeps; gives up when a rank never joins)
 	HIPOK(hipMemcpy(vals, t->d_words, (size_t)count * 8, hipMemcpyDeviceToHost));
 	return 0;
 }
@@ -215,6 +218,10 @@ int send_to(Transport *t, int dst, const void *buf, int64_t n, bool loop, void *
 		const int b = (int)(i & 1);
 		const size_t o = i * kPiece, k = (size_t)n - o < kPiece ? (size_t)n - o : kPiece;
 		if (!loop) {
+			// the piece sent from this buffer two pieces ago must have left it: waited for here, on the host and with a
+			// bound (a copy from pageable memory would make the runtime wait for it instead, for as long as it takes)
+			if (i >= 2)
+				HIPOK(wait_event_bounded(t->out_stage[b]));
 			HIPOK(hipStreamWaitEvent(t->copy_stream, t->out_stage[b], 0)); // (never recorded yet: no wait)
 			HIPOK(hipMemcpyAsync(t->stage[b], src + o, k, hipMemcpyHostToDevice, t->copy_stream));
 			HIPOK(hipEventRecord(t->in_stage[b], t->copy_stream));

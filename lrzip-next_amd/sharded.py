@@ -71,14 +71,17 @@ def rccl_comm(lib, rank, world, device, bcast_id):
     """lrzgpu_shard_comm over the library's own RCCL transport (csrc/shard_rccl.cpp): ncclAllReduce / ncclSend /
     ncclRecv in C, no Python on the hand-off.  bcast_id(bytes or None) -> bytes carries rank 0's 128-byte unique id to
     every rank (the caller's bootstrap).  Returns (ShardComm, close); raises RuntimeError when RCCL cannot be used."""
-    if not lib.lrzgpu_rccl_available():
-        raise RuntimeError("no librccl in this process")
+    # every rank takes part in the broadcast whatever it finds locally (a rank that left before it would leave the others
+    # waiting in it): all zero = "rank 0 has none"
+    have = bool(lib.lrzgpu_rccl_available())
     uid = None
     if rank == 0:
         raw = (C.c_ubyte * 128)()
-        rc = lib.lrzgpu_rccl_unique_id(raw)
-        uid = bytes(raw) if rc == 0 else bytes(128)  # (all zero = "rank 0 has none": the others must not wait for ever)
+        rc = lib.lrzgpu_rccl_unique_id(raw) if have else -1
+        uid = bytes(raw) if rc == 0 else bytes(128)
     uid = bcast_id(uid)
+    if not have:
+        raise RuntimeError("no librccl in this process")
     if uid == bytes(128):
         raise RuntimeError("rank 0 could not make a unique id")
     comm = ShardComm()
