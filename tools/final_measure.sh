@@ -2,7 +2,7 @@
 # The measurement set of a round (GPU box): PMC + kernel trace of the headline step, the full bench line with the
 # whole-file CPU baseline, the file-to-file leg and a timeline, the cfg 2 line, and bench --gpus 2 over gloo on the one GPU.
 mkdir -p gpurun_out/final
-TAG=${1:-r4}
+TAG=${1:-r5}
 timeout 1200 python tools/pmc_collect.py $TAG 2>&1 | tail -3
 cp gpurun_out/prof/pmc_summary.json profiles/pmc_summary.json   # bench.py reads it from profiles/ (same build id)
 timeout 1500 python bench.py --steps 3 --warmup 1 --verify --timeline gpurun_out/final/${TAG}_timeline.csv > gpurun_out/final/${TAG}_bench_n1.json 2> gpurun_out/final/${TAG}_bench_n1.err
