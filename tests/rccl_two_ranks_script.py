@@ -50,9 +50,8 @@ def ranks(fn):
         t.start()
     for t in th:
         t.join(180)
-    for e in err:
-        if e is not None:
-            raise e
+    if any(e is not None for e in err):
+        raise RuntimeError("rank errors: %r" % (err,))
     return out
 
 

@@ -23,7 +23,14 @@ def stub(tmp_path_factory):
 
 
 @pytest.mark.parametrize("scenario", ["exchange", "sharded", "peer_fails"])
-def test_two_ranks(stub, scenario):
+def test_two_ranks(B, stub, scenario):
+    # (the child shares the GPU with this process: what earlier tests left parked here goes back first)
+    B.lib().lrzgpu_trim()
+    try:
+        import torch
+        torch.cuda.empty_cache()
+    except Exception:
+        pass
     env = dict(os.environ)
     if scenario == "peer_fails":
         env["NCCL_STUB_FAIL_SEND"] = "3"
