@@ -74,7 +74,8 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 	const u64 lanes_below = lane_bit - 1;
 	i64 *hit_lds = hit_all[wave];
 
-	Resolver R; // wave 0: the automaton; the others: the read-only part their simulations need
+	Automaton A; // wave 0: the automaton; the others: the read-only part their simulations need
+	Resolver &R = A.R;
 	R.buf = buf;
 	R.tbl = tbl;
 	R.rk = rank_bytes;
@@ -107,12 +108,20 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 		x_miss = 0;
 
 	// ---- wave 0 only ----
-	i64 p_skip = st->p_skip;
-	i64 cur_p = st->cur_p, cur_ofs = st->cur_ofs, cur_len = st->cur_len;
-	i64 n_rec = st->n_records;
-	const i64 rec_cap = st->rec_cap;
-	i64 inserts = st->inserts, lookups = st->lookups;
-	int error = st->error;
+	i64 &p_skip = A.p_skip, &cur_p = A.cur_p, &cur_ofs = A.cur_ofs, &cur_len = A.cur_len;
+	i64 &n_rec = A.n_rec, &inserts = A.inserts, &lookups = A.lookups, &serial_n = A.serial_n;
+	int &error = A.error;
+	p_skip = st->p_skip;
+	cur_p = st->cur_p;
+	cur_ofs = st->cur_ofs;
+	cur_len = st->cur_len;
+	n_rec = st->n_records;
+	A.rec_cap = st->rec_cap;
+	inserts = st->inserts;
+	lookups = st->lookups;
+	error = st->error;
+	serial_n = 0; // (dbg[2] at the end)
+	A.records = records;
 	// round / stop counters and the profile laps of wave 0: in LDS, bumped by one lane (as sixteen 64-bit values per lane
 	// they were 32 of the 512 registers of a kernel that spills)
 	__shared__ i64 dbg[16];
@@ -134,61 +143,8 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 	i64 miss_acc = 0; // per lane, every wave
 	const i64 tbl_size = (i64)R.hmask + 1;
 
-	// One exact automaton step at candidate (P, T): see k_resolve.
-	auto serial_step = [&](i64 P, u64 T) {
-		bump(2, 1);
-		bool again;
-		R.allow_abort = true;
-		do {
-			again = false;
-			i64 offset = 0, reverse = 0;
-			lookups++;
-			const i64 hits0 = R.tag_hits, misses0 = R.tag_misses;
-			i64 mlen = R.lookup(T, P, &offset, &reverse);
-			if (R.aborted) {
-				lookups--;
-				bump(2, -1);
-				R.tag_hits = hits0;
-				R.tag_misses = misses0;
-				if (P - 1 > p_skip)
-					p_skip = P - 1;
-				error = 3;
-				return;
-			}
-			R.allow_abort = false;
-			if ((T & R.tag_mask) == R.tag_mask) {
-				inserts++;
-				R.hash_count++;
-				R.insert(T, P);
-				if (R.hash_count > R.hash_limit)
-					R.tag_mask = R.clean_one();
-			}
-			if (mlen > cur_len) {
-				cur_p = P - reverse;
-				cur_len = mlen;
-				cur_ofs = offset;
-			}
-			if ((cur_len >= GREAT_MATCH || P >= cur_p + MINIMUM_MATCH) && cur_len >= MINIMUM_MATCH) {
-				if (n_rec >= rec_cap) {
-					error = 1;
-					return;
-				}
-				if (lane == 0) {
-					MatchRec r;
-					r.p = cur_p;
-					r.ofs = cur_ofs;
-					r.len = cur_len;
-					records[n_rec] = r;
-				}
-				n_rec++;
-				R.last_match = cur_p + cur_len;
-				p_skip = R.last_match;
-				cur_p = R.last_match;
-				cur_len = 0;
-				again = P > p_skip && P <= R.end && (T & R.min_mask) == R.min_mask;
-			}
-		} while (again);
-	};
+	// (wave 0) one exact automaton step at candidate (P, T)
+	auto serial_step = [&](i64 P, u64 T) { A.step(P, T); };
 
 	// ---- candidate queue (LDS), filled by wave 0 from the K1 lists ----
 	int tile = 0;
@@ -351,7 +307,14 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 		// (the staging area is the hit scratch of phase A: the first barrier of the next round lies in between)
 	};
 
-	int poor_rounds = 0, serial_left = 0;
+	// When rounds stop paying the automaton takes a stretch of exact steps and then tries rounds again.  A round that
+	// commits fewer than POOR_ROUND candidates is a poor one (it costs 12 to 35 us, an exact step 2 to 3); poor rounds
+	// raise a score, good ones lower it twice as fast; at POOR_SCORE a stretch begins, and every stretch that ends
+	// where it began -- two more poor rounds -- is twice as long as the one before, until the score is back at zero.
+	// (With fixed stretches of 256 steps a 5 MiB input of four symbols spent 3 of its 8 s in the rounds in between, one
+	// of random phrases a round per match: profiles/r5_serial_step.log.)
+	constexpr int POOR_ROUND = 12, SPAN_MIN = 256, SPAN_MAX = 16384, POOR_SCORE = 8;
+	int poor_rounds = 0, serial_left = 0, serial_span = SPAN_MIN;
 	__syncthreads();
 	for (;;) {
 		// ---- wave 0: queue, top-up size, state for the others ----
@@ -433,8 +396,8 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 				while (c < lim && !error && (c == 0 || !(batch_mode & 1) || cur_len > 0 || serial_left > 0)) {
 					if (serial_left > 0)
 						serial_left--;
-					const i64 P = (i64)bcast64((u64)w_pos, c);
-					const u64 T = bcast64(w_tag, c);
+					const i64 P = (i64)readlane64((u64)w_pos, c);
+					const u64 T = readlane64(w_tag, c);
 					if (P > p_skip && (T & R.min_mask) == R.min_mask)
 						serial_step(P, T);
 					c++;
@@ -805,13 +768,18 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 				R.clean_ptr = (i64)last_clean;
 				R.tag_mask = better; // clean_one_from_hash() returns better_than_min
 			}
-			if (f < 4 && f < wcount) {
-				if (++poor_rounds >= 8) {
-					poor_rounds = 0;
-					serial_left = 256;
+			if (n_commit < POOR_ROUND && f < wcount) { // (f also counts the candidates a match has jumped over)
+				if (++poor_rounds >= POOR_SCORE) {
+					poor_rounds = POOR_SCORE - 2; // (two more poor rounds after the stretch and the next one follows)
+					serial_left = serial_span;
+					if (serial_span < SPAN_MAX)
+						serial_span *= 2;
 				}
-			} else
-				poor_rounds = 0;
+			} else {
+				poor_rounds = poor_rounds > 2 ? poor_rounds - 2 : 0;
+				if (!poor_rounds)
+					serial_span = SPAN_MIN;
+			}
 		}
 		if (first_clean)
 			w_simd = false; // the insert mask changed: every kept simulation is stale
@@ -865,6 +833,6 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 		st->tag_hits = R.tag_hits;
 		st->tag_misses = R.tag_misses;
 		for (int k = 0; k < 16; k++)
-			st->dbg[k] += dbg[k];
+			st->dbg[k] += dbg[k] + (k == 2 ? serial_n : 0);
 	}
 }

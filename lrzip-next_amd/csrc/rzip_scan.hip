@@ -255,6 +255,12 @@ __device__ __forceinline__ u64 bcast64(u64 v, int src)
 	uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)(v >> 32), src);
 	return ((u64)hi << 32) | lo;
 }
+// the same when every lane asks for the same source lane (src is wave-uniform): no trip through the LDS crossbar
+__device__ __forceinline__ u64 readlane64(u64 v, int src)
+{
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+	return ((u64)hi << 32) | lo;
+}
 __device__ __forceinline__ u64 mask_up(u64 m) { return (m << 1) | 1; }
 __device__ __forceinline__ int bitness_rank(u64 t) // ffsll(~t)
 {
@@ -379,6 +385,7 @@ back_done:;
 	return len < MINIMUM_MATCH ? 0 : len;
 }
 
+
 struct Resolver {
 	const uint8_t *buf;
 	Slot *tbl;
@@ -442,7 +449,7 @@ struct Resolver {
 			u64 stop = __ballot(mism < 8);
 			if (stop) {
 				int first = __ffsll((long long)stop) - 1;
-				i64 r = done + (i64)first * 8 + __shfl(mism, first);
+				i64 r = done + (i64)first * 8 + __builtin_amdgcn_readlane(mism, first);
 				return r < total ? r : total;
 			}
 			done += 512;
@@ -518,7 +525,7 @@ struct Resolver {
 				if (o < best)
 					best = o;
 			}
-			best = (i64)bcast64((u64)best, 0);
+			best = (i64)readlane64((u64)best, 0);
 			if (best < ((i64)1 << 40)) {
 				i64 r = done + best;
 				return r < total ? r : total;
@@ -553,7 +560,7 @@ struct Resolver {
 			u64 stop = __ballot(mism < 8);
 			if (stop) {
 				int first = __ffsll((long long)stop) - 1;
-				i64 r = done + (i64)first * 8 + __shfl(mism, first);
+				i64 r = done + (i64)first * 8 + __builtin_amdgcn_readlane(mism, first);
 				return r < max_back ? r : max_back;
 			}
 			done += 512;
@@ -604,9 +611,9 @@ struct Resolver {
 			while (hits) {
 				int idx = __ffsll((long long)hits) - 1;
 				hits &= hits - 1;
-				i64 cand_off = (i64)bcast64((u64)s.offset, idx);
-				i64 rev = (i64)bcast64((u64)l_rev, idx);
-				i64 mlen = (i64)bcast64((u64)l_len, idx);
+				i64 cand_off = (i64)readlane64((u64)s.offset, idx);
+				i64 rev = (i64)readlane64((u64)l_rev, idx);
+				i64 mlen = (i64)readlane64((u64)l_len, idx);
 				if (mlen < 0)
 					mlen = match_len(p, cand_off, &rev);
 				if (mlen) {
@@ -681,8 +688,8 @@ struct Resolver {
 						write_h = (i64)sh;
 					} else { // lesser bitness: rehash the occupant, then take its place
 						displaced = true;
-						disp_t = bcast64(s.t, s1);
-						disp_off = (i64)bcast64((u64)s.offset, s1);
+						disp_t = readlane64(s.t, s1);
+						disp_off = (i64)readlane64((u64)s.offset, s1);
 						write_h = (i64)sh;
 					}
 					break;
@@ -745,6 +752,79 @@ struct Resolver {
 			min_mask = better;
 			clean_ptr = 0;
 		}
+	}
+};
+
+// The hash_search automaton as wave 0 of k_resolve_mw carries it: the table side (Resolver) and the match in the making.
+struct Automaton {
+	Resolver R;
+	i64 p_skip, cur_p, cur_ofs, cur_len;
+	i64 n_rec, rec_cap, inserts, lookups;
+	i64 serial_n; // exact steps taken
+	MatchRec *records;
+	int error;
+
+	// what follows the lookup and the insert of a step (src/rzip.c:697-731): the longer match is kept, and one that is
+	// long enough or far enough behind is emitted; true = emitted and the same candidate stands again
+	__device__ __forceinline__ bool keep_or_emit(i64 P, u64 T, i64 mlen, i64 offset, i64 reverse)
+	{
+		if (mlen > cur_len) {
+			cur_p = P - reverse;
+			cur_len = mlen;
+			cur_ofs = offset;
+		}
+		if (!((cur_len >= GREAT_MATCH || P >= cur_p + MINIMUM_MATCH) && cur_len >= MINIMUM_MATCH))
+			return false;
+		if (n_rec >= rec_cap) {
+			error = 1;
+			return false;
+		}
+		if (R.lane == 0) {
+			MatchRec r;
+			r.p = cur_p;
+			r.ofs = cur_ofs;
+			r.len = cur_len;
+			records[n_rec] = r;
+		}
+		n_rec++;
+		R.last_match = cur_p + cur_len;
+		p_skip = R.last_match;
+		cur_p = R.last_match;
+		cur_len = 0;
+		return P > p_skip && P <= R.end && (T & R.min_mask) == R.min_mask;
+	}
+
+	// One exact step at candidate (P, T), every case: the body of hash_search's loop, src/rzip.c:656-736.
+	__device__ __forceinline__ void step(i64 P, u64 T)
+	{
+		serial_n++;
+		R.allow_abort = true; // (a long extent may go to the whole GPU only before the candidate's first insert)
+		bool again;
+		do {
+			i64 offset = 0, reverse = 0;
+			lookups++;
+			const i64 hits0 = R.tag_hits, misses0 = R.tag_misses;
+			const i64 mlen = R.lookup(T, P, &offset, &reverse);
+			if (R.aborted) {
+				lookups--;
+				serial_n--;
+				R.tag_hits = hits0;
+				R.tag_misses = misses0;
+				if (P - 1 > p_skip)
+					p_skip = P - 1;
+				error = 3;
+				return;
+			}
+			R.allow_abort = false;
+			if ((T & R.tag_mask) == R.tag_mask) {
+				inserts++;
+				R.hash_count++;
+				R.insert(T, P);
+				if (R.hash_count > R.hash_limit)
+					R.tag_mask = R.clean_one();
+			}
+			again = keep_or_emit(P, T, mlen, offset, reverse);
+		} while (again && !error);
 	}
 };
 
