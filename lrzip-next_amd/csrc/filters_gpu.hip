@@ -14,14 +14,15 @@
 //     ORIGINAL bytes only (everything a conversion writes lies behind the scan position), and both forget their
 //     history quickly: after 7 bytes without an opcode byte the x86 scan is in its initial state at the next one;
 //     after three parcels that are neither JAL nor AUIPC the RISC-V scan visits the next candidate whatever happened
-//     before.  So: (1) compact the candidate positions (hipCUB select), (2) one thread per run of candidates that lie
+//     before.  So: (1) compact the candidate positions (rocPRIM select), (2) one thread per run of candidates that lie
 //     closer than that walks its run exactly like the serial scan and marks what is converted (and with which
 //     history), (3) one thread per marked candidate converts it -- converted units never overlap.  The candidate
 //     list holds every position if it must: a block dense in opcode bytes (not machine code) goes the same way, its
 //     candidates forming fewer, longer runs (round 3 had a one-thread kernel for such blocks: seconds per block).
 // Bound: HBM, ~3 B per block byte (count + select read the block, the word kernels read + write it).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 #include "common.h"
 #include "filters.h"
@@ -354,10 +355,10 @@ size_t filter_scratch_bytes(int flag, size_t n)
 	// code -- is walked by the same kernels, its candidates just form few long runs), marks, select's temp
 	const size_t cap = n + 1024;
 	size_t temp = 0, temp2 = 0;
-	hipcub::CountingInputIterator<uint32_t> it(0);
+	rocprim::counting_iterator<uint32_t> it(0);
 	const int items = (int)(n > 0x7FFFFFFF ? 0x7FFFFFFF : n);
-	(void)hipcub::DeviceSelect::If(nullptr, temp, it, (uint32_t *)nullptr, (int *)nullptr, items, IsX86Opcode{nullptr});
-	(void)hipcub::DeviceSelect::If(nullptr, temp2, it, (uint32_t *)nullptr, (int *)nullptr, items, IsRvCandidate{nullptr});
+	(void)rocprim::select(nullptr, temp, it, (uint32_t *)nullptr, (int *)nullptr, (size_t)items, IsX86Opcode{nullptr});
+	(void)rocprim::select(nullptr, temp2, it, (uint32_t *)nullptr, (int *)nullptr, (size_t)items, IsRvCandidate{nullptr});
 	if (temp2 > temp)
 		temp = temp2;
 	return 256 + ((cap * 4 + 255) & ~(size_t)255) + ((cap + 255) & ~(size_t)255) + temp + 4096;
@@ -426,12 +427,12 @@ int filter_block_device(int flag, int delta, uint8_t *d, size_t n, uint8_t *scra
 			return 0;
 		if (total > cap)
 			return -2; // (cannot happen: there are no more candidates than positions)
-		hipcub::CountingInputIterator<uint32_t> it(0);
+		rocprim::counting_iterator<uint32_t> it(0);
 		hipError_t e;
 		if (x86)
-			e = hipcub::DeviceSelect::If(d_temp, temp, it, d_pos, d_count, (int)n_items, IsX86Opcode{d}, s);
+			e = rocprim::select(d_temp, temp, it, d_pos, d_count, (size_t)n_items, IsX86Opcode{d}, s);
 		else
-			e = hipcub::DeviceSelect::If(d_temp, temp, it, d_pos, d_count, (int)n_items, IsRvCandidate{d}, s);
+			e = rocprim::select(d_temp, temp, it, d_pos, d_count, (size_t)n_items, IsRvCandidate{d}, s);
 		if (e != hipSuccess)
 			return -3;
 		const unsigned g = grid_for((size_t)total);

@@ -23,8 +23,8 @@ struct MfWorkspace {
 	uint32_t *pool_tmp;
 	uint32_t *pool_out;   // result: entries in position order
 	void *scalars;
-	void *cub_tmp;
-	size_t cub_bytes;
+	void *prim_tmp;
+	size_t prim_bytes;
 };
 
 // pool_per_pos: u32 pool entries reserved per input byte (typical text needs ~6-10).

@@ -25,7 +25,11 @@
 // Roofline: latency bound pointer chasing (the longest bucket's serial walk sets the launch time), no MFMA.
 // Algorithmic bytes/position: 1 B read + 4 B head r/w + 8 B son pair (+ <=48 node visits) -- see DESIGN.md.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include <cstdio>
 #include <cstdlib>
@@ -1324,20 +1328,20 @@ int mf_workspace_create(MfWorkspace **out, size_t max_n, double pool_per_pos)
 	HIPCHK(hipMalloc(&w->pool_tmp, w->pool_cap * 4));
 	HIPCHK(hipMalloc(&w->pool_out, w->pool_cap * 4));
 	HIPCHK(hipMalloc(&w->scalars, 128));
-	// temp storage: the largest request among the cub calls used below
+	// temp storage: the largest request among the rocPRIM calls used below
 	size_t need = 0, t = 0;
-	(void)hipcub::DeviceRadixSort::SortPairs(nullptr, t, w->key_a, w->key_b, w->val_a, w->val_b, (int)max_n, 0, 32);
+	(void)rocprim::radix_sort_pairs(nullptr, t, w->key_a, w->key_b, w->val_a, w->val_b, (size_t)max_n, 0, 32);
 	need = t;
-	(void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, t, w->key_a, w->key_b, w->val_a, w->val_b, (int)max_n, 0, 32);
+	(void)rocprim::radix_sort_pairs_desc(nullptr, t, w->key_a, w->key_b, w->val_a, w->val_b, (size_t)max_n, 0, 32);
 	if (t > need) need = t;
-	(void)hipcub::DeviceSelect::Flagged(nullptr, t, hipcub::CountingInputIterator<uint32_t>(0), w->flags, w->seg_start,
-				      (uint32_t *)w->scalars, (int)max_n);
+	(void)rocprim::select(nullptr, t, rocprim::counting_iterator<uint32_t>(0), w->flags, w->seg_start,
+				      (uint32_t *)w->scalars, (size_t)max_n);
 	if (t > need) need = t;
-	hipcub::TransformInputIterator<unsigned long long, CountToU64, const uint8_t *> it(w->counts, CountToU64());
-	(void)hipcub::DeviceScan::ExclusiveSum(nullptr, t, it, (unsigned long long *)w->offsets, (int)max_n);
+	rocprim::transform_iterator<const uint8_t *, CountToU64, unsigned long long> it(w->counts, CountToU64());
+	(void)rocprim::exclusive_scan(nullptr, t, it, (unsigned long long *)w->offsets, 0ull, (size_t)max_n, rocprim::plus<unsigned long long>());
 	if (t > need) need = t;
-	w->cub_bytes = need + 256;
-	HIPCHK(hipMalloc(&w->cub_tmp, w->cub_bytes));
+	w->prim_bytes = need + 256;
+	HIPCHK(hipMalloc(&w->prim_tmp, w->prim_bytes));
 	*out = w;
 	return 0;
 }
@@ -1348,7 +1352,7 @@ void mf_workspace_destroy(MfWorkspace *w)
 		return;
 	void *ptrs[] = {w->key_a, w->key_b, w->val_a, w->val_b, w->spos, w->prev2, w->prev3, w->seg_start, w->seg_len,
 			w->seg_start_s, w->seg_len_s, w->flags, w->son, w->counts, w->tmp_start, w->offsets, w->pool_tmp,
-			w->pool_out, w->scalars, w->cub_tmp};
+			w->pool_out, w->scalars, w->prim_tmp};
 	for (void *p : ptrs)
 		if (p)
 			(void)hipFree(p);
@@ -1400,16 +1404,16 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 			const int g = grid_for(n5, 256);
 			uint32_t *prev5 = w->son; // the tree array is free in this mode
 			hipLaunchKernelGGL(k_keys<2>, dim3(g), dim3(256), 0, s, d_src, n5, mask, 0, w->key_a, w->val_a);
-			tb = w->cub_bytes;
-			HIPCHK(hipcub::DeviceRadixSort::SortPairs(w->cub_tmp, tb, w->key_a, w->key_b, w->val_a, w->val_b, (int)n5, 0, 10, s));
+			tb = w->prim_bytes;
+			HIPCHK(rocprim::radix_sort_pairs(w->prim_tmp, tb, w->key_a, w->key_b, w->val_a, w->val_b, (size_t)n5, 0, 10, s));
 			hipLaunchKernelGGL(k_link_prev, dim3(g), dim3(256), 0, s, w->key_b, w->val_b, n5, w->prev2);
 			hipLaunchKernelGGL(k_keys<3>, dim3(g), dim3(256), 0, s, d_src, n5, mask, 0, w->key_a, w->val_a);
-			tb = w->cub_bytes;
-			HIPCHK(hipcub::DeviceRadixSort::SortPairs(w->cub_tmp, tb, w->key_a, w->key_b, w->val_a, w->val_b, (int)n5, 0, 16, s));
+			tb = w->prim_bytes;
+			HIPCHK(rocprim::radix_sort_pairs(w->prim_tmp, tb, w->key_a, w->key_b, w->val_a, w->val_b, (size_t)n5, 0, 16, s));
 			hipLaunchKernelGGL(k_link_prev, dim3(g), dim3(256), 0, s, w->key_b, w->val_b, n5, w->prev3);
 			hipLaunchKernelGGL(k_keys<5>, dim3(g), dim3(256), 0, s, d_src, n5, mask, 0, w->key_a, w->val_a);
-			tb = w->cub_bytes;
-			HIPCHK(hipcub::DeviceRadixSort::SortPairs(w->cub_tmp, tb, w->key_a, w->key_b, w->val_a, w->val_b, (int)n5, 0, bits, s));
+			tb = w->prim_bytes;
+			HIPCHK(rocprim::radix_sort_pairs(w->prim_tmp, tb, w->key_a, w->key_b, w->val_a, w->val_b, (size_t)n5, 0, bits, s));
 			hipLaunchKernelGGL(k_link_prev, dim3(g), dim3(256), 0, s, w->key_b, w->val_b, n5, prev5);
 			t_bt = new EventTimer(s);
 			hipLaunchKernelGGL(k_hc5, dim3((unsigned)((n + 63) / 64)), dim3(64), rec_lds_bytes(cut + 2), s, d_src, (uint32_t)n, w->prev2, w->prev3, prev5, dict, fb,
@@ -1426,22 +1430,22 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 
 		// h2 table: previous position with the same 10-bit hash
 		hipLaunchKernelGGL(k_keys<2>, dim3(g), dim3(256), 0, s, d_src, n4, mask, big, w->key_a, w->val_a);
-		tb = w->cub_bytes;
-		HIPCHK(hipcub::DeviceRadixSort::SortPairs(w->cub_tmp, tb, w->key_a, w->key_b, w->val_a, w->val_b, (int)n4, 0, 10, s));
+		tb = w->prim_bytes;
+		HIPCHK(rocprim::radix_sort_pairs(w->prim_tmp, tb, w->key_a, w->key_b, w->val_a, w->val_b, (size_t)n4, 0, 10, s));
 		hipLaunchKernelGGL(k_link_prev, dim3(g), dim3(256), 0, s, w->key_b, w->val_b, n4, w->prev2);
 		// h3 table
 		hipLaunchKernelGGL(k_keys<3>, dim3(g), dim3(256), 0, s, d_src, n4, mask, big, w->key_a, w->val_a);
-		tb = w->cub_bytes;
-		HIPCHK(hipcub::DeviceRadixSort::SortPairs(w->cub_tmp, tb, w->key_a, w->key_b, w->val_a, w->val_b, (int)n4, 0, 16, s));
+		tb = w->prim_bytes;
+		HIPCHK(rocprim::radix_sort_pairs(w->prim_tmp, tb, w->key_a, w->key_b, w->val_a, w->val_b, (size_t)n4, 0, 16, s));
 		hipLaunchKernelGGL(k_link_prev, dim3(g), dim3(256), 0, s, w->key_b, w->val_b, n4, w->prev3);
 		// main hash: buckets
 		hipLaunchKernelGGL(k_keys<4>, dim3(g), dim3(256), 0, s, d_src, n4, mask, big, w->key_a, w->val_a);
-		tb = w->cub_bytes;
-		HIPCHK(hipcub::DeviceRadixSort::SortPairs(w->cub_tmp, tb, w->key_a, w->key_b, w->val_a, w->spos, (int)n4, 0, bits, s));
+		tb = w->prim_bytes;
+		HIPCHK(rocprim::radix_sort_pairs(w->prim_tmp, tb, w->key_a, w->key_b, w->val_a, w->spos, (size_t)n4, 0, bits, s));
 		hipLaunchKernelGGL(k_flag_heads, dim3(g), dim3(256), 0, s, w->key_b, n4, w->flags);
-		tb = w->cub_bytes;
-		HIPCHK(hipcub::DeviceSelect::Flagged(w->cub_tmp, tb, hipcub::CountingInputIterator<uint32_t>(0), w->flags,
-						     w->seg_start, d_nseg, (int)n4, s));
+		tb = w->prim_bytes;
+		HIPCHK(rocprim::select(w->prim_tmp, tb, rocprim::counting_iterator<uint32_t>(0), w->flags,
+						     w->seg_start, d_nseg, (size_t)n4, s));
 		// buckets of at least long_min positions get a wavefront each, those of at least mid_min eight lanes (k_bt_group),
 		// the rest one lane (k_bt); read per call: tests force 1 (every bucket through the pipelined kernels) and a huge
 		// value (none) inside one process
@@ -1464,9 +1468,9 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 		const uint32_t nmid_end = sc[13] > nseg ? nseg : (sc[13] < nlong ? nlong : sc[13]);
 		const uint32_t ngrp_waves = (nmid_end - nlong + 7) / 8;
 		// longest buckets first
-		tb = w->cub_bytes;
-		HIPCHK(hipcub::DeviceRadixSort::SortPairsDescending(w->cub_tmp, tb, w->seg_len, w->seg_len_s, w->seg_start,
-								    w->seg_start_s, (int)nseg, 0, 32, s));
+		tb = w->prim_bytes;
+		HIPCHK(rocprim::radix_sort_pairs_desc(w->prim_tmp, tb, w->seg_len, w->seg_len_s, w->seg_start,
+								    w->seg_start_s, (size_t)nseg, 0, 32, s));
 		const uint32_t chunk = pool_chunk(w->pool_cap, (unsigned long long)nlong + ngrp_waves + (nseg - nmid_end + 63) / 64);
 		t_bt = new EventTimer(s);
 		// the eight-lane kernel starts walks / writes finished ones out when 24 lanes of the wavefront wait for it, at the
@@ -1487,9 +1491,9 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 		t_bt->stop();
 	}
 	{
-		size_t tb = w->cub_bytes;
-		hipcub::TransformInputIterator<unsigned long long, CountToU64, const uint8_t *> it(w->counts, CountToU64());
-		HIPCHK(hipcub::DeviceScan::ExclusiveSum(w->cub_tmp, tb, it, (unsigned long long *)w->offsets, (int)n, s));
+		size_t tb = w->prim_bytes;
+		rocprim::transform_iterator<const uint8_t *, CountToU64, unsigned long long> it(w->counts, CountToU64());
+		HIPCHK(rocprim::exclusive_scan(w->prim_tmp, tb, it, (unsigned long long *)w->offsets, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), s));
 		hipLaunchKernelGGL(k_gather, dim3(grid_for(n, 256)), dim3(256), 0, s, w->counts, w->tmp_start,
 				   (const unsigned long long *)w->offsets, w->pool_tmp, w->pool_out, (uint32_t)n, w->pool_cap, mode, d_src);
 		hipLaunchKernelGGL(k_total, dim3(1), dim3(1), 0, s, w->counts, (const unsigned long long *)w->offsets, (uint32_t)n, d_total);

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Sections of the exact steps of a serial episode (a build with -DLRZGPU_SERIAL_LAPS; shader-clock ticks of 10 ns).
+"""Sections of the exact steps of a serial episode: needs tools/experiments/resolver_serial_steps_as_functions.patch applied and a build
+with -DLRZGPU_SERIAL_LAPS (make HIPFLAGS_rzip_scan="... -DLRZGPU_SERIAL_LAPS"); ticks of s_memtime.
 usage: python tools/serial_laps.py [few|phrases] [level]"""
 import os, sys, time, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
