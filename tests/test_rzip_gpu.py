@@ -35,6 +35,22 @@ def test_scan_equals_oracle(B, O, kind, level):
     _check(B, O, datagen.KINDS[kind](n, seed=level + 11), level=level)
 
 
+@pytest.mark.parametrize("kind", ["few", "phrases"])
+def test_serial_stretches_replace_rounds_that_do_not_pay(B, O, kind):
+    """An input whose tags crowd into a few buckets ('few': every candidate conflicts with its neighbours), or one that is a
+    short match every 25 candidates ('phrases'), commits two or three candidates per round: the resolver takes stretches of
+    exact steps that double while rounds stay poor (rzip_resolve_mw.h).  Same streams and statistics as the oracle, and
+    the rounds are few -- with fixed stretches of 256 steps they were 1 per 25 candidates (about 40 000 here)."""
+    from test_chunks_gpu import _bench, _profile
+    data = datagen.KINDS[kind]((2 << 20) + 99, seed=9)
+    B.lib().lrzgpu_profile_reset()
+    st = _check(B, O, data, level=7)
+    p = _profile(B, _bench())
+    rounds, committed, exact = (int(v) for v in p.resolve_dbg[:3])
+    assert committed + exact <= st.lookups  # (a candidate that stands again after its match was emitted is looked up twice)
+    assert exact > 0.9 * st.lookups and rounds < 2500, (rounds, committed, exact)
+
+
 def test_table_fill_and_clean_sweeps(B, O):
     """Large enough that the L7 table (2.8M entries) fills and the clean sweep wraps several times."""
     n = 48 * 1048576 + 5
