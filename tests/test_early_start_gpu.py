@@ -40,7 +40,7 @@ def test_every_block_started_early(B, O, forced, kind):
     # (a four-symbol alphabet makes the slowest blocks there are for resolver, finder and parser alike: one whole block + the
     #  short last one of those -- 50 repeated phrases, as slow, go through the same paths in tests/test_compress_gpu.py --;
     #  three of the others)
-    n = (34 << 20) + 77 if kind not in ("phrases", "few") else (12 << 20) + 5
+    n = (34 << 20) + 77 if kind not in ("phrases", "few") else (10 << 20) + (640 << 10) + 5
     data = datagen.KINDS[kind](n, seed=41)
     if kind in ("phrases", "few"):
         forced.setenv("LRZGPU_EARLY_STEP", str(3 << 20))  # (a finder run on such a prefix takes seconds: four of them, not ten)
