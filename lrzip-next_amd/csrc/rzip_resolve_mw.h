@@ -310,21 +310,22 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 	};
 
 	// When rounds stop paying the automaton takes a stretch of exact steps and then tries rounds again.  A round is a
-	// poor one when the exact steps its time buys are more than the candidates it committed -- both measured on the
-	// shader clock: a round costs 12 us on text and 35 us where every probe window is full, an exact step 2 to 3 us --;
-	// poor rounds raise a score, good ones lower it twice as fast; at POOR_SCORE a stretch begins, and every stretch
-	// that ends where it began -- two more poor rounds -- is twice as long as the one before, until the score is back at
-	// zero.  (With fixed stretches of 256 steps a 5 MiB input of four symbols spent 3 of its 8 s in the rounds in
-	// between, one of random phrases a round per match: profiles/r5_serial_step.log.)
-	constexpr int SPAN_MIN = 256, SPAN_MAX = 16384, POOR_SCORE = 8;
-	u64 t_round = 0;            // (wave 0) shader clock at the top of the round
-	uint32_t step_ticks = 5000; // (wave 0) what an exact step costs, running average
+	// poor one when it stopped early having committed fewer than POOR_COMMIT candidates: a round costs 12 us on text and
+	// 35 us where every probe window is full, an exact step 2 to 3 us, so below eight candidates the steps are the cheaper
+	// way.  The rule counts candidates and nothing else: rounds 1 to 5 judged a round by the shader clock against an
+	// assumed cost of a step, which made a branch of this kernel depend on what s_memtime counts on the box (on one whose
+	// counter ran slower than assumed no round was ever poor).  Poor rounds raise a score, good ones lower it
+	// twice as fast; at POOR_SCORE a stretch begins, and every stretch that ends where it began -- two more poor rounds --
+	// is twice as long as the one before, until the score is back at zero.  (With fixed stretches of 256 steps a 5 MiB
+	// input of four symbols spent 3 of its 8 s in the rounds in between, one of random phrases a round per match:
+	// profiles/r5_serial_step.log.)  batch_mode bits 2 and 3 are the test hooks that force the verdict: no round is ever
+	// poor / every round is (LRZGPU_RESOLVE_POOR=never|always, read per scan): both paths are parity-tested on every box.
+	constexpr int SPAN_MIN = 256, SPAN_MAX = 16384, POOR_SCORE = 8, POOR_COMMIT = 8;
 	int poor_rounds = 0, serial_left = 0, serial_span = SPAN_MIN;
 	__syncthreads();
 	for (;;) {
 		// ---- wave 0: queue, top-up size, state for the others ----
 		if (master) {
-			t_round = __builtin_amdgcn_s_memtime();
 			int mode = 0, k = 0;
 			if (error)
 				mode = 2;
@@ -398,7 +399,6 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 		if (mode == 1) {
 			if (master) {
 				const int lim = wcount < 64 ? wcount : 64;
-				const i64 steps0 = serial_n;
 				int c = 0;
 				while (c < lim && !error && (c == 0 || !(batch_mode & 1) || cur_len > 0 || serial_left > 0)) {
 					if (serial_left > 0)
@@ -408,10 +408,6 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 					if (P > p_skip && (T & R.min_mask) == R.min_mask)
 						serial_step(P, T);
 					c++;
-				}
-				if (serial_n > steps0) {
-					const uint32_t each = (uint32_t)(__builtin_amdgcn_s_memtime() - t_round) / (uint32_t)(serial_n - steps0);
-					step_ticks = (3 * step_ticks + each) / 4;
 				}
 				if (lane == 0)
 					U.shift = c;
@@ -780,7 +776,8 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 				R.tag_mask = better; // clean_one_from_hash() returns better_than_min
 			}
 			// (n_commit, not f: f also counts the candidates a match has jumped over)
-			if (f < wcount && (u64)n_commit * step_ticks < __builtin_amdgcn_s_memtime() - t_round) {
+			const bool poor = (batch_mode & 8) ? true : (batch_mode & 4) ? false : f < wcount && n_commit < POOR_COMMIT;
+			if (poor) {
 				if (++poor_rounds >= POOR_SCORE) {
 					poor_rounds = POOR_SCORE - 2; // (two more poor rounds after the stretch and the next one follows)
 					serial_left = serial_span;

@@ -1602,6 +1602,15 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 	HIPCHK(hipMemsetAsync(w->fp_bytes, 0, ((size_t)1 << w->hash_bits) + 256, s));
 	HIPCHK(hipMemcpyAsync(w->state, &h, sizeof(h), hipMemcpyHostToDevice, s));
 
+	// test hook, read per scan: the resolver's verdict on its rounds forced either way (rzip_resolve_mw.h) -- the rounds and
+	// the stretches of exact steps are two implementations of one automaton, and the suite runs every data kind through both
+	int batch_mode = w->batch_mode;
+	if (const char *e = getenv("LRZGPU_RESOLVE_POOR")) {
+		if (!strcmp(e, "never"))
+			batch_mode |= 4;
+		else if (!strcmp(e, "always"))
+			batch_mode |= 8;
+	}
 	const auto wall0 = std::chrono::steady_clock::now();
 	const int64_t end = h.end;
 	int64_t p_skip = 0;
@@ -1670,7 +1679,7 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 		{
 			hipLaunchKernelGGL((k_resolve_mw<4, MAX_HITS, MAX_EQS>), dim3(1), dim3(256), 0, s, d_chunk, (Slot *)w->table, w->state, (i64)seg_lo,
 					   ntiles, (const uint32_t *)w->cand_rel, (const u64 *)w->cand_tag, (const uint32_t *)w->tile_count, w->records,
-					   w->batch_mode, (const uint32_t *)w->tile_base, (const uint32_t *)w->comp_rel, (const u64 *)w->comp_tag,
+					   batch_mode, (const uint32_t *)w->tile_base, (const uint32_t *)w->comp_rel, (const u64 *)w->comp_tag,
 					   (uint32_t)w->comp_cap, w->rank_bytes, w->fp_bytes);
 		}
 		t2.stop();

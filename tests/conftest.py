@@ -16,6 +16,7 @@ sys.path.insert(0, HERE)
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "perf: asserts round counts or seconds, not bytes -- collected after every parity test")
 
 
 # The two full-size configurations run first: 32 GiB of input + a 34 GB image (and 16 GiB + its decode) want the
@@ -28,6 +29,10 @@ def pytest_collection_modifyitems(config, items):
     if first:
         rest = [it for it in items if it not in first]
         items[:] = first + rest
+    # assertions about counts and seconds go last: under -x they can never hide a parity test
+    perf = [it for it in items if it.get_closest_marker("perf")]
+    if perf:
+        items[:] = [it for it in items if it not in perf] + perf
 
 
 def load_bindings():

@@ -141,7 +141,6 @@ def test_block_beyond_the_device_is_refused_at_once(B):
     3 GiB file is ONE 3 GiB block.  The GPU match finder keeps ~142 B per block byte resident, so a block has a
     ceiling on a given device (lrzgpu_max_block_bytes: ~1.9 GB on 288 GB); a plan above it is refused with
     LRZGPU_E_BLOCK_TOO_LARGE before anything is scanned -- not with an out-of-memory error minutes into the run."""
-    import time
     import torch
     L = B.lib()
     L.lrzgpu_max_block_bytes.restype = C.c_int64
@@ -156,7 +155,5 @@ def test_block_beyond_the_device_is_refused_at_once(B):
     plan, _ = B.plan(n, level=7, threads=1, processors=1, ramsize=ram)
     assert plan.stream_bufsize == n > ceiling
     buf = torch.zeros(n + 256, dtype=torch.uint8, device="cuda")
-    t0 = time.time()
-    with pytest.raises(RuntimeError, match="rc=-108"):
+    with pytest.raises(RuntimeError, match="rc=-108"):  # (that it comes at once: tests/test_zz_perf_gpu.py)
         B.compress_device(buf.data_ptr(), n, level=7, threads=1, processors=1, ramsize=ram, host_threads=4)
-    assert time.time() - t0 < 5.0

@@ -53,6 +53,20 @@ def test_k1_full_path_equals_reference_binary_output(O, syn64):
     assert len(out) == rec["size"] and sha(out) == rec["sha256"]
 
 
+def test_k3_reference_defaults_equal_reference_binary_output(O, syn64):
+    """The reference binary run with its DEFAULTS on the survey container (third row: 8 cores => 9 compress
+    slots, 62 GiB of RAM): the other branch of open_stream_out's stream_bufsize rule (src/stream.c:1311-1323: limit /
+    threads is not above 10 MiB => 10 MiB blocks) and seven LZMA blocks in one chunk; recorded sha256."""
+    if O.ref_lzma() is None:
+        pytest.skip("oracle/_ref/liblzma_ref.so not present")
+    rec = KA["reference_recorded"]["k3"]
+    out, fs = O.compress_buffer(syn64, compression_level=7, threads=8, processors=rec["processors"], ramsize=rec["ramsize"], workers=4)
+    assert fs.stream_bufsize == rec["stream_bufsize"] and fs.threads_used == rec["threads"]
+    assert len(out) == rec["size"] and sha(out) == rec["sha256"]
+    k1 = KA["reference_recorded"]["k1"]
+    assert (rec["size"], rec["sha256"]) != (k1["size"], k1["sha256"])
+
+
 @pytest.mark.parametrize("case", KA["oracle"], ids=lambda c: "%s-%d-L%d" % (c["kind"], c["n"], c["level"]))
 def test_oracle_stream_fixtures(O, case):
     data = datagen.KINDS[case["kind"]](case["n"], seed=case["seed"])

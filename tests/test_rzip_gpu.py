@@ -35,20 +35,19 @@ def test_scan_equals_oracle(B, O, kind, level):
     _check(B, O, datagen.KINDS[kind](n, seed=level + 11), level=level)
 
 
-@pytest.mark.parametrize("kind", ["few", "phrases"])
-def test_serial_stretches_replace_rounds_that_do_not_pay(B, O, kind):
-    """An input whose tags crowd into a few buckets ('few': every candidate conflicts with its neighbours), or one that is a
-    short match every 25 candidates ('phrases'), commits two or three candidates per round: the resolver takes stretches of
-    exact steps that double while rounds stay poor (rzip_resolve_mw.h).  Same streams and statistics as the oracle, and
-    the rounds are few -- with fixed stretches of 256 steps they were 1 per 25 candidates (about 40 000 here)."""
-    from test_chunks_gpu import _bench, _profile
-    data = datagen.KINDS[kind]((2 << 20) + 99, seed=9)
-    B.lib().lrzgpu_profile_reset()
-    st = _check(B, O, data, level=7)
-    p = _profile(B, _bench())
-    rounds, committed, exact = (int(v) for v in p.resolve_dbg[:3])
-    assert committed + exact <= st.lookups  # (a candidate that stands again after its match was emitted is looked up twice)
-    assert exact > 0.9 * st.lookups and rounds < 2500, (rounds, committed, exact)
+@pytest.mark.parametrize("verdict", ["never", "always"])
+@pytest.mark.parametrize("kind", ["few", "phrases", "text", "longrange", "random"])
+def test_rounds_and_exact_stretches_are_one_automaton(B, O, kind, verdict, monkeypatch):
+    """The resolver replays hash_search (src/rzip.c:304-353, 495-534, 586-762) two ways: speculative rounds over a window of
+    candidates, and stretches of exact steps when rounds stop paying (rzip_resolve_mw.h: a round is poor when it stopped
+    early with fewer than eight candidates committed -- a count, not a clock).  LRZGPU_RESOLVE_POOR forces the verdict, so
+    every data kind goes through BOTH paths on every box: 'never' = rounds only (the degenerate kinds commit two or three
+    candidates a round: kept small), 'always' = a stretch after every eight rounds, doubling to 16 384 steps."""
+    monkeypatch.setenv("LRZGPU_RESOLVE_POOR", verdict)
+    degenerate = kind in ("few", "phrases")
+    n = ((256 << 10) if verdict == "never" else (1 << 20)) + 99 if degenerate else 3 * 1048576 + 777
+    for level in ((7, 9) if degenerate else (7,)):
+        _check(B, O, datagen.KINDS[kind](n, seed=9 + level), level=level)
 
 
 def test_table_fill_and_clean_sweeps(B, O):

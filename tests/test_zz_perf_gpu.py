@@ -1,0 +1,40 @@
+"""Assertions about ROUND COUNTS and SECONDS -- not about bytes.  They live here, collected after every parity test
+(the file name sorts last and conftest.py moves anything marked `perf` to the end), so that under `pytest -x` a
+performance regression can never again keep parity tests from running (one such assertion inside
+test_rzip_gpu.py hid 83 tests)."""
+import ctypes as C
+import time
+
+import pytest
+
+import datagen
+
+pytestmark = [pytest.mark.gpu, pytest.mark.perf]
+
+
+@pytest.mark.parametrize("kind", ["few", "phrases"])
+def test_serial_stretches_replace_rounds_that_do_not_pay(B, O, kind):
+    """An input whose tags crowd into a few buckets ('few': every candidate conflicts with its neighbours), or one that is a
+    short match every 25 candidates ('phrases'), commits two or three candidates per round: the resolver must not pay a
+    35 us round for them.  The verdict counts candidates (no clock), so the figures are the same on every box."""
+    from test_chunks_gpu import _bench, _profile
+    from test_rzip_gpu import _check
+    data = datagen.KINDS[kind]((2 << 20) + 99, seed=9)
+    B.lib().lrzgpu_profile_reset()
+    st = _check(B, O, data, level=7)
+    p = _profile(B, _bench())
+    rounds, committed, exact = (int(v) for v in p.resolve_dbg[:3])
+    assert committed + exact <= st.lookups  # (a candidate that stands again after its match was emitted is looked up twice)
+    assert rounds < 2500 or committed > 0.9 * st.lookups, (rounds, committed, exact)
+
+
+def test_block_above_the_ceiling_is_refused_at_once(B):
+    """LRZGPU_E_BLOCK_TOO_LARGE comes before anything is scanned: in seconds, not minutes into the run
+    (the refusal itself is asserted in test_configs_gpu.py)."""
+    import torch
+    n = 3 << 30
+    buf = torch.zeros(n + 256, dtype=torch.uint8, device="cuda")
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match="rc=-108"):
+        B.compress_device(buf.data_ptr(), n, level=7, threads=1, processors=1, ramsize=64 << 30, host_threads=4)
+    assert time.time() - t0 < 5.0
