@@ -60,7 +60,8 @@ class Profile(C.Structure):
                 ("long_compare_launches", C.c_int64), ("long_compare_bytes", C.c_int64), ("spec_rollbacks", C.c_int64),
                 ("spec_cancelled_blocks", C.c_int64), ("victim_rescans", C.c_int64),
                 ("union_ms", C.c_double * 8), ("peak_concurrency", C.c_double * 8),
-                ("pipeline_s", C.c_double * 8), ("mf_wave_dbg", C.c_int64 * 4), ("early_s", C.c_double * 4)]
+                ("pipeline_s", C.c_double * 8), ("mf_wave_dbg", C.c_int64 * 4), ("early_s", C.c_double * 4),
+                ("shard_s", C.c_double * 6)]
 
 
 ALPHABETS = {
@@ -255,11 +256,11 @@ def gpu_state():
         return {"unavailable": repr(e)[:120]}
 
 
-def file_to_file_leg(B, buf, n_bytes, fresh_ctl):
+def file_to_file_leg(B, buf, n_bytes, fresh_ctl, passes=3):
     """The metric as test/speedtest.sh:98 defines it -- file in, file out: the identical bytes as a FILE (tmpfs, so
     the page cache is what the reference's mmap would read too), lrzgpu_compress_file() from its fd to the fd of an
     output file on the same tmpfs.  Input pages go host -> HBM over PCIe inside the timed region, the image is
-    written with write().  One warm-up pass, one timed pass."""
+    written with write().  One warm-up pass, then `passes` timed ones: the MEDIAN is the figure."""
     import torch
     best = None
     for d in ("/dev/shm", "/tmp"):
@@ -280,7 +281,7 @@ def file_to_file_leg(B, buf, n_bytes, fresh_ctl):
                 f.write(buf[o:min(n_bytes, o + piece)].cpu().numpy().tobytes())
         times = []
         size = 0
-        for _ in range(2):
+        for _ in range(1 + passes):
             fi = os.open(src, os.O_RDONLY)
             fo = os.open(dst, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
             c = fresh_ctl()
@@ -300,10 +301,14 @@ def file_to_file_leg(B, buf, n_bytes, fresh_ctl):
             for piece in iter(lambda: f.read(64 << 20), b""):
                 h.update(piece)
         digest = h.hexdigest()
-        return {"value": round(n_bytes / 1048576 / times[-1], 2), "unit": "MB/s (2^20 B/s)", "seconds": round(times[-1], 2),
-                "first_pass_seconds": round(times[0], 2), "output_bytes": size, "image_sha256": digest,
+        timed = sorted(times[1:])
+        med = timed[len(timed) // 2] if len(timed) % 2 else 0.5 * (timed[len(timed) // 2 - 1] + timed[len(timed) // 2])
+        return {"value": round(n_bytes / 1048576 / med, 2), "unit": "MB/s (2^20 B/s)", "seconds": round(med, 2),
+                "timed_passes_seconds": [round(t, 2) for t in times[1:]], "first_pass_seconds": round(times[0], 2),
+                "output_bytes": size, "image_sha256": digest,
                 "what": "lrzgpu_compress_file(fd of a %d-byte file on %s -> fd of a file on %s): pread + H2D of every chunk, "
-                        "write() of every chunk image, magic rewritten at the end; second of two passes" % (n_bytes, best, best)}
+                        "write() of every chunk image, magic rewritten at the end; median of %d timed passes after one "
+                        "warm-up pass" % (n_bytes, best, best, len(timed))}
     finally:
         for pth in (src, dst):
             try:
@@ -350,6 +355,7 @@ def main():
     ap.add_argument("--cpu-sample-chunks", type=int, default=0,
                     help="rzip chunks of the same buffer the CPU baseline compresses (0 = the WHOLE file, the default)")
     ap.add_argument("--no-file-leg", action="store_true", help="skip the untimed-for-`value` file-to-file step")
+    ap.add_argument("--file-passes", type=int, default=3, help="timed passes of the file-to-file leg (the median is reported)")
     ap.add_argument("--timeline", default="", help="write every kernel launch of the timed region as kernel,start_ms,end_ms (CSV) "
                                                    "plus a per-250-ms count of launches in flight per kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -523,6 +529,20 @@ def main():
     L.lrzgpu_profile_get(C.byref(prof))
     role_cpu = (C.c_double * 8)()
     L.lrzgpu_profile_cpu(role_cpu, 0)
+    rank_stages = None
+    if world > 1:
+        # what each stage needs on a rank's own resources, per step: the MAX over the ranks (and rank 0's hash, which no
+        # other rank has) -- the step cannot be shorter than the largest of them
+        k = max(args.steps, 1)
+        mine_s = [prof.pipeline_s[0] / max(host_threads, 1) / k, prof.pipeline_s[4] / k,
+                  (prof.pipeline_s[2] + prof.pipeline_s[3]) / max(args.gpu_slots, 1) / k,
+                  prof.shard_s[0] / k, prof.shard_s[1] / k, prof.shard_s[2] / k, prof.shard_s[3] / k, prof.shard_s[4] / k,
+                  prof.shard_s[5] / k, prof.pipeline_s[1] / k, role_cpu[0] / k]
+        t = torch.tensor(mine_s, dtype=torch.float64, device=comm_dev)
+        tsum = t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        rank_stages = ([float(v) for v in t.tolist()], [float(v) for v in tsum.tolist()])
     state_after = gpu_state() if rank == 0 else None
     if rank == 0 and args.timeline:
         names = ["k_tag_scan", "k_resolve", "k_crc32_tiles", "k_gather_runs", "k_lz4_size", "k_bt", "finder", "k_long_compare"]
@@ -624,10 +644,28 @@ def main():
                          "note": "a stage's figure is the time it needs on its own resources (busy seconds / workers; the scans "
                                  "run unthrottled from t = 0); the step cannot be shorter than the largest.  The finder "
                                  "workers are throttled by the encoders (a bounded number of blocks hold lists in host "
-                                 "memory), so their LAST block ends late whatever their speed"} if world == 1 else None
+                                 "memory), so their LAST block ends late whatever their speed"}
+        if world > 1:
+            mx, sm = rank_stages
+            st_n = {"host parser + range coder (%d threads per rank, max over ranks)" % host_threads: mx[0],
+                    "rzip scan (a rank's last chunk done, max over ranks)": mx[1],
+                    "match finder + list copy (%d GPU slots per rank, max over ranks)" % args.gpu_slots: mx[2],
+                    "whole-input hash on rank 0 (done at, since the start of its run)": mx[7],
+                    "chunk hand-off into rank 0 (receive + lay-out)": mx[6]}
+            critical_path = {"stage": max(st_n, key=lambda q: st_n[q]), "seconds_per_step": {q: round(v, 2) for q, v in st_n.items()},
+                             "step_seconds": round(step_s, 2),
+                             "a_rank_own_chunks_wall_s_max": round(mx[3], 2), "chain_check_wait_s_max": round(mx[4], 2),
+                             "chunks_redone_s_max": round(mx[5], 2), "protocol_wall_s_max": round(mx[8], 2),
+                             "encoders_cpu_s_per_step_all_ranks": round(sm[10], 1), "encoders_idle_s_per_step_all_ranks": round(sm[9], 1),
+                             "host_cpus_usable_shared_by_the_ranks": round(usable, 1),
+                             "encoder_cpu_s_over_usable_cpus": round(sm[10] / max(usable, 1.0), 2),
+                             "note": "one file over N ranks is STRONG scaling of a format with two serial parts: the whole-input "
+                                     "MD5 (one dependency chain, on rank 0 from t = 0: src/rzip.c:1195-1219) and the LZMA parse on "
+                                     "host threads, which the N ranks of one node SHARE (encoder CPU-seconds / usable CPUs is a "
+                                     "floor of the step at any N).  What shards is the GPU half: scan, gate, finder (DESIGN.md 7)"}
         file_leg = None
         if world == 1 and not args.no_file_leg:
-            file_leg = file_to_file_leg(B, buf, n_bytes, fresh_ctl)
+            file_leg = file_to_file_leg(B, buf, n_bytes, fresh_ctl, max(1, args.file_passes))
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             sample = n_bytes if args.cpu_sample_chunks <= 0 else min(n_bytes, args.cpu_sample_chunks * chunk_size)
@@ -655,6 +693,10 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
             "critical_path": critical_path,
             "value_file_to_file": file_leg,
+            "value_note": "`value` = the K timed steps with the input ALREADY RESIDENT in HBM -- what this run's measurement contract "
+                          "prescribes for `value` (the PCIe-inclusive rate is never `value`); the metric exactly as "
+                          "test/speedtest.sh:98 / SURVEY 8(d) define it (file open -> magic written) is value_file_to_file.value, "
+                          "the median of its timed passes, and vs_cpu_baseline.file_to_file is the ratio to quote",
             "gpu_state": {"before_timed_region": state_before, "after_timed_region": state_after},
         }
         if cpu and cpu.get("value"):

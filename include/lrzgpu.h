@@ -428,6 +428,12 @@ typedef struct lrzgpu_profile {
 	 * spent waiting for the next part of a started block (counted in pipeline_s[1] too), 2 blocks started early,
 	 * 3 finder runs on their prefixes */
 	double early_s[4];
+	/* one file over N ranks (lrzgpu_compress_sharded*, lrzgpu_shard_protocol), this rank, summed over the runs since the
+	 * reset (seconds): 0 this rank's own chunks through the whole path (on rank 0 the whole-input hash runs beside them
+	 * and is waited for), 1 the chain check (all-reduce: includes waiting for the slowest rank), 2 chunks redone + their
+	 * checks, 3 the hand-off (sending this rank's images / receiving the others' and laying the file out), 4 when the
+	 * whole-input hash was done (since the start of its run; rank 0), 5 wall time of the protocol */
+	double shard_s[6];
 } lrzgpu_profile;
 void lrzgpu_profile_reset(void);
 void lrzgpu_profile_get(lrzgpu_profile *out);

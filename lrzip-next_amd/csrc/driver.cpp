@@ -107,7 +107,9 @@ extern "C" int64_t lrzgpu_max_block_bytes(int device)
 	const double per_byte = 110.0 + 8.0 * kMinPoolPerPos + 2.0;
 	const double room = (double)total - (double)DeviceBudget::margin() - (double)((size_t)4 << 30) - (double)((size_t)64 << 20);
 	const double n = room / per_byte;
-	const double cap = 4294967295.0 - 65536.0; // (and the 32-bit positions of the format's encoder)
+	// (the walk's son slots are 32-bit `2 * node + side` words: 2^31 positions -- mf_run_device has the same guard; a
+	// part with 320 GB or more would otherwise advertise blocks the finder cannot hold: ADVICE r5)
+	const double cap = 2147483632.0; // 0x7FFFFFF0
 	return n <= 0 ? 0 : (int64_t)(n < cap ? n : cap);
 }
 

@@ -1377,7 +1377,7 @@ int mf_run_device(MfWorkspace *w, const uint8_t *d_src, size_t n, uint32_t dict,
 	const size_t mask_n = block_n > n ? block_n : n; // the size the reference's finder would be created for
 	if (mode < 0 || mode > 2 || (mode == 2 && (dict > (1u << 25) || fb > 65)))
 		return -3;
-	if (n > w->max_n || n >= 0xFFFFFFF0ull)
+	if (n > w->max_n || n >= 0x7FFFFFF0ull) // (son slots are 32-bit `2 * node + side` words: lrzgpu_max_block_bytes() has the same cap)
 		return -2;
 	if (2 * (cut + 2) > (uint32_t)kMaxRec || 2 * (cut + 2) > 255)
 		return -3;

@@ -336,7 +336,12 @@ int duplicate_census(const uint8_t *d_chunk, int64_t n, int device, hipStream_t 
 	st->sample_equal = (int64_t)dups;
 	if (r == 1 || dups > (unsigned long long)kMaxSuspects)
 		return 0; // (a few equal values may be chance: the full pass looks at them)
-	// all of them
+	// all of them -- two key arrays of 8 B per anchor (one per 8 positions at most) and the sort's own temporary: about
+	// 3 n bytes for the moment, while other scanners and the finders of the run allocate beside this one.  A census that
+	// would take the device below its margin is skipped (the resolver runs as ever) rather than make somebody else's
+	// allocation fail
+	if (DeviceBudget::free_now() < (size_t)n * 3 + DeviceBudget::margin())
+		return 0;
 	const unsigned long long cap = (unsigned long long)(n / 8) + 65536;
 	uint64_t suspects[kMaxSuspects];
 	r = census_pass(d_chunk, n, 0, cap, device, s, &dups, &anchors, suspects);

@@ -41,6 +41,9 @@ struct Run {
 		bool allocated = false;
 	};
 	std::vector<ReadState> read_state;
+	// input copies the committer is through with and only the whole-input hash still reads (under mu)
+	static constexpr int kHashHeldMax = 2;
+	int hash_held_behind = 0;
 	void reader_main(int t)
 	{
 		if (hipSetDevice(P.device) != hipSuccess) {
@@ -52,6 +55,10 @@ struct Run {
 		uint8_t *stage[2] = {nullptr, nullptr};
 		hipEvent_t done[2] = {nullptr, nullptr};
 		auto cleanup = [&] {
+			// (a failing run arrives here with copies out of the pinned pieces still queued: the stream and the pieces go
+			// back to their pools, where the next run -- or another run of this process -- takes them, only once it is idle)
+			if (s)
+				(void)stream_wait(s);
 			for (int q = 0; q < 2; q++)
 				if (done[q])
 					(void)hipEventDestroy(done[q]);
@@ -80,10 +87,14 @@ struct Run {
 			ChunkCtx *cc = chunks[(size_t)mine[m]].get();
 			int rc = 0;
 			{
-				// at most scan_slots + 1 chunks ahead of the committer hold input copies; the first reader to arrive
-				// sets the chunk's buffer up for all of them
+				// at most scan_slots + 1 chunks ahead of the committer hold input copies -- plus, for a file, the copies
+				// the committer has let go of and the whole-input hash has not passed yet (md5_main reads the chunks from
+				// HBM): where the pipeline outruns the hash (stored blocks, the census, -n) those are bounded too, or a file
+				// larger than the free HBM would end in LRZGPU_E_NOMEM instead of streaming through.  The
+				// hash works in chunk order on chunks that are already in HBM, so it never waits for a reader held here.
+				// The first reader to arrive sets the chunk's buffer up for all of them.
 				std::unique_lock<std::mutex> lk(mu);
-				cv.wait(lk, [&] { return P.err || m < committed + (size_t)scan_slots + 1; });
+				cv.wait(lk, [&] { return P.err || (m < committed + (size_t)scan_slots + 1 && hash_held_behind <= kHashHeldMax); });
 				if (P.err)
 					break;
 				ReadState &rs = read_state[m];
@@ -299,6 +310,8 @@ struct Run {
 					if (cc->release_wanted) {
 						cc->in_buf.release();
 						cc->d_in = nullptr;
+						hash_held_behind--;
+						cv.notify_all();
 					}
 				}
 			}
@@ -316,7 +329,9 @@ struct Run {
 			}
 		}
 		m.finish(digest);
+		t_hash_done = now_s();
 	}
+	double t_hash_done = 0; // when the whole-input hash was through (md5_main)
 
 	// ---- one chunk through K1..K5 with early block release ---------------------------------------
 	struct Scanner {
@@ -902,9 +917,10 @@ int Run::commit_chunk(size_t m, Commit &c)
 	{
 		// no rescan can be asked for any more: the input copy goes (now, or when the hash has passed it)
 		std::lock_guard<std::mutex> lk(mu);
-		if (cc->hash_holds)
+		if (cc->hash_holds) {
 			cc->release_wanted = true;
-		else {
+			hash_held_behind++; // (readers wait while more than kHashHeldMax copies are held for the hash alone)
+		} else {
 			cc->in_buf.release();
 			cc->d_in = nullptr;
 		}
@@ -1046,6 +1062,7 @@ int Run::run()
 		ps.p.early_s[1] += P.rest_wait;
 		ps.p.early_s[2] += (double)P.n_early_jobs;
 		ps.p.early_s[3] += (double)P.n_early_stages;
+		ps.p.shard_s[4] += t_hash_done > t0 ? t_hash_done - t0 : 0;
 	}
 	{
 		LzmaParams p;

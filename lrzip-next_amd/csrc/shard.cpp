@@ -13,6 +13,7 @@
 // byte of the data path is computed by it.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -24,6 +25,7 @@
 #include "driver.h"
 #include "hashes.h"
 #include "pools.h"
+#include "profile.h"
 #include "stream_layer.h"
 
 using namespace lrzgpu;
@@ -60,6 +62,26 @@ int protocol(lrzgpu_control *control, int64_t n, const lrzgpu_shard_comm *comm, 
 	     const uint8_t *digest, uint8_t **out, int64_t *out_len, int64_t *redone_out)
 {
 	const int rank = comm->rank, world = comm->world;
+	// where this rank's seconds go (lrzgpu_profile.shard_s): a flat curve over N must explain itself
+	auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double t_start = now();
+	double t_own = 0, t_check = 0, t_redo = 0;
+	struct Note {
+		const double &own, &check, &redo, t_start;
+		double t_handoff0 = 0;
+		decltype(now) clk;
+		~Note()
+		{
+			ProfileStore &ps = ProfileStore::get();
+			std::lock_guard<std::mutex> lk(ps.mu);
+			const double t = clk();
+			ps.p.shard_s[0] += own;
+			ps.p.shard_s[1] += check;
+			ps.p.shard_s[2] += redo;
+			ps.p.shard_s[3] += t_handoff0 > 0 ? t - t_handoff0 : 0;
+			ps.p.shard_s[5] += t - t_start;
+		}
+	} note{t_own, t_check, t_redo, t_start, 0, now};
 	Sizing sz;
 	int rc = sizing_for_input(control, n, &sz);
 	if (rc)
@@ -86,6 +108,7 @@ int protocol(lrzgpu_control *control, int64_t n, const lrzgpu_shard_comm *comm, 
 		if (rc || col.rc)
 			local_rc = rc ? rc : col.rc;
 	}
+	t_own = now() - t_start;
 	int64_t redone = 0;
 	std::vector<int64_t> meta((size_t)n_chunks * 3 + 1);
 	for (;;) {
@@ -97,7 +120,10 @@ int protocol(lrzgpu_control *control, int64_t n, const lrzgpu_shard_comm *comm, 
 				meta[(size_t)kv.first * 3 + 2] = kv.second->len;
 			}
 		meta[(size_t)n_chunks * 3] = local_rc ? 1 : 0;
-		if (world > 1 && comm->allreduce_sum_i64(comm->ctx, meta.data(), n_chunks * 3 + 1) != 0)
+		const double t_c0 = now();
+		const int arc = world > 1 ? comm->allreduce_sum_i64(comm->ctx, meta.data(), n_chunks * 3 + 1) : 0;
+		(redone ? t_redo : t_check) += now() - t_c0;
+		if (arc != 0)
 			return local_rc ? local_rc : LRZGPU_E_IO;
 		if (meta[(size_t)n_chunks * 3] != 0)
 			return local_rc ? local_rc : LRZGPU_E_PEER;
@@ -115,7 +141,9 @@ int protocol(lrzgpu_control *control, int64_t n, const lrzgpu_shard_comm *comm, 
 			std::vector<int64_t> victim((size_t)n_chunks, -1);
 			victim[(size_t)bad] = meta[(size_t)(bad - 1) * 3 + 1];
 			images.erase(bad);
+			const double t_r0 = now();
 			rc = safe_fn(bad, n_chunks > bad + 1 ? n_chunks : bad + 1, victim.data()); // chunk `bad` alone
+			t_redo += now() - t_r0;
 			if (rc || col.rc)
 				local_rc = rc ? rc : col.rc; // reported by the next round's all-reduce
 		}
@@ -123,6 +151,7 @@ int protocol(lrzgpu_control *control, int64_t n, const lrzgpu_shard_comm *comm, 
 	if (redone_out)
 		*redone_out = redone;
 	// chunk hand-off to rank 0, in file order
+	note.t_handoff0 = now();
 	if (rank != 0) {
 		for (int k = rank; k < n_chunks; k += world)
 			if (comm->send(comm->ctx, 0, images[k]->bytes.data(), images[k]->len) != 0)

@@ -42,7 +42,15 @@ struct Rccl {
 	ncclResult_t (*GroupStart)() = nullptr;
 	ncclResult_t (*GroupEnd)() = nullptr;
 	bool ok = false;
+	std::string loaded_from; // the path asked for with lrzgpu_rccl_use_library(), or empty: the process's librccl
 };
+// the library to take the entry points from instead of librccl (lrzgpu_rccl_use_library); read once, under its mutex,
+// by the initialisation below
+std::mutex &override_mu()
+{
+	static std::mutex m;
+	return m;
+}
 std::string &library_override()
 {
 	static std::string path;
@@ -53,8 +61,12 @@ Rccl &rccl()
 	static Rccl r;
 	static std::once_flag once;
 	std::call_once(once, [] {
-		if (!library_override().empty())
-			r.h = dlopen(library_override().c_str(), RTLD_NOW | RTLD_LOCAL);
+		{
+			std::lock_guard<std::mutex> lk(override_mu());
+			r.loaded_from = library_override();
+		}
+		if (!r.loaded_from.empty())
+			r.h = dlopen(r.loaded_from.c_str(), RTLD_NOW | RTLD_LOCAL);
 		else
 			for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
 				r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
@@ -296,8 +308,14 @@ extern "C" int lrzgpu_rccl_use_library(const char *path)
 {
 	if (!path || !*path)
 		return LRZGPU_E_PARAM;
-	library_override() = path;
-	return rccl().ok && rccl().h && library_override() == path ? 0 : LRZGPU_E_NODEVICE;
+	{
+		std::lock_guard<std::mutex> lk(override_mu());
+		library_override() = path;
+	}
+	// (an initialisation that has already happened -- from librccl, or from another path -- is not undone: the call
+	// then fails instead of reporting a library that was never loaded)
+	const Rccl &r = rccl();
+	return r.ok && r.h && r.loaded_from == path ? 0 : LRZGPU_E_NODEVICE;
 }
 
 extern "C" int lrzgpu_rccl_available(void)

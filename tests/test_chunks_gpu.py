@@ -175,3 +175,21 @@ def test_fd_path_streams_chunks(B, O, tmp_path):
     B.compress_file(str(src), str(tmp_path / "b.part"), rzip_only_fd=True, level=7, threads=4, processors=8, ramsize=RAM,
                     window=1, host_threads=16)
     assert (tmp_path / "b.part").read_bytes() == want[21:]
+
+
+def test_file_whose_scan_outruns_the_hash(B, tmp_path):
+    """A file of many chunks whose scans take no time (zeros: one long match per chunk, compared at HBM speed) against
+    the whole-input MD5's ~1 GB/s on one host thread: the committer lets go of chunk after chunk while the hash is
+    still reading them from their copies in HBM.  Those copies are bounded (readers wait while more than two are held
+    for the hash alone: csrc/scan_run.cpp) -- the image is the memory-to-memory call's, which
+    tests/test_compress_gpu.py pins to the oracle's."""
+    n = 12 * 104857600 + 4321
+    data = bytes(n)
+    kw = dict(level=7, threads=4, processors=8, ramsize=RAM, window=1, host_threads=8)
+    want, _ = B.compress_buffer(data, **kw)
+    src = tmp_path / "zeros.bin"
+    src.write_bytes(data)
+    B.compress_file(str(src), str(tmp_path / "z.lrz"), **kw)
+    got = (tmp_path / "z.lrz").read_bytes()
+    assert got == want
+    assert B.file_info(got).chunks == 13
