@@ -31,7 +31,7 @@ struct MwUniform { // published by wave 0 before the first barrier of a round
 	i64 scan_end;
 };
 
-template <int NW, int MAXH, int MAXE>
+template <int NW, int MAXH, int MAXE, bool DENSE = false>
 __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restrict__ buf, Slot *__restrict__ tbl, ScanState *__restrict__ st, i64 seg_lo,
 							int ntiles, const uint32_t *__restrict__ cand_rel, const u64 *__restrict__ cand_tag,
 							const uint32_t *__restrict__ tile_count, MatchRec *__restrict__ records, int batch_mode,
@@ -41,7 +41,8 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 {
 	constexpr int W = 64 * NW;
 	constexpr int RINGN = NW >= 8 ? 2 * W : 4 * W;
-	constexpr int PWB = 16; // suspects per wave that get the exact test
+	static_assert(!DENSE || NW == 1, "the dense variant is one wavefront");
+	constexpr int PWB = DENSE ? 64 : 16; // suspects per wave that get the exact test
 	constexpr int CFB = CF_BITS + (NW >= 4 ? 1 : 0); // four times the writes per round: twice the counters
 	constexpr int CFW = (1 << CFB) / 2;
 	__shared__ i64 ring_pos[RINGN];
@@ -66,6 +67,14 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 	__shared__ uint32_t fl_k[NW][PWB], fl_lo[NW][PWB], fl_hi[NW][PWB];
 	__shared__ int fl_res[NW][NW][PWB];
 	__shared__ i64 x_miss;
+	// ---- the dense variant (see "dense" below) ----
+	constexpr int DH = DENSE ? MAXH * 64 : 1, DP = DENSE ? PWB : 1, DEM = 16;
+	__shared__ uint32_t hit_fr[DH];                          // measured extents of the tag hits, beside hit_all
+	__shared__ u64 fl_tag[DP], fl_fa[DP], fl_ba[DP];         // a suspect's tag and the 8 bytes after / before its position
+	__shared__ uint32_t fl_w0[DP];                           // ... and its one write slot
+	__shared__ int fl_soft[DP];                              // did a same-tag eviction in front of it pass as harmless?
+	__shared__ i64 em_p[DEM], em_ofs[DEM], em_len[DEM];      // matches emitted inside the round, in order
+	__shared__ int em_lane[DEM];
 	static_assert(sizeof(i64) * MAXH * 64 * NW >= (size_t)W * 128, "staging area");
 
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, gi = threadIdx.x;
@@ -292,6 +301,10 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 			L.k0 = (int)((pk >> 2) & 7) - 1;
 			L.nw = (int)((pk >> 5) & 7);
 			L.misses = (int)(pk >> 8);
+			if constexpr (DENSE) {
+				L.pot = L.match; // (a kept lane never has possible matches: those are simulated again, their hits are gone)
+				L.nh = 0;
+			}
 			L.lo = sg_u32[2 * W + src];
 			L.hi = sg_u32[3 * W + src];
 			L.tw_slot = sg_u32[4 * W + src];
@@ -322,11 +335,34 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 	// poor / every round is (LRZGPU_RESOLVE_POOR=never|always, read per scan): both paths are parity-tested on every box.
 	constexpr int SPAN_MIN = 256, SPAN_MAX = 16384, POOR_SCORE = 8, POOR_COMMIT = 8;
 	int poor_rounds = 0, serial_left = 0, serial_span = SPAN_MIN;
+	// the two variants hand over to each other through the host (scan_chunk_device): this one asks for the dense variant
+	// when its rounds stop paying (leave = 4), the dense variant gives back when DENSE_IDLE rounds in a row had no use
+	// for what it adds (leave = 5); the kernel ends with ScanState::error = leave and p_skip in front of the first
+	// candidate it has not examined
+	constexpr int DENSE_IDLE = 1024;
+	int leave = 0, dense_idle = 0;
 	__syncthreads();
 	for (;;) {
 		// ---- wave 0: queue, top-up size, state for the others ----
 		if (master) {
 			int mode = 0, k = 0;
+			if (DENSE && dense_idle >= DENSE_IDLE && !(batch_mode & 32))
+				leave = 5;
+			if (leave && !error && cur_len == 0) {
+				// (between two matches only: the next launch starts a new segment at p_skip + 1)
+				refill_ring();
+				i64 next_p = -1;
+				if (wcount > 0)
+					next_p = (i64)readlane64((u64)w_pos, 0);
+				else if (ring_cnt > 0)
+					next_p = ring_pos[ring_head];
+				if (next_p >= 0) {
+					if (next_p - 1 > p_skip)
+						p_skip = next_p - 1;
+					error = leave;
+				}
+				leave = 0;
+			}
 			if (error)
 				mode = 2;
 			else {
@@ -336,8 +372,8 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 					k = ring_cnt;
 				if (wcount + k == 0)
 					mode = 2;
-				else if (!(batch_mode & 1) || cur_len > 0 || serial_left > 0)
-					mode = 1;
+				else if (!(batch_mode & 1) || (!DENSE && cur_len > 0) || serial_left > 0)
+					mode = 1; // (dense: a match in the making is carried through the rounds)
 			}
 			if (lane == 0) {
 				U.min_mask = R.min_mask;
@@ -400,7 +436,7 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 			if (master) {
 				const int lim = wcount < 64 ? wcount : 64;
 				int c = 0;
-				while (c < lim && !error && (c == 0 || !(batch_mode & 1) || cur_len > 0 || serial_left > 0)) {
+				while (c < lim && !error && (c == 0 || !(batch_mode & 1) || (!DENSE && cur_len > 0) || serial_left > 0)) {
 					if (serial_left > 0)
 						serial_left--;
 					const i64 P = (i64)readlane64((u64)w_pos, c);
@@ -426,16 +462,129 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 		{
 			const bool need_sim = alive && !w_simd;
 			if (__ballot(need_sim)) {
-				simulate_lanes<MAXH, MAXE>(R, tbl, buf, tbl_size, better, lane, alive, need_sim, w_tag, w_pos, w_ticket, hit_lds, eqs_lds, W, L, [](int) {});
+				simulate_lanes<MAXH, MAXE, DENSE>(R, tbl, buf, tbl_size, better, lane, alive, need_sim, w_tag, w_pos, w_ticket, hit_lds, eqs_lds, W, L, [](int) {}, hit_fr);
 				if (need_sim)
 					w_simd = true;
 			}
 		}
 
+		// ---- dense: the lazy-match automaton over the window, in candidate order (src/rzip.c:697-731) ----
+		// In the dense variant a candidate whose lookup finds a match does not end the round.  Every lane has measured
+		// its tag hits (simulate_lanes, measure_hit); here the wavefront replays what hash_search does with them one
+		// candidate after the other: the longer match is kept (first of equal lengths: an inclusive prefix maximum over
+		// (length, -lane)), a match is emitted at the first candidate MINIMUM_MATCH behind its start, the candidates
+		// inside it are dead, the ones behind it price their hits again under the new last_match (which clips backward
+		// extents) -- until nothing more is emitted or a candidate needs the exact step (d_stop).  Nothing is written
+		// here: the emissions go to LDS and count only as far as the round commits (phase D).
+		bool live_d = alive;
+		int d_stop = MW_NONE, n_em = 0;
+		i64 post_len = 0, post_p = 0, post_ofs = 0, post_lm = 0; // the match in the making and last_match AFTER this lane
+		int ev_real = 0, ev_miss = 0;                             // what a lane's hits are worth under the last_match it meets
+		u64 d_fa = 0, d_ba = 0;                                   // the 8 bytes after / before the candidate (pair test below)
+		bool d_fb_ok = false;
+		if constexpr (DENSE) {
+			if (alive && w_pos >= 8 && R.end - w_pos >= 8) {
+				d_fa = reinterpret_cast<const U64u *>(buf + w_pos)->v;
+				d_ba = reinterpret_cast<const U64u *>(buf + w_pos - 8)->v;
+				d_fb_ok = true;
+			}
+			i64 c_len = cur_len, c_p = cur_p, c_ofs = cur_ofs, lm = R.last_match; // (wave-uniform)
+			int start = 0;
+			for (;;) {
+				i64 b_len = 0, b_off = 0, b_rev = 0;
+				bool unk = false;
+				const bool mine = live_d && gi >= start;
+				if (mine && L.pot && !L.complex_) {
+					const i64 mb = w_pos - (lm > 0 ? lm : 0);
+					int real = 0, miss = 0;
+					for (int k = 0; k < L.nh; k++) {
+						const uint32_t fr = hit_fr[k * 64 + lane];
+						const i64 fwd = (i64)(fr & 0xFFFFu), back = (i64)((fr >> 16) & 0x7FFFu);
+						const i64 rev = back < mb ? back : mb;
+						if ((fr >> 31) && mb > back)
+							unk = true; // the backward compare stopped at its cap and last_match allows more
+						const i64 len = fwd + rev;
+						if (len < MINIMUM_MATCH)
+							miss++;
+						else {
+							real++;
+							if (len > b_len) {
+								b_len = len;
+								b_rev = rev;
+								b_off = hit_lds[k * 64 + lane] - rev;
+							}
+						}
+					}
+					ev_real = real;
+					ev_miss = miss + (L.twin ? 1 : 0);
+				}
+				const u64 barm = __ballot(mine && (L.complex_ || unk));
+				const int barrier = barm ? __ffsll((long long)barm) - 1 : 64;
+				const bool inr = gi >= start && gi < barrier;
+				uint32_t key = (mine && inr) ? ((uint32_t)b_len << 6 | (uint32_t)(63 - lane)) : 0u;
+#pragma unroll
+				for (int d = 1; d < 64; d <<= 1) {
+					const uint32_t o = __shfl_up(key, d);
+					if (lane >= d && o > key)
+						key = o;
+				}
+				const int src = 63 - (int)(key & 63u);
+				const i64 run_len = (i64)(key >> 6);
+				const i64 s_rev = (i64)bcast64((u64)b_rev, src), s_off = (i64)bcast64((u64)b_off, src), s_pos = (i64)bcast64((u64)w_pos, src);
+				i64 my_len = c_len, my_p = c_p, my_ofs = c_ofs;
+				if (run_len > c_len) {
+					my_len = run_len;
+					my_p = s_pos - s_rev;
+					my_ofs = s_off;
+				}
+				const bool emit = mine && inr && my_len >= MINIMUM_MATCH && (my_len >= GREAT_MATCH || w_pos >= my_p + MINIMUM_MATCH);
+				const u64 em = __ballot(emit);
+				if (inr) {
+					post_len = my_len;
+					post_p = my_p;
+					post_ofs = my_ofs;
+					post_lm = lm;
+				}
+				if (!em) {
+					if (barrier < 64)
+						d_stop = barrier;
+					break;
+				}
+				const int e = __ffsll((long long)em) - 1;
+				const i64 E_len = (i64)readlane64((u64)my_len, e), E_p = (i64)readlane64((u64)my_p, e), E_ofs = (i64)readlane64((u64)my_ofs, e);
+				const i64 E_P = (i64)readlane64((u64)w_pos, e);
+				const i64 nlm = E_p + E_len;
+				if (E_P > nlm || n_em >= DEM || n_rec + n_em >= A.rec_cap) {
+					d_stop = e; // the candidate stands again behind its own emission (or no room): the exact step
+					break;
+				}
+				if (lane == 0) {
+					em_lane[n_em] = e;
+					em_p[n_em] = E_p;
+					em_ofs[n_em] = E_ofs;
+					em_len[n_em] = E_len;
+				}
+				n_em++;
+				if (gi == e) {
+					post_len = 0;
+					post_p = nlm;
+					post_lm = nlm;
+				}
+				c_len = 0;
+				c_p = nlm;
+				c_ofs = E_ofs;
+				lm = nlm;
+				if (gi > e && w_pos <= nlm)
+					live_d = false;
+				start = e + 1;
+			}
+		}
+
 		// ---- phase C: the longest conflict-free prefix of the window ----
-		const bool live = alive;
-		const int x = (live && L.ins && !L.dec && !L.complex_ && !L.match) ? 1 : 0;
-		const bool evicts = live && L.victim && !L.complex_ && !L.match;
+		const bool live = DENSE ? live_d : alive;
+		const bool cut_match = !DENSE && L.match; // (the dense variant carries matches through the round)
+		const int x = (live && L.ins && !L.dec && !L.complex_ && !cut_match) ? 1 : 0;
+		const bool evicts = live && L.victim && !L.complex_ && !cut_match;
 		{
 			const u64 bx = __ballot(x != 0), be = __ballot(evicts);
 			if (lane == 0) {
@@ -533,9 +682,13 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 		if (live && L.complex_) {
 			stop = true;
 			why = 3;
-		} else if (live && L.match) {
+		} else if (live && cut_match) {
 			stop = true;
 			why = 4;
+		}
+		if (DENSE && live && gi == d_stop && !stop) {
+			stop = true;
+			why = 3;
 		}
 		if (cleans) {
 			if (kth < nv)
@@ -558,11 +711,11 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 					why = 7;
 				}
 		// twin successors: did the predecessor's simulation make exactly the predicted insert?
-		const bool tw_live = live && L.twin && !L.complex_ && !L.match;
+		const bool tw_live = live && L.twin && !L.complex_ && !cut_match;
 		if (__ballot(tw_live)) {
 			const uint32_t p_slot = __shfl_up(L.w_slot[0], 1);
 			const int p_nw = __shfl_up(L.nw, 1), p_k0 = __shfl_up(L.k0, 1);
-			const int p_ok = __shfl_up((int)(live && L.ins && !L.complex_ && !L.match && !L.victim && !stop), 1);
+			const int p_ok = __shfl_up((int)(live && L.ins && !L.complex_ && !cut_match && !L.victim && !stop), 1);
 			if (tw_live && !stop && !(lane > 0 && p_ok && p_nw >= 1 && p_slot == L.tw_slot && p_k0 == L.tw_kind)) {
 				stop = true;
 				why = 5;
@@ -590,7 +743,7 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 				__hip_atomic_fetch_add(&cf_bits[wh[k] >> 1], 1u << (16 * (wh[k] & 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		__syncthreads(); // #5
 		lap(14); // stops, twin check, filter writes
-		const bool reads = live && !L.complex_ && !L.match;
+		const bool reads = live && !L.complex_ && !cut_match;
 		const uint32_t r_lo = L.lo & ~7u, r_hi = L.hi | 7u;
 		const uint32_t tw_h = tw_live && !stop ? ((L.tw_slot >> gsh) * 2654435761u) >> (32 - CFB) : 0xFFFFFFFFu;
 		bool flagged = false;
@@ -622,6 +775,8 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 		}
 		lap(15); // filter reads
 		int first_conf = MW_NONE; // window index of the earliest conflicting writer
+		int sup_by = MW_NONE;     // dense: the later candidate that evicts the slot of my own eviction again
+		bool soft_me = false;     // dense: a same-tag eviction in front of me passed as harmless (my kept simulation is stale once it lands)
 		int fidx;
 		{
 			const u64 bf = __ballot(flagged);
@@ -631,6 +786,14 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 					fl_k[wave][fidx] = (uint32_t)gi | (tw_live ? 0x80000000u : 0u); // (a twin's predecessor's insert is part of its simulation)
 					fl_lo[wave][fidx] = r_lo;
 					fl_hi[wave][fidx] = r_hi;
+					if constexpr (DENSE) {
+						// bit 30: one write at most and no clean, 29: no hit of mine can be a match, 28: my bytes are there
+						fl_k[wave][fidx] |= ((L.nw <= 1 && !cleans) ? 0x40000000u : 0u) | (!L.pot ? 0x20000000u : 0u) | (d_fb_ok ? 0x10000000u : 0u);
+						fl_tag[fidx] = w_tag;
+						fl_fa[fidx] = d_fa;
+						fl_ba[fidx] = d_ba;
+						fl_w0[fidx] = wr[0];
+					}
 				} else
 					first_conf = 0; // too many suspects: call the rest conflicting (they re-simulate)
 			}
@@ -652,23 +815,57 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 						continue;
 					// the whole list in registers (lane e holds entry e), then one uniform pass per entry
 					const uint32_t mk = fl_k[w2][lane & (PWB - 1)], mlo = fl_lo[w2][lane & (PWB - 1)], mhi = fl_hi[w2][lane & (PWB - 1)];
-					int res = MW_NONE;
+					// dense: the rest of the suspect's record (lane e holds entry e)
+					const u64 mtag = DENSE ? fl_tag[lane & (DP - 1)] : 0, mfa = DENSE ? fl_fa[lane & (DP - 1)] : 0, mba = DENSE ? fl_ba[lane & (DP - 1)] : 0;
+					const uint32_t mw0 = DENSE ? fl_w0[lane & (DP - 1)] : 0;
+					int res = MW_NONE, soft_res = 0;
 					for (int e = 0; e < n2; e++) {
 						const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)mk, e);
 						const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)mlo, e), khi = (uint32_t)__builtin_amdgcn_readlane((int)mhi, e);
-						const int k = (int)(kk & 0x7FFFFFFFu);
+						const int k = (int)(kk & 0xFFFFu);
 						const bool excl0 = (kk >> 31) != 0 && gi == k - 1; // the twin's predecessor: its insert is expected
 						const uint32_t span = khi - klo;                 // (an unused write slot, 0xFFFFFFFF, is never inside)
 						bool hit = wr[0] - klo <= span && !excl0;
+						bool soft = false;
+						if constexpr (DENSE) {
+							// A round-robin eviction replaces one entry of my tag by another entry of my tag: the slot's rank
+							// byte, fingerprint byte and tag word stay what they are -- only a later candidate of the SAME
+							// tag can tell (its lookup meets my position instead of the evicted one), or one that writes
+							// the slot itself.  For a same-tag candidate whose hits were all misses the exchange is one
+							// certain miss for another when its bytes and mine differ within 8 both ways (fwd < 8 and
+							// back < 8: single_match_len() = 0 whatever last_match is) -- and if it evicts that very slot
+							// in its turn, its store is the one that stands (sup_by).
+							const u64 ktag = readlane64(mtag, e), kfa = readlane64(mfa, e), kba = readlane64(mba, e);
+							const uint32_t kw0 = (uint32_t)__builtin_amdgcn_readlane((int)mw0, e);
+							if (hit && evicts && gi < k && ((kk >> 30) & 1)) {
+								if (w_tag != ktag) {
+									if (wr[0] != kw0)
+										hit = false;
+								} else if (((kk >> 29) & 1) && ((kk >> 28) & 1) && d_fb_ok && d_fa != kfa && d_ba != kba) {
+									hit = false;
+									soft = true;
+									if (wr[0] == kw0 && k < sup_by)
+										sup_by = k;
+								}
+							}
+						}
 #pragma unroll
 						for (int q = 1; q < 5; q++)
 							hit |= wr[q] - klo <= span;
 						const u64 hm = __ballot(hit && gi < k);
 						if (lane == e && hm)
 							res = 64 * wave + __ffsll((long long)hm) - 1;
+						if constexpr (DENSE) {
+							const u64 sm = __ballot(soft && gi < k);
+							if (lane == e && sm)
+								soft_res = 1;
+						}
 					}
-					if (lane < n2)
+					if (lane < n2) {
 						fl_res[wave][w2][lane] = res;
+						if constexpr (DENSE)
+							fl_soft[lane] = soft_res;
+					}
 				}
 				__syncthreads(); // #8
 				if (flagged && fidx < PWB) {
@@ -679,6 +876,8 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 							if (r < first_conf)
 								first_conf = r;
 						}
+					if constexpr (DENSE)
+						soft_me = fl_soft[fidx] != 0;
 				}
 			}
 		}
@@ -720,13 +919,22 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 
 		// ---- phase D: apply the committed prefix ----
 		const bool nxt_over = __shfl_down((int)(gi < f && live && L.twin && L.tw_over), 1) != 0 && lane < 63;
+		int n_real = 0; // dense: real matches met by the committed lookups (tag_hits)
 		if (committed) {
+			const bool superseded = DENSE && evicts && sup_by < f; // (a later committed eviction of the same slot stands)
 			for (int k = 0; k < 4; k++)
-				if (k < L.nw && !(k == 0 && nxt_over))
+				if (k < L.nw && !(k == 0 && (nxt_over || superseded)))
 					R.store_slot(L.w_slot[k], L.w_t[k], L.w_off[k]);
 			if (cleans)
 				R.store_slot(my_vict, 0, 0);
-			miss_acc += L.misses;
+			miss_acc += (DENSE && L.pot) ? ev_miss : L.misses;
+			if (DENSE && L.pot)
+				n_real = ev_real;
+		}
+		if constexpr (DENSE) {
+#pragma unroll
+			for (int d = 32; d >= 1; d >>= 1)
+				n_real += __shfl_xor(n_real, d);
 		}
 		{
 			const u64 cm = __ballot(committed);
@@ -765,6 +973,41 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 			lookups += n_commit;
 			bump(0, 1);
 			bump(1, n_commit);
+			if constexpr (DENSE) {
+				// the matches emitted in front of lane f, and the automaton as lane f - 1 left it
+				R.tag_hits += n_real;
+				int applied = 0;
+				for (int q = 0; q < n_em; q++)
+					if (em_lane[q] < f) {
+						if (lane == 0) {
+							MatchRec r;
+							r.p = em_p[q];
+							r.ofs = em_ofs[q];
+							r.len = em_len[q];
+							A.records[n_rec] = r;
+						}
+						n_rec++;
+						applied++;
+					}
+				if (f > 0) {
+					cur_len = (i64)readlane64((u64)post_len, f - 1);
+					cur_p = (i64)readlane64((u64)post_p, f - 1);
+					cur_ofs = (i64)readlane64((u64)post_ofs, f - 1);
+					const i64 lm = (i64)readlane64((u64)post_lm, f - 1);
+					if (applied) {
+						R.last_match = lm;
+						if (lm > p_skip)
+							p_skip = lm;
+					}
+				}
+				const bool used = applied > 0 || __ballot(committed && (L.pot || soft_me)) != 0;
+				dense_idle = used ? 0 : dense_idle + 1;
+				if (!prof) {
+					bump(8, applied);
+					bump(9, __popcll(__ballot(committed && soft_me)));
+					bump(10, 1);
+				}
+			}
 			if (f < wcount && why_f >= 3 && why_f <= 7)
 				bump(why_f, 1);
 			inserts += n_ins;
@@ -780,15 +1023,25 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 			if (poor) {
 				if (++poor_rounds >= POOR_SCORE) {
 					poor_rounds = POOR_SCORE - 2; // (two more poor rounds after the stretch and the next one follows)
-					serial_left = serial_span;
-					if (serial_span < SPAN_MAX)
-						serial_span *= 2;
+					if (!DENSE && (batch_mode & 16))
+						leave = 4; // the dense variant takes over from the next candidate on (host: scan_chunk_device)
+					else {
+						serial_left = serial_span;
+						if (serial_span < SPAN_MAX)
+							serial_span *= 2;
+					}
 				}
 			} else {
 				poor_rounds = poor_rounds > 2 ? poor_rounds - 2 : 0;
 				if (!poor_rounds)
 					serial_span = SPAN_MIN;
 			}
+		}
+		if constexpr (DENSE) {
+			// a kept lane with possible matches has lost its hits (the window's staging area overlays them), one whose
+			// chain a committed eviction has changed reads other offsets now: both are simulated again
+			if (gi >= f && (L.pot || soft_me))
+				w_simd = false;
 		}
 		if (first_clean)
 			w_simd = false; // the insert mask changed: every kept simulation is stale

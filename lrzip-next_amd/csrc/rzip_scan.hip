@@ -62,6 +62,7 @@ constexpr long long LONG_EXTENT = 4 << 20; // forward extents longer than this g
 constexpr int A1_MAX_STEPS = 8192; // slots a speculative walk may cover (longer clusters: serial path)
 constexpr int MAX_EQS = 32;  // round-robin eviction handled in the batch up to this max_chain_len
 constexpr int MAX_HITS = 24; // tag hits one speculative lookup may verify (more -> serial path)
+constexpr int DENSE_HITS = 40; // ... in the dense variant (one wavefront: its hits and their measured extents have the LDS to themselves)
 // the 8-wavefront resolver trades both for window: 160 KB of LDS hold 512 candidates with these (levels <= 7 only)
 constexpr int CF_BITS = 13; // conflict filter: 16-bit write counters per hashed 8-slot granule (<= 320 writes per round)
 
@@ -851,6 +852,9 @@ struct LaneSim {
 	int tw_kind;
 	int k0; // kind of the first stop of this lane's own insert (-1 none, 3 round-robin eviction)
 	uint32_t tw_slot;
+	// the dense variant (k_resolve_mw<1, ..., true>): the lookup's tag hits stay in LDS with their measured extents
+	int nh;   // how many (<= MAXH)
+	bool pot; // some hit may be a match (forward + backward extent >= MINIMUM_MATCH before last_match clips the latter)
 };
 
 // is there a match of at least MINIMUM_MATCH bytes between p0 and op? (single_match_len() != 0)
@@ -891,16 +895,64 @@ fwd_done:
 	return true;
 }
 
+// The dense variant measures every tag hit instead of asking "is it a match at all": the forward extent (as
+// single_match_len computes it) and the backward extent BEFORE last_match clips it -- min(equal bytes, p0, op) --, so that
+// the in-order pass of a round can price the hit under whatever last_match the emissions in front of it leave
+// (len = fwd + min(back, p0 - last_match), < MINIMUM_MATCH = 0; src/rzip.c:431-461).  Packed: fwd in bits 0..15, back in
+// 16..30, bit 31 = the backward compare stopped at its cap (the extent may be longer).  ~0 = the forward compare ran
+// into its cap: the candidate takes the exact step.
+constexpr uint32_t HIT_UNMEASURED = 0xFFFFFFFFu;
+__device__ __forceinline__ uint32_t measure_hit(const uint8_t *buf, i64 p0, i64 op, i64 end)
+{
+	constexpr i64 FWD_CAP = 512, BACK_CAP = 256;
+	if (op >= p0)
+		return 0;
+	i64 total = end - p0;
+	if (total < 0)
+		total = 0;
+	const i64 capf = total < FWD_CAP ? total : FWD_CAP;
+	i64 fwd = 0;
+	while (fwd + 8 <= capf) {
+		const u64 x = reinterpret_cast<const U64u *>(buf + p0 + fwd)->v ^ reinterpret_cast<const U64u *>(buf + op + fwd)->v;
+		if (x) {
+			fwd += (__ffsll((long long)x) - 1) >> 3;
+			goto fwd_done;
+		}
+		fwd += 8;
+	}
+	while (fwd < capf && buf[p0 + fwd] == buf[op + fwd])
+		fwd++;
+	if (fwd == capf && capf < total)
+		return HIT_UNMEASURED;
+fwd_done:;
+	const i64 max_back = op; // (op < p0)
+	const i64 capb = max_back < BACK_CAP ? max_back : BACK_CAP;
+	i64 back = 0;
+	while (back + 8 <= capb) {
+		const u64 x = reinterpret_cast<const U64u *>(buf + p0 - 8 - back)->v ^ reinterpret_cast<const U64u *>(buf + op - 8 - back)->v;
+		if (x) {
+			back += (i64)(__clzll((long long)x) >> 3);
+			goto back_done;
+		}
+		back += 8;
+	}
+	while (back < capb && buf[p0 - 1 - back] == buf[op - 1 - back])
+		back++;
+back_done:;
+	return (uint32_t)fwd | (uint32_t)back << 16 | ((back == capb && capb < max_back) ? 0x80000000u : 0u);
+}
+
 // Phase A/B of a resolver round, for the lanes with need_sim: one automaton step each, simulated
 // against the table as it stands.  Wave-convergent, so that every dependent HBM round trip is shared
 // by all simulating lanes: (A1) lookup walk in 64-slot steps over the side arrays, (A2) verification of
 // tag hits, (A3) the displacement chain of the insert, one level at a time.  Called by the resolver
 // wave for its window and by the pre-simulation waves for the candidates still in the queue; R is
 // only read (masks, table pointers, last_match); hit_lds / eqs_lds are the caller's own LDS scratch.
-template <int MAXH, int MAXE, class LapF>
+template <int MAXH, int MAXE, bool DENSE, class LapF>
 __device__ __forceinline__ void simulate_lanes(const Resolver &R, const Slot *__restrict__ tbl, const uint8_t *__restrict__ buf, const i64 tbl_size,
 					       const u64 better, const int lane, const bool alive, const bool need_sim, const u64 w_tag,
-					       const i64 w_pos, const int w_ticket, i64 *hit_lds, uint32_t *eqs_lds, const int eqs_stride, LaneSim &L, LapF lap)
+					       const i64 w_pos, const int w_ticket, i64 *hit_lds, uint32_t *eqs_lds, const int eqs_stride, LaneSim &L, LapF lap,
+					       uint32_t *hit_fr = nullptr)
 {
 		const u64 T = w_tag;
 		const i64 P = w_pos;
@@ -1105,7 +1157,33 @@ __device__ __forceinline__ void simulate_lanes(const Resolver &R, const Slot *__
 		}
 		lap(9);
 		// ---- A2: are the tag hits real matches (>= MINIMUM_MATCH)? ----
-		{
+		if constexpr (DENSE) {
+			// every hit measured (measure_hit): what it is worth is decided in candidate order, under the last_match
+			// the emissions in front of the candidate leave behind
+			if (need_sim) {
+				L.nh = 0;
+				L.pot = false;
+			}
+			if (need_sim && !L.complex_) {
+				const int n = nhit < MAXH ? nhit : MAXH;
+				bool pot = false;
+				for (int k = 0; k < n; k++) {
+					const i64 op = hit_lds[k * 64 + lane];
+					uint32_t fr = 0;
+					if (!quick_reject(buf, P, op, R.end, 0))
+						fr = measure_hit(buf, P, op, R.end);
+					hit_fr[k * 64 + lane] = fr;
+					if (fr == HIT_UNMEASURED)
+						L.complex_ = true;
+					else if ((fr & 0xFFFFu) + ((fr >> 16) & 0x7FFFu) >= (uint32_t)MINIMUM_MATCH)
+						pot = true;
+				}
+				L.nh = n;
+				L.pot = pot;
+				L.match = pot;
+				L.misses = n; // (of a candidate without a possible match: every hit a miss under any last_match)
+			}
+		} else {
 			// all hits are pre-tested with independent loads (one round trip), the rare
 			// undecided ones get the exact compare
 			uint32_t und = 0; // bit k: hit k needs the exact compare
@@ -1146,7 +1224,7 @@ __device__ __forceinline__ void simulate_lanes(const Resolver &R, const Slot *__
 		{
 			u64 cur_t = T;
 			i64 cur_off = P;
-			bool chain = need_sim && L.ins && !L.complex_ && !L.match;
+			bool chain = need_sim && L.ins && !L.complex_ && (DENSE || !L.match); // (dense: a match does not end the round)
 #pragma unroll 1
 			for (int level = 0; level < 5; level++) {
 				if (!__ballot(chain))
@@ -1537,7 +1615,8 @@ int scan_workspace_create(ScanWorkspace **out, int rzip_level, int64_t max_chunk
 		const char *pr = getenv("LRZGPU_TRACE"); // bit 1: per-phase cycle counters in the profile (trace level 3)
 		if (pr && atoi(pr) >= 3)
 			w->batch_mode |= 2;
-		w->batch_mode |= 4 << 4; // (bits 4..7: the wavefronts of the resolver workgroup -- four, k_resolve_mw<4>)
+		// bits 2, 3: the verdict on a round forced (LRZGPU_RESOLVE_POOR); 4: the dense variant may be asked for; 5: ... and
+		// never gives back -- all three read per scan (scan_chunk_device)
 	}
 	w->seg_cap = (size_t)1 << 28; // up to 256 Mi positions per segment
 	if ((int64_t)w->seg_cap > max_chunk + TILE)
@@ -1611,6 +1690,22 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 		else if (!strcmp(e, "always"))
 			batch_mode |= 8;
 	}
+	// The resolver has two variants that hand over to each other between launches: k_resolve_mw<4> (four wavefronts, 256
+	// candidates a round: a real match or a neighbour's write into a candidate's probe run ends the round) and the dense
+	// one (one wavefront: matches are carried through the round by an in-order pass, round-robin evictions of one tag
+	// pass each other) for inputs where the first commits two or three candidates a round -- a few symbols, short
+	// phrases over and over.  LRZGPU_RESOLVE_DENSE=0: never (exact stretches instead, rounds 1 to 5); =always: every
+	// launch is the dense one (tests: every data kind through it)
+	bool dense = false;
+	{
+		const char *e = getenv("LRZGPU_RESOLVE_DENSE");
+		if (!e || strcmp(e, "0"))
+			batch_mode |= 16;
+		if (e && !strcmp(e, "always")) {
+			batch_mode |= 32;
+			dense = true;
+		}
+	}
 	const auto wall0 = std::chrono::steady_clock::now();
 	const int64_t end = h.end;
 	int64_t p_skip = 0;
@@ -1676,12 +1771,16 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 				   (u64 *)w->comp_tag);
 		t1.stop();
 		EventTimer t2(s);
-		{
+		if (dense)
+			hipLaunchKernelGGL((k_resolve_mw<1, DENSE_HITS, MAX_EQS, true>), dim3(1), dim3(64), 0, s, d_chunk, (Slot *)w->table, w->state, (i64)seg_lo,
+					   ntiles, (const uint32_t *)w->cand_rel, (const u64 *)w->cand_tag, (const uint32_t *)w->tile_count, w->records,
+					   batch_mode, (const uint32_t *)w->tile_base, (const uint32_t *)w->comp_rel, (const u64 *)w->comp_tag,
+					   (uint32_t)w->comp_cap, w->rank_bytes, w->fp_bytes);
+		else
 			hipLaunchKernelGGL((k_resolve_mw<4, MAX_HITS, MAX_EQS>), dim3(1), dim3(256), 0, s, d_chunk, (Slot *)w->table, w->state, (i64)seg_lo,
 					   ntiles, (const uint32_t *)w->cand_rel, (const u64 *)w->cand_tag, (const uint32_t *)w->tile_count, w->records,
 					   batch_mode, (const uint32_t *)w->tile_base, (const uint32_t *)w->comp_rel, (const u64 *)w->comp_tag,
 					   (uint32_t)w->comp_cap, w->rank_bytes, w->fp_bytes);
-		}
 		t2.stop();
 		HIPCHK(d2h_pageable(&h, w->state, sizeof(h), s)); // (sleeps while the resolver runs)
 		if (getenv("LRZGPU_TRACE"))
@@ -1724,6 +1823,22 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 			if (getenv("LRZGPU_TRACE"))
 				fprintf(stderr, "lrzgpu scan: long extent at %lld from %lld: %lld bytes, k3 %.2f ms\n", (long long)h.ext_p,
 					(long long)h.ext_op, (long long)best, t3.ms());
+			p_skip = h.p_skip;
+			min_mask = h.min_mask;
+			if (progress) {
+				int pr = progress(h, p_skip);
+				if (pr)
+					return pr;
+			}
+			continue;
+		}
+		if (h.error == 4 || h.error == 5) {
+			// the variants hand over: the other one goes on at the first candidate this one has not examined
+			if (getenv("LRZGPU_TRACE"))
+				fprintf(stderr, "lrzgpu scan: the %s resolver takes over at %lld\n", h.error == 4 ? "dense" : "four-wavefront", (long long)h.p_skip + 1);
+			dense = h.error == 4;
+			h.error = 0;
+			HIPCHK(hipMemcpyAsync(w->state, &h, sizeof(h), hipMemcpyHostToDevice, s));
 			p_skip = h.p_skip;
 			min_mask = h.min_mask;
 			if (progress) {

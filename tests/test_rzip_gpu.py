@@ -35,19 +35,68 @@ def test_scan_equals_oracle(B, O, kind, level):
     _check(B, O, datagen.KINDS[kind](n, seed=level + 11), level=level)
 
 
+@pytest.mark.parametrize("dense", ["0", "1"])
 @pytest.mark.parametrize("verdict", ["never", "always"])
 @pytest.mark.parametrize("kind", ["few", "phrases", "text", "longrange", "random"])
-def test_rounds_and_exact_stretches_are_one_automaton(B, O, kind, verdict, monkeypatch):
+def test_rounds_and_exact_stretches_are_one_automaton(B, O, kind, verdict, dense, monkeypatch):
     """The resolver replays hash_search (src/rzip.c:304-353, 495-534, 586-762) two ways: speculative rounds over a window of
     candidates, and stretches of exact steps when rounds stop paying (rzip_resolve_mw.h: a round is poor when it stopped
     early with fewer than eight candidates committed -- a count, not a clock).  LRZGPU_RESOLVE_POOR forces the verdict, so
     every data kind goes through BOTH paths on every box: 'never' = rounds only (the degenerate kinds commit two or three
-    candidates a round: kept small), 'always' = a stretch after every eight rounds, doubling to 16 384 steps."""
+    candidates a round: kept small), 'always' = a stretch after every eight rounds, doubling to 16 384 steps.
+    LRZGPU_RESOLVE_DENSE=0 keeps the stretches inside the four-wavefront kernel (rounds 1 to 5); with 1 (the default) that
+    kernel hands over to the dense variant instead, which takes its own stretches under 'always'."""
     monkeypatch.setenv("LRZGPU_RESOLVE_POOR", verdict)
+    monkeypatch.setenv("LRZGPU_RESOLVE_DENSE", dense)
+    if dense == "1" and verdict == "never":
+        pytest.skip("rounds only: the hand-over is never asked for, same run as with 0")
     degenerate = kind in ("few", "phrases")
     n = ((256 << 10) if verdict == "never" else (1 << 20)) + 99 if degenerate else 3 * 1048576 + 777
     for level in ((7, 9) if degenerate else (7,)):
         _check(B, O, datagen.KINDS[kind](n, seed=9 + level), level=level)
+
+
+@pytest.mark.parametrize("level", [1, 4, 6, 7, 9])
+@pytest.mark.parametrize("kind", ["text", "random", "few", "phrases", "sparse", "zeros", "longrange"])
+def test_dense_resolver_equals_oracle(B, O, kind, level, monkeypatch):
+    """Every data kind through the DENSE variant of the resolver on every launch (LRZGPU_RESOLVE_DENSE=always; by default
+    it only takes over where the four-wavefront rounds stop paying): one wavefront, real matches carried through the
+    round by the in-order lazy-match pass (src/rzip.c:697-731), round-robin evictions of one tag passing each other
+    (src/rzip.c:304-353).  Same streams, same statistics (tag hits and misses included) as the oracle."""
+    monkeypatch.setenv("LRZGPU_RESOLVE_DENSE", "always")
+    n = (2 if kind in ("phrases", "few") else 3) * 1048576 + 777
+    _check(B, O, datagen.KINDS[kind](n, seed=level + 11), level=level)
+
+
+@pytest.mark.parametrize("dense", ["0", "always"])
+def test_dense_resolver_tiny_and_ragged(B, O, dense, monkeypatch):
+    monkeypatch.setenv("LRZGPU_RESOLVE_DENSE", dense)
+    for kind in ("phrases", "few", "longrange", "zeros"):
+        for n in (0, 31, 63, 100, 4097, 70000, 300001):
+            _check(B, O, datagen.KINDS[kind](n, seed=5), level=7)
+
+
+@pytest.mark.parametrize("kind", ["few", "phrases", "dna"])
+def test_degenerate_inputs_hand_over_to_the_dense_resolver(B, O, kind):
+    """Default switches: the four-wavefront resolver asks for the dense one when its rounds commit fewer than eight
+    candidates (a four-letter alphabet: every candidate's insert lands in its neighbours' probe run; phrases: a match
+    every few candidates), the dense one gives back after 1024 rounds that had no use for it.  8 MiB each (the
+    reference's one core needs about 2 s for these; rounds 1 to 5 of this library needed 8 to 13 s for FIVE MiB)."""
+    n = (8 << 20) + 123
+    if kind == "dna":
+        # four letters with repeats: a genome-like input (every 40 KB a copy of an earlier 1-3 KB stretch, lightly mutated)
+        import numpy as np
+        rng = np.random.default_rng(77)
+        a = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].copy()
+        for at in range(50000, n - 4000, 40000):
+            ln = int(rng.integers(1000, 3000))
+            src = int(rng.integers(0, at - ln))
+            a[at:at + ln] = a[src:src + ln]
+            a[at + ln // 2] = 65 if a[at + ln // 2] != 65 else 67
+        data = a.tobytes()
+    else:
+        data = datagen.KINDS[kind](n, seed=9)
+    _check(B, O, data, level=7)
 
 
 def test_table_fill_and_clean_sweeps(B, O):
