@@ -85,6 +85,14 @@ uint64_t lrzgpu_next_tag(const uint8_t *buf, int64_t p, uint64_t t); /* tag at p
 /* equal bytes forwards from (p0, op) up to `end` plus backwards down to max(0, last_match); 0 if fewer than 31;
  * *rev = the backward part */
 int64_t lrzgpu_match_len(const uint8_t *buf, int64_t p0, int64_t op, int64_t end, int64_t last_match, int64_t *rev);
+/* The accelerated form of the first two, on its own: every position p in [first, chunk_size - 31] of a chunk in HBM
+ * (16-byte aligned, readable 64 bytes past its end) whose tag has all bits of min_mask set -- the candidates of
+ * hash_search's loop (src/rzip.c:654-659) as k_tag_scan hands them to the resolver.  *count = how many, *checksum = the
+ * sum over them of ((p + 1) * 0x9E3779B97F4A7C15) ^ (tag * 0xC2B2AE3D27D4EB4F) mod 2^64 (order-free: a caller -- the
+ * tests -- recomputes it from lrzgpu_full_tag / lrzgpu_next_tag).  reps > 1: the kernels are run that many times and
+ * *ms_per_pass is the average of the passes after the first (only_tags: of k_tag_scan alone, without the two list kernels). */
+int lrzgpu_tag_candidates_dev(const void *d_chunk, int64_t chunk_size, int64_t first, uint64_t min_mask, int reps,
+			      int64_t *count, uint64_t *checksum, double *ms_per_pass, int only_tags, int device);
 
 /* ---- misc ------------------------------------------------------------------------------------------------------
  * lrzgpu_trim() (lrzgpu.h) returns parked buffers and workspaces; the streams the library parks instead of destroying

@@ -90,6 +90,42 @@ void emit_streams(const std::vector<MatchRec> &recs, int64_t chunk_size, int chu
 
 } // namespace lrzgpu
 
+// K1 of the scan on its own: the candidate positions of d_chunk[first .. chunk_size - 31] whose 31-byte XOR tag has all
+// bits of min_mask set (src/rzip.c:385-416, 654-659), as the resolver would be handed them.
+extern "C" int lrzgpu_tag_candidates_dev(const void *d_chunk, int64_t chunk_size, int64_t first, uint64_t min_mask, int reps,
+					 int64_t *count, uint64_t *checksum, double *ms_per_pass, int only_tags, int device)
+{
+	int rc = select_device(device);
+	if (rc)
+		return rc;
+	if (chunk_size < 0 || first < 0 || !count || !checksum || ((uintptr_t)d_chunk & 15) != 0)
+		return LRZGPU_E_PARAM;
+	*count = 0;
+	*checksum = 0;
+	if (ms_per_pass)
+		*ms_per_pass = 0;
+	const int64_t end = chunk_size - 31;
+	if (end < first)
+		return 0;
+	ScanWorkspace *w = nullptr;
+	if (scan_workspace_create(&w, 1, chunk_size) != 0) {
+		scan_workspace_destroy(w);
+		return LRZGPU_E_NOMEM;
+	}
+	unsigned long long *d_out = nullptr, h_out[2] = {0, 0};
+	rc = LRZGPU_E_HIP;
+	if (hipMalloc(&d_out, 16) == hipSuccess && tag_candidates_device(w, (const uint8_t *)d_chunk, first, end, min_mask, reps, d_out, ms_per_pass, 0, only_tags != 0) == 0 &&
+	    hipMemcpy(h_out, d_out, 16, hipMemcpyDeviceToHost) == hipSuccess) {
+		*count = (int64_t)h_out[0];
+		*checksum = (uint64_t)h_out[1];
+		rc = 0;
+	}
+	if (d_out)
+		(void)hipFree(d_out);
+	scan_workspace_destroy(w);
+	return rc;
+}
+
 extern "C" int lrzgpu_hash_search_dev(const void *d_chunk, int64_t chunk_size, int rzip_level, int chunk_bytes,
 				      int64_t *victim_round, uint8_t **stream0, int64_t *stream0_len,
 				      void *d_stream1, int64_t *stream1_len, uint32_t *crc32, lrzgpu_scan_stats *stats,

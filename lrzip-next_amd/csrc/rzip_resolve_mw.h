@@ -68,11 +68,9 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 	__shared__ int fl_res[NW][NW][PWB];
 	__shared__ i64 x_miss;
 	// ---- the dense variant (see "dense" below) ----
-	constexpr int DH = DENSE ? MAXH * 64 : 1, DP = DENSE ? PWB : 1, DEM = 16;
+	constexpr int DH = DENSE ? MAXH * 64 : 1, DEM = 16;
 	__shared__ uint32_t hit_fr[DH];                          // measured extents of the tag hits, beside hit_all
-	__shared__ u64 fl_tag[DP], fl_fa[DP], fl_ba[DP];         // a suspect's tag and the 8 bytes after / before its position
-	__shared__ uint32_t fl_w0[DP];                           // ... and its one write slot
-	__shared__ int fl_soft[DP];                              // did a same-tag eviction in front of it pass as harmless?
+	__shared__ u64 q_cache[DENSE ? 32 * 64 : 1];             // a walk step's 4th .. 19th fingerprint match (tag, offset), per lane
 	__shared__ i64 em_p[DEM], em_ofs[DEM], em_len[DEM];      // matches emitted inside the round, in order
 	__shared__ int em_lane[DEM];
 	static_assert(sizeof(i64) * MAXH * 64 * NW >= (size_t)W * 128, "staging area");
@@ -270,7 +268,8 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 			sg_pos[gi] = w_pos;
 			sg_tag[gi] = w_tag;
 			sg_u32[0 * W + gi] = (uint32_t)w_simd | (uint32_t)L.complex_ << 1 | (uint32_t)L.match << 2 | (uint32_t)L.ins << 3 |
-					     (uint32_t)L.victim << 4 | (uint32_t)L.twin << 5 | (uint32_t)L.tw_over << 6 | (uint32_t)(L.dec != 0) << 7;
+					     (uint32_t)L.victim << 4 | (uint32_t)L.twin << 5 | (uint32_t)L.tw_over << 6 | (uint32_t)(L.dec != 0) << 7 |
+					     (uint32_t)(DENSE && L.soft1) << 8;
 			sg_u32[1 * W + gi] = (uint32_t)(L.tw_kind & 3) | (uint32_t)((L.k0 + 1) & 7) << 2 | (uint32_t)(L.nw & 7) << 5 | (uint32_t)(L.misses & 0xFFFF) << 8;
 			sg_u32[2 * W + gi] = L.lo;
 			sg_u32[3 * W + gi] = L.hi;
@@ -297,6 +296,7 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 			L.twin = (fl & 32) != 0;
 			L.tw_over = (fl & 64) != 0;
 			L.dec = (fl >> 7) & 1;
+			L.soft1 = (fl >> 8) & 1;
 			L.tw_kind = (int)(pk & 3);
 			L.k0 = (int)((pk >> 2) & 7) - 1;
 			L.nw = (int)((pk >> 5) & 7);
@@ -336,18 +336,16 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 	constexpr int SPAN_MIN = 256, SPAN_MAX = 16384, POOR_SCORE = 8, POOR_COMMIT = 8;
 	int poor_rounds = 0, serial_left = 0, serial_span = SPAN_MIN;
 	// the two variants hand over to each other through the host (scan_chunk_device): this one asks for the dense variant
-	// when its rounds stop paying (leave = 4), the dense variant gives back when DENSE_IDLE rounds in a row had no use
-	// for what it adds (leave = 5); the kernel ends with ScanState::error = leave and p_skip in front of the first
+	// when its rounds stop paying (leave = 4), the dense variant gives back when fewer than one in eight of DENSE_WINDOW rounds had a
+	// use for what it adds (leave = 5); the kernel ends with ScanState::error = leave and p_skip in front of the first
 	// candidate it has not examined
-	constexpr int DENSE_IDLE = 1024;
-	int leave = 0, dense_idle = 0;
+	constexpr int DENSE_WINDOW = 512;
+	int leave = 0, dense_rounds = 0, dense_used = 0;
 	__syncthreads();
 	for (;;) {
 		// ---- wave 0: queue, top-up size, state for the others ----
 		if (master) {
 			int mode = 0, k = 0;
-			if (DENSE && dense_idle >= DENSE_IDLE && !(batch_mode & 32))
-				leave = 5;
 			if (leave && !error && cur_len == 0) {
 				// (between two matches only: the next launch starts a new segment at p_skip + 1)
 				refill_ring();
@@ -462,7 +460,7 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 		{
 			const bool need_sim = alive && !w_simd;
 			if (__ballot(need_sim)) {
-				simulate_lanes<MAXH, MAXE, DENSE>(R, tbl, buf, tbl_size, better, lane, alive, need_sim, w_tag, w_pos, w_ticket, hit_lds, eqs_lds, W, L, [](int) {}, hit_fr);
+				simulate_lanes<MAXH, MAXE, DENSE>(R, tbl, buf, tbl_size, better, lane, alive, need_sim, w_tag, w_pos, w_ticket, hit_lds, eqs_lds, W, L, [](int) {}, hit_fr, q_cache);
 				if (need_sim)
 					w_simd = true;
 			}
@@ -476,6 +474,8 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 		// inside it are dead, the ones behind it price their hits again under the new last_match (which clips backward
 		// extents) -- until nothing more is emitted or a candidate needs the exact step (d_stop).  Nothing is written
 		// here: the emissions go to LDS and count only as far as the round commits (phase D).
+		if constexpr (DENSE)
+			lap(9); // simulations (the in-order pass below: slot 4, which counts nothing in this variant)
 		bool live_d = alive;
 		int d_stop = MW_NONE, n_em = 0;
 		i64 post_len = 0, post_p = 0, post_ofs = 0, post_lm = 0; // the match in the making and last_match AFTER this lane
@@ -580,11 +580,15 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 			}
 		}
 
+		if constexpr (DENSE)
+			lap(4);
 		// ---- phase C: the longest conflict-free prefix of the window ----
 		const bool live = DENSE ? live_d : alive;
 		const bool cut_match = !DENSE && L.match; // (the dense variant carries matches through the round)
 		const int x = (live && L.ins && !L.dec && !L.complex_ && !cut_match) ? 1 : 0;
 		const bool evicts = live && L.victim && !L.complex_ && !cut_match;
+		// dense: my one write puts an entry of my tag where one of my tag was (round-robin eviction, or kind 1 over my own tag)
+		const bool soft_w = DENSE && (evicts || (live && L.soft1 && L.nw == 1 && !L.complex_));
 		{
 			const u64 bx = __ballot(x != 0), be = __ballot(evicts);
 			if (lane == 0) {
@@ -735,7 +739,9 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 				} else
 					wr[k] = my_vict;
 			}
-			wh[k] = wr[k] != 0xFFFFFFFFu ? ((wr[k] >> gsh) * 2654435761u) >> (32 - CFB) : 0xFFFFFFFFu;
+			// (dense: a write that puts my tag where my tag was is no write for the filter and the exact test -- the pass
+			// over the soft writers below deals with it)
+			wh[k] = wr[k] != 0xFFFFFFFFu && !(k == 0 && soft_w) ? ((wr[k] >> gsh) * 2654435761u) >> (32 - CFB) : 0xFFFFFFFFu;
 		}
 #pragma unroll
 		for (int k = 0; k < 5; k++)
@@ -786,14 +792,6 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 					fl_k[wave][fidx] = (uint32_t)gi | (tw_live ? 0x80000000u : 0u); // (a twin's predecessor's insert is part of its simulation)
 					fl_lo[wave][fidx] = r_lo;
 					fl_hi[wave][fidx] = r_hi;
-					if constexpr (DENSE) {
-						// bit 30: one write at most and no clean, 29: no hit of mine can be a match, 28: my bytes are there
-						fl_k[wave][fidx] |= ((L.nw <= 1 && !cleans) ? 0x40000000u : 0u) | (!L.pot ? 0x20000000u : 0u) | (d_fb_ok ? 0x10000000u : 0u);
-						fl_tag[fidx] = w_tag;
-						fl_fa[fidx] = d_fa;
-						fl_ba[fidx] = d_ba;
-						fl_w0[fidx] = wr[0];
-					}
 				} else
 					first_conf = 0; // too many suspects: call the rest conflicting (they re-simulate)
 			}
@@ -815,57 +813,23 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 						continue;
 					// the whole list in registers (lane e holds entry e), then one uniform pass per entry
 					const uint32_t mk = fl_k[w2][lane & (PWB - 1)], mlo = fl_lo[w2][lane & (PWB - 1)], mhi = fl_hi[w2][lane & (PWB - 1)];
-					// dense: the rest of the suspect's record (lane e holds entry e)
-					const u64 mtag = DENSE ? fl_tag[lane & (DP - 1)] : 0, mfa = DENSE ? fl_fa[lane & (DP - 1)] : 0, mba = DENSE ? fl_ba[lane & (DP - 1)] : 0;
-					const uint32_t mw0 = DENSE ? fl_w0[lane & (DP - 1)] : 0;
-					int res = MW_NONE, soft_res = 0;
+					int res = MW_NONE;
 					for (int e = 0; e < n2; e++) {
 						const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)mk, e);
 						const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)mlo, e), khi = (uint32_t)__builtin_amdgcn_readlane((int)mhi, e);
 						const int k = (int)(kk & 0xFFFFu);
 						const bool excl0 = (kk >> 31) != 0 && gi == k - 1; // the twin's predecessor: its insert is expected
 						const uint32_t span = khi - klo;                 // (an unused write slot, 0xFFFFFFFF, is never inside)
-						bool hit = wr[0] - klo <= span && !excl0;
-						bool soft = false;
-						if constexpr (DENSE) {
-							// A round-robin eviction replaces one entry of my tag by another entry of my tag: the slot's rank
-							// byte, fingerprint byte and tag word stay what they are -- only a later candidate of the SAME
-							// tag can tell (its lookup meets my position instead of the evicted one), or one that writes
-							// the slot itself.  For a same-tag candidate whose hits were all misses the exchange is one
-							// certain miss for another when its bytes and mine differ within 8 both ways (fwd < 8 and
-							// back < 8: single_match_len() = 0 whatever last_match is) -- and if it evicts that very slot
-							// in its turn, its store is the one that stands (sup_by).
-							const u64 ktag = readlane64(mtag, e), kfa = readlane64(mfa, e), kba = readlane64(mba, e);
-							const uint32_t kw0 = (uint32_t)__builtin_amdgcn_readlane((int)mw0, e);
-							if (hit && evicts && gi < k && ((kk >> 30) & 1)) {
-								if (w_tag != ktag) {
-									if (wr[0] != kw0)
-										hit = false;
-								} else if (((kk >> 29) & 1) && ((kk >> 28) & 1) && d_fb_ok && d_fa != kfa && d_ba != kba) {
-									hit = false;
-									soft = true;
-									if (wr[0] == kw0 && k < sup_by)
-										sup_by = k;
-								}
-							}
-						}
+						bool hit = wr[0] - klo <= span && !excl0 && !soft_w;
 #pragma unroll
 						for (int q = 1; q < 5; q++)
 							hit |= wr[q] - klo <= span;
 						const u64 hm = __ballot(hit && gi < k);
 						if (lane == e && hm)
 							res = 64 * wave + __ffsll((long long)hm) - 1;
-						if constexpr (DENSE) {
-							const u64 sm = __ballot(soft && gi < k);
-							if (lane == e && sm)
-								soft_res = 1;
-						}
 					}
-					if (lane < n2) {
+					if (lane < n2)
 						fl_res[wave][w2][lane] = res;
-						if constexpr (DENSE)
-							fl_soft[lane] = soft_res;
-					}
 				}
 				__syncthreads(); // #8
 				if (flagged && fidx < PWB) {
@@ -876,9 +840,43 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 							if (r < first_conf)
 								first_conf = r;
 						}
-					if constexpr (DENSE)
-						soft_me = fl_soft[fidx] != 0;
 				}
+			}
+		}
+		if constexpr (DENSE) {
+			// Soft writes: a round-robin eviction, or a kind-1 insert over an entry of its own tag, replaces one entry of my
+			// tag by another entry of my tag -- the slot's rank byte, fingerprint byte and tag word stay what they are.
+			// Only two kinds of later candidates can tell: one that writes that very slot (the later store must be the
+			// one that stands), and one of the SAME tag, whose lookup meets my position where the replaced entry was.
+			// For a same-tag candidate all of whose hits were misses the exchange is one certain miss for another when
+			// its bytes and mine differ within 8 both ways (fwd < 8, back < 8: single_match_len() = 0 under any
+			// last_match); anything else is a conflict like a hard write.  One pass over the soft writers, every later
+			// lane against the writer's tag, slot and bytes -- no interval, no filter: a lookup always covers its own chain.
+			// (32-bit folds stand for the 64-bit values: different folds prove different values, equal folds are taken for
+			// equal values -- the cautious side of each test; a lane without its bytes gets folds nothing differs from)
+			// (multiplicative folds: the bytes of a four-letter input XOR-fold onto a few hundred values)
+			const uint32_t th = (uint32_t)(w_tag ^ (w_tag >> 32));
+			const uint32_t fah = (uint32_t)((d_fa * 0x9E3779B97F4A7C15ull) >> 32), bah = (uint32_t)((d_ba * 0x9E3779B97F4A7C15ull) >> 32);
+			const bool passable = L.nw <= 1 && !cleans && !L.pot && d_fb_ok && live && !L.complex_;
+			const bool multi = live && (wr[1] != 0xFFFFFFFFu || wr[4] != 0xFFFFFFFFu); // (more write slots than wr[0])
+			const bool looks = live && !L.complex_;
+			for (u64 sw = __ballot(soft_w); sw; sw &= sw - 1) {
+				const int w = __ffsll((long long)sw) - 1;
+				const uint32_t th_w = (uint32_t)__builtin_amdgcn_readlane((int)th, w), fah_w = (uint32_t)__builtin_amdgcn_readlane((int)fah, w);
+				const uint32_t bah_w = (uint32_t)__builtin_amdgcn_readlane((int)bah, w), w0_w = (uint32_t)__builtin_amdgcn_readlane((int)wr[0], w);
+				const bool fb_w = __builtin_amdgcn_readlane((int)d_fb_ok, w) != 0;
+				const bool later = looks && gi > w;
+				const bool writes_it = wr[0] == w0_w || (multi && (wr[1] == w0_w || wr[2] == w0_w || wr[3] == w0_w || wr[4] == w0_w));
+				const bool same_tag = th == th_w;
+				const bool passes = same_tag && passable && fb_w && fah != fah_w && bah != bah_w;
+				const bool conf = later && (same_tag ? !passes : writes_it);
+				if (later && passes)
+					soft_me = true;
+				if (conf && w < first_conf)
+					first_conf = w;
+				const u64 sm = __ballot(later && passes && writes_it);
+				if (lane == w && sm && __ffsll((long long)sm) - 1 < sup_by)
+					sup_by = __ffsll((long long)sm) - 1;
 			}
 		}
 #pragma unroll
@@ -915,19 +913,40 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 		}
 		if (f > wcount)
 			f = wcount;
+#ifdef LRZGPU_DEBUG_DENSE
+		if (DENSE && (batch_mode & 64) && dbg[0] >= 14 && dbg[0] < 19) {
+			if (gi == f || gi + 1 == f)
+				printf("dense round %lld: wcount %d f %d why %d | lane %d P %lld tag %llx live %d ins %d victim %d complex %d pot %d nh %d nw %d w0 %u lo %u hi %u flagged %d fidx %d first_conf %d soft %d fb %d stop %d why %d d_stop %d\n",
+				       (long long)dbg[0], wcount, f, why_f, gi, (long long)w_pos, (unsigned long long)w_tag, (int)live, (int)L.ins, (int)L.victim, (int)L.complex_, (int)L.pot, L.nh, L.nw, wr[0], L.lo, L.hi, (int)flagged, fidx, first_conf, (int)soft_me, (int)d_fb_ok, (int)stop, why, d_stop);
+			if (first_conf != MW_NONE && gi == f) {
+				printf("   suspect record: k %x lo %u hi %u tag %llx w0 %u\n", fl_k[0][fidx], fl_lo[0][fidx], fl_hi[0][fidx], (unsigned long long)fl_tag[fidx], fl_w0[fidx]);
+			}
+			if (gi == first_conf)
+				printf("   conflicting writer lane %d: tag %llx w0 %u evicts %d fb %d\n", gi, (unsigned long long)w_tag, wr[0], (int)evicts, (int)d_fb_ok);
+		}
+#endif
+#ifdef LRZGPU_DEBUG_DENSE
+		if (DENSE && has && w_pos >= 74200 && w_pos <= 74285)
+			printf("R %lld gi %d P %lld f %d live %d alive %d simd %d ins %d nw %d w0 %u lo %u hi %u pot %d nh %d kind %d victim %d soft1 %d twin %d flagged %d first_conf %d soft_me %d stop %d why %d d_stop %d\n",
+			       (long long)dbg[0], gi, (long long)w_pos, f, (int)live, (int)alive, (int)w_simd, (int)L.ins, L.nw, wr[0], L.lo, L.hi, (int)L.pot, L.nh, L.k0, (int)L.victim, (int)L.soft1, (int)L.twin, (int)flagged, first_conf, (int)soft_me, (int)stop, why, d_stop);
+#endif
 		const bool committed = gi < f && live;
 
 		// ---- phase D: apply the committed prefix ----
 		const bool nxt_over = __shfl_down((int)(gi < f && live && L.twin && L.tw_over), 1) != 0 && lane < 63;
 		int n_real = 0; // dense: real matches met by the committed lookups (tag_hits)
 		if (committed) {
-			const bool superseded = DENSE && evicts && sup_by < f; // (a later committed eviction of the same slot stands)
+			const bool superseded = DENSE && soft_w && sup_by < f; // (a later committed store of my tag into the same slot stands)
 			for (int k = 0; k < 4; k++)
 				if (k < L.nw && !(k == 0 && (nxt_over || superseded)))
 					R.store_slot(L.w_slot[k], L.w_t[k], L.w_off[k]);
 			if (cleans)
 				R.store_slot(my_vict, 0, 0);
 			miss_acc += (DENSE && L.pot) ? ev_miss : L.misses;
+#ifdef LRZGPU_DEBUG_DENSE
+			if (DENSE && L.pot && ev_real > 0)
+				printf("H %lld %d D\n", (long long)w_pos, ev_real);
+#endif
 			if (DENSE && L.pot)
 				n_real = ev_real;
 		}
@@ -1001,14 +1020,19 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 					}
 				}
 				const bool used = applied > 0 || __ballot(committed && (L.pot || soft_me)) != 0;
-				dense_idle = used ? 0 : dense_idle + 1;
+				dense_used += used ? 1 : 0;
+				if (++dense_rounds == DENSE_WINDOW) {
+					if (dense_used < DENSE_WINDOW / 8 && !(batch_mode & 32))
+						leave = 5; // seven rounds in eight had no use for this variant: four wavefronts do them faster
+					dense_rounds = dense_used = 0;
+				}
 				if (!prof) {
 					bump(8, applied);
 					bump(9, __popcll(__ballot(committed && soft_me)));
 					bump(10, 1);
 				}
 			}
-			if (f < wcount && why_f >= 3 && why_f <= 7)
+			if (f < wcount && why_f >= 3 && why_f <= 7 && !(DENSE && prof && why_f == 4))
 				bump(why_f, 1);
 			inserts += n_ins;
 			const i64 hc = R.hash_count + n_x;
@@ -1023,8 +1047,9 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 			if (poor) {
 				if (++poor_rounds >= POOR_SCORE) {
 					poor_rounds = POOR_SCORE - 2; // (two more poor rounds after the stretch and the next one follows)
-					if (!DENSE && (batch_mode & 16))
-						leave = 4; // the dense variant takes over from the next candidate on (host: scan_chunk_device)
+					if (!DENSE && (batch_mode & 16) && serial_span > SPAN_MIN)
+						leave = 4; // rounds were still poor after a first stretch of exact steps: the dense variant takes
+							   // over from the next candidate on (host: scan_chunk_device)
 					else {
 						serial_left = serial_span;
 						if (serial_span < SPAN_MAX)
@@ -1040,7 +1065,9 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 		if constexpr (DENSE) {
 			// a kept lane with possible matches has lost its hits (the window's staging area overlays them), one whose
 			// chain a committed eviction has changed reads other offsets now: both are simulated again
-			if (gi >= f && (L.pot || soft_me))
+			// ... and so is one that was dead for this round's analysis only (inside a match the in-order pass emitted at
+			// a lane the round did not get to): nobody checked its reads against the round's writes
+			if (gi >= f && (L.pot || soft_me || !live))
 				w_simd = false;
 		}
 		if (first_clean)

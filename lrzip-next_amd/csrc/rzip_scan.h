@@ -86,6 +86,12 @@ typedef std::function<int(const ScanState &h, int64_t scanned_upto)> ScanProgres
 int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_size, int rzip_level,
 		      int64_t *victim_round, ScanResult *res, hipStream_t s, const ScanProgressFn &progress = nullptr, bool census = false);
 
+// K1 alone: candidates of positions [first, end] under min_mask -> d_out[0] = how many, d_out[1] = checksum over
+// (position, tag); *ms = one pass of the K1 kernels (only_tags: of k_tag_scan alone) over the range, the average of
+// reps - 1 passes after the first
+int tag_candidates_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t first, int64_t end, uint64_t min_mask, int reps,
+			  unsigned long long *d_out, double *ms, hipStream_t s, bool only_tags);
+
 // literal gather: dst[dst_off + k] = src[src_off + k] for each run (device pointers)
 struct CopyRun {
 	int64_t src_off, dst_off, len;

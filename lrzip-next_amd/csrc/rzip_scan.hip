@@ -122,57 +122,99 @@ void hash_index_table(uint64_t out[256])
 // ---------------------------------------------------------------------------------------------
 // K1: tags + candidate compaction
 // ---------------------------------------------------------------------------------------------
+// Round 6.  tag(p) = XOR of hash_index[b] over the 31 bytes from p on (src/rzip.c:385-416) = X(p + 31) ^ X(p) with
+// X(i) = the XOR over all bytes in front of i: ONE table lookup per position, a prefix XOR over the tile (16 positions per
+// thread in registers, the thread totals through a wavefront scan, the wave totals through LDS), and X(p + 31) from the
+// thread one or two places on through a transposed LDS array (lane t reads lane t + 1's or t + 2's column: consecutive
+// lanes, consecutive addresses).  Rounds 1 to 5 rolled every thread's tag by itself: 61 table reads and 61 byte reads per
+// 16 positions, the byte reads 16 bytes apart from lane to lane -- all of them on eight banks.  The tile's bytes come
+// straight from memory, one aligned 16-byte word per thread: the host starts a segment on a multiple of 16 (positions in
+// front of the first candidate that counts are dropped by the resolver's `pos > p_skip` as before).
 __global__ void __launch_bounds__(256) k_tag_scan(const uint8_t *__restrict__ buf, i64 seg_lo, i64 seg_hi,
 						  const u64 *__restrict__ hx_g, const ScanState *__restrict__ st,
 						  uint32_t *__restrict__ cand_rel, u64 *__restrict__ cand_tag,
 						  uint32_t *__restrict__ tile_count)
 {
 	__shared__ u64 hx[256];
-	__shared__ __attribute__((aligned(16))) uint8_t stage[TILE + 64];
+	__shared__ u64 xs[PER_THREAD][256 + 2]; // xs[j][t] = X(16 t + j); columns 256, 257: the 32 positions behind the tile
+	__shared__ u64 wave_x[4];
 	__shared__ uint32_t wave_tot[4];
 
-	const int tid = threadIdx.x;
-	const i64 p0 = seg_lo + (i64)blockIdx.x * TILE;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const i64 p0 = seg_lo + (i64)blockIdx.x * TILE; // (a multiple of 16, like the chunk's base: caller contract)
 	const u64 min_mask = st->min_mask;
 	hx[tid] = hx_g[tid];
-
-	// stage bytes [p0, p0 + need + 30] with aligned 16-byte loads; the chunk base is 16-byte
-	// aligned and its allocation is readable 64 B past the end (caller contract).
 	i64 need = seg_hi - p0;
 	if (need > TILE)
 		need = TILE;
-	const i64 nbytes = need + (MINIMUM_MATCH - 1);
-	const int mis = (int)((uintptr_t)(buf + p0) & 15);
-	{
-		const uint8_t *ga = buf + p0 - mis;
-		for (int off = tid * 16; off < nbytes + mis; off += 256 * 16)
-			*reinterpret_cast<uint4 *>(stage + off) = *reinterpret_cast<const uint4 *>(ga + off);
-	}
-	const uint8_t *bytes = stage + mis;
+	const i64 nbytes = need + (MINIMUM_MATCH - 1); // (the chunk's allocation is readable 64 B past its end)
+	uint4 w = make_uint4(0, 0, 0, 0), h0 = w, h1 = w;
+	if ((i64)tid * 16 < nbytes)
+		w = *reinterpret_cast<const uint4 *>(buf + p0 + tid * 16);
+	if (tid < 2 && TILE < nbytes)
+		h0 = *reinterpret_cast<const uint4 *>(buf + p0 + TILE);
+	if (tid == 1 && TILE + 16 < nbytes)
+		h1 = *reinterpret_cast<const uint4 *>(buf + p0 + TILE + 16);
 	__syncthreads();
 
-	// tags for PER_THREAD consecutive positions
+	auto byte_of = [](const uint4 &q, int j) -> uint32_t {
+		const uint32_t d = j < 4 ? q.x : j < 8 ? q.y : j < 12 ? q.z : q.w;
+		return (d >> (8 * (j & 3))) & 0xFFu;
+	};
+	u64 x[PER_THREAD]; // inclusive prefix XOR over my 16 bytes
+	u64 acc = 0;
+#pragma unroll
+	for (int j = 0; j < PER_THREAD; j++) {
+		acc ^= hx[byte_of(w, j)];
+		x[j] = acc;
+	}
+	u64 inc = acc; // inclusive scan of the thread totals over the wavefront
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const u64 o = ((u64)__shfl_up((uint32_t)(inc >> 32), d) << 32) | __shfl_up((uint32_t)inc, d);
+		if (lane >= d)
+			inc ^= o;
+	}
+	if (lane == 63)
+		wave_x[wv] = inc;
+	__syncthreads();
+	u64 excl = inc ^ acc; // everything in front of my first byte
+	for (int q = 0; q < wv; q++)
+		excl ^= wave_x[q];
+#pragma unroll
+	for (int j = 0; j < PER_THREAD; j++)
+		xs[j][tid] = j ? excl ^ x[j - 1] : excl;
+	if (tid < 2) {
+		u64 a = wave_x[0] ^ wave_x[1] ^ wave_x[2] ^ wave_x[3]; // X(4096)
+		if (tid == 1) {
+#pragma unroll
+			for (int j = 0; j < 16; j++)
+				a ^= hx[byte_of(h0, j)];
+		}
+		const uint4 mine = tid ? h1 : h0;
+#pragma unroll
+		for (int j = 0; j < PER_THREAD; j++) {
+			xs[j][256 + tid] = a;
+			a ^= hx[byte_of(mine, j)];
+		}
+	}
+	__syncthreads();
+
+	// tags of my 16 positions: X(i + 31) ^ X(i), i = 16 tid + k; X(i + 31) sits in column tid + 1 (k = 0) or tid + 2
 	const int l0 = tid * PER_THREAD;
 	u64 tags[PER_THREAD];
 	uint32_t bits = 0;
-	if (l0 < need) {
-		u64 t = 0;
 #pragma unroll
-		for (int i = 0; i < MINIMUM_MATCH; i++)
-			t ^= hx[bytes[l0 + i]];
-#pragma unroll
-		for (int k = 0; k < PER_THREAD; k++) {
-			if (k)
-				t ^= hx[bytes[l0 + k - 1]] ^ hx[bytes[l0 + k + MINIMUM_MATCH - 1]];
-			tags[k] = t;
-			if (l0 + k < need && (t & min_mask) == min_mask)
-				bits |= 1u << k;
-		}
+	for (int k = 0; k < PER_THREAD; k++) {
+		const u64 xi = k ? excl ^ x[k - 1] : excl;
+		const u64 t = xs[(k + 15) & 15][tid + 1 + ((k + 15) >> 4)] ^ xi;
+		tags[k] = t;
+		if (l0 + k < need && (t & min_mask) == min_mask)
+			bits |= 1u << k;
 	}
 	// workgroup exclusive scan of popcounts
 	uint32_t cnt = __popc(bits);
 	uint32_t incl = cnt;
-	const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
 	for (int d = 1; d < 64; d <<= 1) {
 		uint32_t o = __shfl_up(incl, d);
@@ -183,8 +225,8 @@ __global__ void __launch_bounds__(256) k_tag_scan(const uint8_t *__restrict__ bu
 		wave_tot[wv] = incl;
 	__syncthreads();
 	uint32_t base = 0;
-	for (int w = 0; w < wv; w++)
-		base += wave_tot[w];
+	for (int q = 0; q < wv; q++)
+		base += wave_tot[q];
 	uint32_t pos = base + incl - cnt;
 	const size_t out0 = (size_t)blockIdx.x * TILE;
 #pragma unroll
@@ -592,6 +634,9 @@ struct Resolver {
 		i64 best = 0;
 		u64 h = t & hmask;
 		*reverse = 0;
+#ifdef LRZGPU_DEBUG_DENSE
+		const i64 dbg_hits0 = tag_hits;
+#endif
 		for (;;) {
 			Slot s = tbl[(h + lane) & hmask];
 			bool empty = !(s.offset | (i64)s.t);
@@ -631,6 +676,10 @@ struct Resolver {
 				break;
 			h = (h + 64) & hmask;
 		}
+#ifdef LRZGPU_DEBUG_DENSE
+		if (lane == 0 && tag_hits - dbg_hits0 > 0)
+			printf("H %lld %lld S\n", (long long)p, (long long)(tag_hits - dbg_hits0));
+#endif
 		return best;
 	}
 
@@ -855,6 +904,8 @@ struct LaneSim {
 	// the dense variant (k_resolve_mw<1, ..., true>): the lookup's tag hits stay in LDS with their measured extents
 	int nh;   // how many (<= MAXH)
 	bool pot; // some hit may be a match (forward + backward extent >= MINIMUM_MATCH before last_match clips the latter)
+	bool soft1; // my insert replaces an entry of MY OWN tag that was due for cleaning (kind 1): like a round-robin eviction it
+	            // leaves the slot's rank byte, fingerprint byte and tag word as they are
 };
 
 // is there a match of at least MINIMUM_MATCH bytes between p0 and op? (single_match_len() != 0)
@@ -942,6 +993,129 @@ back_done:;
 	return (uint32_t)fwd | (uint32_t)back << 16 | ((back == capb && capb < max_back) ? 0x80000000u : 0u);
 }
 
+// Equal leading bytes of two 16-byte pieces; equal trailing bytes (the piece's last byte is the one next to the position).
+__device__ __forceinline__ int lead16(const U128u &a, const U128u &b)
+{
+	const u64 x0 = a.a ^ b.a, x1 = a.b ^ b.b;
+	return x0 ? (__ffsll((long long)x0) - 1) >> 3 : x1 ? 8 + ((__ffsll((long long)x1) - 1) >> 3) : 16;
+}
+__device__ __forceinline__ int trail16(const U128u &a, const U128u &b)
+{
+	const u64 x0 = a.a ^ b.a, x1 = a.b ^ b.b;
+	return x1 ? __clzll((long long)x1) >> 3 : x0 ? 8 + (__clzll((long long)x0) >> 3) : 16;
+}
+
+// measure_hit for all n hits of a lane, with the loads of four hits in flight together: 32 bytes each way first (a hit
+// that ends within them both ways is measured; one that ends within 15 both ways is a certain miss), the next 32 for
+// the directions still open, the byte-wise measure_hit beyond 64 (rare) and near the chunk's ends.  One lane's hits were
+// measured one after the other until round 6: two dependent trips to memory per hit, sixteen hits per candidate on the
+// inputs this variant is for.
+__device__ __forceinline__ void measure_hits(const uint8_t *buf, const i64 P, const i64 end, const int n, const int lane, const i64 *hit_lds,
+					     uint32_t *hit_fr, bool &pot, bool &unmeasured)
+{
+	auto note = [&](int k, uint32_t fr) {
+		hit_fr[k * 64 + lane] = fr;
+		if (fr == HIT_UNMEASURED)
+			unmeasured = true;
+		else if ((fr & 0xFFFFu) + ((fr >> 16) & 0x7FFFu) >= (uint32_t)MINIMUM_MATCH)
+			pot = true;
+	};
+	auto slow = [&](int k, i64 op) { note(k, quick_reject(buf, P, op, end, 0) ? 0u : measure_hit(buf, P, op, end)); };
+	if (P < 64 || end - P < 64) {
+		for (int k = 0; k < n; k++)
+			slow(k, hit_lds[k * 64 + lane]);
+		return;
+	}
+	U128u pf[4], pb[4]; // the candidate's own 64 bytes each way
+#pragma unroll
+	for (int c = 0; c < 4; c++) {
+		pf[c] = *reinterpret_cast<const U128u *>(buf + P + 16 * c);
+		pb[c] = *reinterpret_cast<const U128u *>(buf + P - 16 - 16 * c);
+	}
+	u64 open = 0; // hits with a direction that ran through its first 32 bytes
+	for (int k0 = 0; k0 < n; k0 += 4) {
+		i64 op[4];
+		U128u f[4][2], b[4][2];
+		bool fast[4];
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			op[j] = k0 + j < n ? hit_lds[(k0 + j) * 64 + lane] : P;
+			fast[j] = op[j] >= 64 && op[j] < P;
+			if (fast[j]) {
+#pragma unroll
+				for (int c = 0; c < 2; c++) {
+					f[j][c] = *reinterpret_cast<const U128u *>(buf + op[j] + 16 * c);
+					b[j][c] = *reinterpret_cast<const U128u *>(buf + op[j] - 16 - 16 * c);
+				}
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			if (k0 + j >= n)
+				continue;
+			if (op[j] >= P)
+				note(k0 + j, 0);
+			else if (!fast[j])
+				slow(k0 + j, op[j]);
+			else {
+				int fw = lead16(pf[0], f[j][0]), bk = trail16(pb[0], b[j][0]);
+				if (fw == 16)
+					fw += lead16(pf[1], f[j][1]);
+				if (bk == 16)
+					bk += trail16(pb[1], b[j][1]);
+				if (fw == 32 || bk == 32) {
+					open |= 1ull << (k0 + j);
+					hit_fr[(k0 + j) * 64 + lane] = (uint32_t)fw | (uint32_t)bk << 16; // (so far)
+				} else
+					note(k0 + j, (uint32_t)fw | (uint32_t)bk << 16);
+			}
+		}
+	}
+	while (open) {
+		int kk[4];
+		i64 op[4];
+		int fw[4], bk[4];
+		U128u f[4][2], b[4][2];
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			kk[j] = open ? __ffsll((long long)open) - 1 : -1;
+			if (kk[j] >= 0) {
+				open &= open - 1;
+				op[j] = hit_lds[kk[j] * 64 + lane];
+				const uint32_t fr = hit_fr[kk[j] * 64 + lane];
+				fw[j] = (int)(fr & 0xFFFFu);
+				bk[j] = (int)(fr >> 16);
+#pragma unroll
+				for (int c = 0; c < 2; c++) {
+					if (fw[j] == 32)
+						f[j][c] = *reinterpret_cast<const U128u *>(buf + op[j] + 32 + 16 * c);
+					if (bk[j] == 32)
+						b[j][c] = *reinterpret_cast<const U128u *>(buf + op[j] - 48 - 16 * c);
+				}
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			if (kk[j] < 0)
+				continue;
+			if (fw[j] == 32) {
+				fw[j] += lead16(pf[2], f[j][0]);
+				if (fw[j] == 48)
+					fw[j] += lead16(pf[3], f[j][1]);
+			}
+			if (bk[j] == 32) {
+				bk[j] += trail16(pb[2], b[j][0]);
+				if (bk[j] == 48)
+					bk[j] += trail16(pb[3], b[j][1]);
+			}
+			if (fw[j] == 64 || bk[j] == 64)
+				note(kk[j], measure_hit(buf, P, op[j], end)); // longer than 64 one way: byte-wise from the start
+			else
+				note(kk[j], (uint32_t)fw[j] | (uint32_t)bk[j] << 16);
+		}
+	}
+}
+
 // Phase A/B of a resolver round, for the lanes with need_sim: one automaton step each, simulated
 // against the table as it stands.  Wave-convergent, so that every dependent HBM round trip is shared
 // by all simulating lanes: (A1) lookup walk in 64-slot steps over the side arrays, (A2) verification of
@@ -952,7 +1126,7 @@ template <int MAXH, int MAXE, bool DENSE, class LapF>
 __device__ __forceinline__ void simulate_lanes(const Resolver &R, const Slot *__restrict__ tbl, const uint8_t *__restrict__ buf, const i64 tbl_size,
 					       const u64 better, const int lane, const bool alive, const bool need_sim, const u64 w_tag,
 					       const i64 w_pos, const int w_ticket, i64 *hit_lds, uint32_t *eqs_lds, const int eqs_stride, LaneSim &L, LapF lap,
-					       uint32_t *hit_fr = nullptr)
+					       uint32_t *hit_fr = nullptr, u64 *q_cache = nullptr)
 {
 		const u64 T = w_tag;
 		const i64 P = w_pos;
@@ -996,6 +1170,7 @@ __device__ __forceinline__ void simulate_lanes(const Resolver &R, const Slot *__
 				if (L.complex_)
 					fin = true;
 				L.tw_over = false;
+				L.soft1 = false;
 				tw = tw && L.ins && !L.complex_;
 				seek_pred = tw;
 			}
@@ -1051,13 +1226,44 @@ __device__ __forceinline__ void simulate_lanes(const Resolver &R, const Slot *__
 							}
 							if (Qp) {
 								q2 = __ffsll((long long)Qp) - 1;
+								Qp &= Qp - 1;
 								const Slot c = tbl[idx + q2];
 								c2t = c.t;
 								c2o = c.offset;
 							}
+							if constexpr (DENSE) {
+								// full chains (sixteen equal tags in a row at level 7): the next sixteen fingerprint matches
+								// of the step are fetched together as well -- unconditional loads, so that they are all on
+								// their way before the first is waited for -- and parked in LDS (q_cache[2 j], [2 j + 1])
+								if (__ballot(Qp != 0)) {
+									Slot c[16];
+									int ql = q2 < 0 ? 0 : q2;
+#pragma unroll
+									for (int j = 0; j < 16; j++) {
+										if (Qp) {
+											ql = __ffsll((long long)Qp) - 1;
+											Qp &= Qp - 1;
+										}
+										c[j] = tbl[idx + ql];
+									}
+#pragma unroll
+									for (int j = 0; j < 16; j++) {
+										q_cache[(2 * j) * 64 + lane] = c[j].t;
+										q_cache[(2 * j + 1) * 64 + lane] = (u64)c[j].offset;
+									}
+								}
+							}
 						}
-						auto tag_at = [&](int q) -> u64 { return q == q0 ? c0t : q == q1 ? c1t : q == q2 ? c2t : tbl[idx + q].t; };
-						auto off_at = [&](int q) -> i64 { return q == q0 ? c0o : q == q1 ? c1o : q == q2 ? c2o : tbl[idx + q].offset; };
+						auto slot_at = [&](int q, int word) -> u64 {
+							if constexpr (DENSE) {
+								const int ord = __popcll(Q & low_mask(q)) - 3; // (the first three are in registers)
+								if (ord < 16)
+									return q_cache[(2 * ord + word) * 64 + lane];
+							}
+							return word ? (u64)tbl[idx + q].offset : tbl[idx + q].t;
+						};
+						auto tag_at = [&](int q) -> u64 { return q == q0 ? c0t : q == q1 ? c1t : q == q2 ? c2t : slot_at(q, 0); };
+						auto off_at = [&](int q) -> i64 { return q == q0 ? c0o : q == q1 ? c1o : q == q2 ? c2o : (i64)slot_at(q, 1); };
 						u64 Em = E;
 						if (kind < 0 && L.ins) {
 							int from = 0;
@@ -1095,6 +1301,8 @@ __device__ __forceinline__ void simulate_lanes(const Resolver &R, const Slot *__
 								if (!seek_pred) {
 									kind = k1;
 									sidx = idx + s1; // a lesser-bitness occupant (kind 2) is fetched after the walk
+									if (DENSE && k1 == 1 && ((Q >> s1) & 1) && tag_at(s1) == T)
+										L.soft1 = true;
 									break; // (a twin that displaces in its turn: A3 checks its walks against tw_slot)
 								}
 								seek_pred = false;
@@ -1102,6 +1310,8 @@ __device__ __forceinline__ void simulate_lanes(const Resolver &R, const Slot *__
 									tw = false; // the predecessor may replace its own tag: conflict path
 									kind = k1;
 									sidx = idx + s1;
+									if (DENSE && tag_at(s1) == T)
+										L.soft1 = true;
 									break;
 								}
 								L.tw_slot = (uint32_t)(idx + s1);
@@ -1166,18 +1376,10 @@ __device__ __forceinline__ void simulate_lanes(const Resolver &R, const Slot *__
 			}
 			if (need_sim && !L.complex_) {
 				const int n = nhit < MAXH ? nhit : MAXH;
-				bool pot = false;
-				for (int k = 0; k < n; k++) {
-					const i64 op = hit_lds[k * 64 + lane];
-					uint32_t fr = 0;
-					if (!quick_reject(buf, P, op, R.end, 0))
-						fr = measure_hit(buf, P, op, R.end);
-					hit_fr[k * 64 + lane] = fr;
-					if (fr == HIT_UNMEASURED)
-						L.complex_ = true;
-					else if ((fr & 0xFFFFu) + ((fr >> 16) & 0x7FFFu) >= (uint32_t)MINIMUM_MATCH)
-						pot = true;
-				}
+				bool pot = false, unmeasured = false;
+				measure_hits(buf, P, R.end, n, lane, hit_lds, hit_fr, pot, unmeasured);
+				if (unmeasured)
+					L.complex_ = true;
 				L.nh = n;
 				L.pot = pot;
 				L.match = pot;
@@ -1592,6 +1794,72 @@ int crc32_device(ScanWorkspace *w, const uint8_t *d_buf, int64_t n, uint32_t *cr
 	return 0;
 }
 
+// K1 on its own (lrzgpu_tag_candidates_dev: parity of the tags against the scan access hooks, and the kernel's rate
+// alone on the GPU): count and an order-independent checksum of the (position, tag) pairs of the per-tile lists.
+__global__ void __launch_bounds__(256) k_cand_checksum(const uint32_t *__restrict__ cand_rel, const u64 *__restrict__ cand_tag,
+						       const uint32_t *__restrict__ tile_count, i64 seg_lo, i64 first, unsigned long long *__restrict__ out)
+{
+	const uint32_t cnt = tile_count[blockIdx.x];
+	const size_t in0 = (size_t)blockIdx.x * TILE;
+	u64 sum = 0, n = 0;
+	for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
+		const i64 pos = seg_lo + (i64)cand_rel[in0 + i];
+		if (pos >= first) {
+			sum += ((u64)pos + 1) * 0x9E3779B97F4A7C15ull ^ cand_tag[in0 + i] * 0xC2B2AE3D27D4EB4Full;
+			n++;
+		}
+	}
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) {
+		sum += bcast64(sum, (threadIdx.x & 63) ^ d);
+		n += bcast64(n, (threadIdx.x & 63) ^ d);
+	}
+	if ((threadIdx.x & 63) == 0 && n) {
+		atomicAdd(&out[0], (unsigned long long)n);
+		atomicAdd(&out[1], (unsigned long long)sum);
+	}
+}
+
+// The candidates of positions [first, end] of a chunk under `min_mask`, segment by segment like the scan; the K1 trio is
+// run `reps` times (events around all of it).  d_out: two 64-bit words, zeroed here.
+int tag_candidates_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t first, int64_t end, uint64_t min_mask, int reps,
+			  unsigned long long *d_out, double *ms, hipStream_t s, bool only_tags)
+{
+	ScanState h;
+	memset(&h, 0, sizeof(h));
+	h.min_mask = h.tag_mask = min_mask;
+	HIPCHK(hipMemcpyAsync(w->state, &h, sizeof(h), hipMemcpyHostToDevice, s));
+	double total_ms = 0;
+	for (int r = 0; r < (reps < 1 ? 1 : reps); r++) {
+		HIPCHK(hipMemsetAsync(d_out, 0, 16, s));
+		EventTimer t(s);
+		for (int64_t lo = first & ~(int64_t)15; lo <= end;) {
+			int64_t hi = lo + (int64_t)w->seg_cap - TILE;
+			if (hi > end + 1)
+				hi = end + 1;
+			const int ntiles = (int)((hi - lo + TILE - 1) / TILE);
+			hipLaunchKernelGGL(k_tag_scan, dim3(ntiles), dim3(256), 0, s, d_chunk, (i64)lo, (i64)hi, (const u64 *)w->hx, (const ScanState *)w->state,
+					   w->cand_rel, (u64 *)w->cand_tag, w->tile_count);
+			if (r == 0 || !only_tags) {
+				hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, s, (const uint32_t *)w->tile_count, ntiles, w->tile_base);
+				hipLaunchKernelGGL(k_compact_cands, dim3(ntiles), dim3(256), 0, s, (const uint32_t *)w->cand_rel, (const u64 *)w->cand_tag,
+						   (const uint32_t *)w->tile_count, (const uint32_t *)w->tile_base, (uint32_t)w->comp_cap, w->comp_rel, (u64 *)w->comp_tag);
+			}
+			if (r == 0)
+				hipLaunchKernelGGL(k_cand_checksum, dim3(ntiles), dim3(256), 0, s, (const uint32_t *)w->cand_rel, (const u64 *)w->cand_tag,
+						   (const uint32_t *)w->tile_count, (i64)lo, (i64)first, d_out);
+			lo = hi;
+		}
+		t.stop();
+		HIPCHK(stream_wait(s));
+		if (r > 0 || reps <= 1)
+			total_ms += t.ms();
+	}
+	if (ms)
+		*ms = total_ms / (reps > 1 ? reps - 1 : 1); // (the first pass also runs the checksum: not timed when there are more)
+	return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------------
@@ -1705,6 +1973,10 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 			batch_mode |= 32;
 			dense = true;
 		}
+#ifdef LRZGPU_DEBUG_DENSE
+		if (getenv("LRZGPU_DEBUG_DENSE"))
+			batch_mode |= 64;
+#endif
 	}
 	const auto wall0 = std::chrono::steady_clock::now();
 	const int64_t end = h.end;
@@ -1745,7 +2017,7 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 		}
 	}
 	while (p_skip + 1 <= end) {
-		const int64_t seg_lo = p_skip + 1;
+		const int64_t seg_lo = (p_skip + 1) & ~(int64_t)15; // (k_tag_scan reads aligned 16-byte words; the resolver drops pos <= p_skip)
 		// size the segment for ~2M candidates under the current mask
 		int mbits = __builtin_popcountll(min_mask);
 		int64_t seg = (int64_t)(2 << 20) << (mbits > 9 ? 9 : mbits);
