@@ -283,6 +283,20 @@ def hash_search(data: bytes, level=7, chunk_bytes=None, victim_round=0, device=0
     return stream0, s1.raw[:s1len.value], st, crc.value, vr.value
 
 
+def tag_candidates_dev(ptr: int, n: int, first=0, min_mask=1, reps=1, only_tags=False, device=0):
+    """K1 of the scan alone over a chunk in HBM -> (count, checksum, ms per pass): lrzgpu_tag_candidates_dev."""
+    cnt = C.c_int64()
+    chk = C.c_uint64()
+    ms = C.c_double()
+    f = lib().lrzgpu_tag_candidates_dev
+    f.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_uint64),
+                  C.POINTER(C.c_double), C.c_int, C.c_int]
+    rc = f(C.c_void_p(ptr), n, first, min_mask, reps, C.byref(cnt), C.byref(chk), C.byref(ms), 1 if only_tags else 0, device)
+    if rc != 0:
+        raise RuntimeError("lrzgpu_tag_candidates_dev rc=%d" % rc)
+    return cnt.value, chk.value, ms.value
+
+
 def lzma_match_lists(data: bytes, dict_size=1 << 25, fb=64, cut=48, device=0, per_pos=16):
     import numpy as np
     n = len(data)

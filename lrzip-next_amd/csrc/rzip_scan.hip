@@ -1830,8 +1830,8 @@ int tag_candidates_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t firs
 	h.min_mask = h.tag_mask = min_mask;
 	HIPCHK(hipMemcpyAsync(w->state, &h, sizeof(h), hipMemcpyHostToDevice, s));
 	double total_ms = 0;
+	HIPCHK(hipMemsetAsync(d_out, 0, 16, s));
 	for (int r = 0; r < (reps < 1 ? 1 : reps); r++) {
-		HIPCHK(hipMemsetAsync(d_out, 0, 16, s));
 		EventTimer t(s);
 		for (int64_t lo = first & ~(int64_t)15; lo <= end;) {
 			int64_t hi = lo + (int64_t)w->seg_cap - TILE;
@@ -1967,8 +1967,8 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 	bool dense = false;
 	{
 		const char *e = getenv("LRZGPU_RESOLVE_DENSE");
-		if (!e || strcmp(e, "0"))
-			batch_mode |= 16;
+		if ((!e || strcmp(e, "0")) && chain <= (unsigned)MAX_EQS)
+			batch_mode |= 16; // (level 9's chains of 128 equal tags are beyond what a lane of the variant holds: exact stretches there)
 		if (e && !strcmp(e, "always")) {
 			batch_mode |= 32;
 			dense = true;

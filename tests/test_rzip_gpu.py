@@ -51,8 +51,8 @@ def test_rounds_and_exact_stretches_are_one_automaton(B, O, kind, verdict, dense
     if dense == "1" and verdict == "never":
         pytest.skip("rounds only: the hand-over is never asked for, same run as with 0")
     degenerate = kind in ("few", "phrases")
-    n = ((256 << 10) if verdict == "never" else (1 << 20)) + 99 if degenerate else 3 * 1048576 + 777
-    for level in ((7, 9) if degenerate else (7,)):
+    n = ((96 << 10) if verdict == "never" else (1 << 20)) + 99 if degenerate else 3 * 1048576 + 777
+    for level in ((7, 9) if degenerate and verdict == "always" else (7,)):
         _check(B, O, datagen.KINDS[kind](n, seed=9 + level), level=level)
 
 
@@ -97,6 +97,49 @@ def test_degenerate_inputs_hand_over_to_the_dense_resolver(B, O, kind):
     else:
         data = datagen.KINDS[kind](n, seed=9)
     _check(B, O, data, level=7)
+
+
+@pytest.mark.parametrize("kind,n", [("text", 5 * 1048576 + 12345), ("random", 3 * 1048576 + 31), ("few", 1048576 + 7), ("zeros", 70000),
+                                    ("text", 4096 + 30), ("text", 4096 + 31), ("text", 31), ("text", 30), ("text", 0)])
+def test_tag_candidates_equal_the_access_hooks(B, kind, n):
+    """k_tag_scan on its own (lrzgpu_tag_candidates_dev): the positions whose 31-byte XOR tag (src/rzip.c:385-416) passes
+    the mask, counted and checksummed on the device, against the tags recomputed here from hash_index[] -- a prefix XOR
+    in numpy, tied to lrzgpu_full_tag / lrzgpu_next_tag (the scan access hooks) at sampled positions.
+    Several masks, ragged starts (the kernel reads aligned 16-byte words; a segment may begin anywhere), tile edges."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    data = datagen.KINDS[kind](n, seed=23)
+    L = B.lib()
+    hx = (C.c_uint64 * 256)()
+    L.lrzgpu_hash_index(hx)
+    hx = np.frombuffer(hx, dtype=np.uint64).copy()
+    a = np.frombuffer(data, dtype=np.uint8)
+    buf = torch.zeros(n + 256, dtype=torch.uint8, device="cuda")
+    buf[:n] = torch.from_numpy(a.copy()).cuda()
+    npos = max(0, n - 30)
+    if npos:
+        X = np.concatenate([[np.uint64(0)], np.bitwise_xor.accumulate(hx[a])])
+        tags = X[31:31 + npos] ^ X[:npos]
+        L.lrzgpu_full_tag.restype = C.c_uint64
+        L.lrzgpu_full_tag.argtypes = [C.c_char_p, C.c_int64]
+        L.lrzgpu_next_tag.restype = C.c_uint64
+        L.lrzgpu_next_tag.argtypes = [C.c_char_p, C.c_int64, C.c_uint64]
+        for p in sorted({0, min(1, npos - 1), npos // 3, npos - 1}):
+            assert int(tags[p]) == L.lrzgpu_full_tag(data, p)
+            if p:
+                assert int(tags[p]) == L.lrzgpu_next_tag(data, p, int(tags[p - 1]))
+    else:
+        tags = np.zeros(0, dtype=np.uint64)
+    pos = np.arange(npos, dtype=np.uint64)
+    for mask in (1, 3, 0xF, 0x1FF):
+        for first in (0, 1, 15, 16, 4097):
+            sel = ((tags & np.uint64(mask)) == np.uint64(mask)) & (pos >= np.uint64(first))
+            want_n = int(sel.sum())
+            with np.errstate(over="ignore"):
+                want = int((((pos[sel] + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)) ^ (tags[sel] * np.uint64(0xC2B2AE3D27D4EB4F))).sum(dtype=np.uint64)) if want_n else 0
+            got_n, got, _ = B.tag_candidates_dev(buf.data_ptr(), n, first=first, min_mask=mask)
+            assert (got_n, got) == (want_n, want), (mask, first)
 
 
 def test_table_fill_and_clean_sweeps(B, O):
