@@ -913,23 +913,6 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 		}
 		if (f > wcount)
 			f = wcount;
-#ifdef LRZGPU_DEBUG_DENSE
-		if (DENSE && (batch_mode & 64) && dbg[0] >= 14 && dbg[0] < 19) {
-			if (gi == f || gi + 1 == f)
-				printf("dense round %lld: wcount %d f %d why %d | lane %d P %lld tag %llx live %d ins %d victim %d complex %d pot %d nh %d nw %d w0 %u lo %u hi %u flagged %d fidx %d first_conf %d soft %d fb %d stop %d why %d d_stop %d\n",
-				       (long long)dbg[0], wcount, f, why_f, gi, (long long)w_pos, (unsigned long long)w_tag, (int)live, (int)L.ins, (int)L.victim, (int)L.complex_, (int)L.pot, L.nh, L.nw, wr[0], L.lo, L.hi, (int)flagged, fidx, first_conf, (int)soft_me, (int)d_fb_ok, (int)stop, why, d_stop);
-			if (first_conf != MW_NONE && gi == f) {
-				printf("   suspect record: k %x lo %u hi %u tag %llx w0 %u\n", fl_k[0][fidx], fl_lo[0][fidx], fl_hi[0][fidx], (unsigned long long)fl_tag[fidx], fl_w0[fidx]);
-			}
-			if (gi == first_conf)
-				printf("   conflicting writer lane %d: tag %llx w0 %u evicts %d fb %d\n", gi, (unsigned long long)w_tag, wr[0], (int)evicts, (int)d_fb_ok);
-		}
-#endif
-#ifdef LRZGPU_DEBUG_DENSE
-		if (DENSE && has && w_pos >= 74200 && w_pos <= 74285)
-			printf("R %lld gi %d P %lld f %d live %d alive %d simd %d ins %d nw %d w0 %u lo %u hi %u pot %d nh %d kind %d victim %d soft1 %d twin %d flagged %d first_conf %d soft_me %d stop %d why %d d_stop %d\n",
-			       (long long)dbg[0], gi, (long long)w_pos, f, (int)live, (int)alive, (int)w_simd, (int)L.ins, L.nw, wr[0], L.lo, L.hi, (int)L.pot, L.nh, L.k0, (int)L.victim, (int)L.soft1, (int)L.twin, (int)flagged, first_conf, (int)soft_me, (int)stop, why, d_stop);
-#endif
 		const bool committed = gi < f && live;
 
 		// ---- phase D: apply the committed prefix ----
@@ -943,10 +926,6 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 			if (cleans)
 				R.store_slot(my_vict, 0, 0);
 			miss_acc += (DENSE && L.pot) ? ev_miss : L.misses;
-#ifdef LRZGPU_DEBUG_DENSE
-			if (DENSE && L.pot && ev_real > 0)
-				printf("H %lld %d D\n", (long long)w_pos, ev_real);
-#endif
 			if (DENSE && L.pot)
 				n_real = ev_real;
 		}

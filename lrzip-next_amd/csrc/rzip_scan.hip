@@ -634,9 +634,6 @@ struct Resolver {
 		i64 best = 0;
 		u64 h = t & hmask;
 		*reverse = 0;
-#ifdef LRZGPU_DEBUG_DENSE
-		const i64 dbg_hits0 = tag_hits;
-#endif
 		for (;;) {
 			Slot s = tbl[(h + lane) & hmask];
 			bool empty = !(s.offset | (i64)s.t);
@@ -676,10 +673,6 @@ struct Resolver {
 				break;
 			h = (h + 64) & hmask;
 		}
-#ifdef LRZGPU_DEBUG_DENSE
-		if (lane == 0 && tag_hits - dbg_hits0 > 0)
-			printf("H %lld %lld S\n", (long long)p, (long long)(tag_hits - dbg_hits0));
-#endif
 		return best;
 	}
 
@@ -1973,10 +1966,6 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 			batch_mode |= 32;
 			dense = true;
 		}
-#ifdef LRZGPU_DEBUG_DENSE
-		if (getenv("LRZGPU_DEBUG_DENSE"))
-			batch_mode |= 64;
-#endif
 	}
 	const auto wall0 = std::chrono::steady_clock::now();
 	const int64_t end = h.end;

@@ -185,7 +185,7 @@ def test_file_whose_scan_outruns_the_hash(B, tmp_path):
     tests/test_compress_gpu.py pins to the oracle's."""
     n = 7 * 104857600 + 4321  # (two scanners: the readers may be three chunks ahead of the committer + two held for the hash)
     data = bytes(n)
-    kw = dict(level=7, threads=4, processors=8, ramsize=RAM, window=1, host_threads=8, scan_slots=2)
+    kw = dict(level=7, threads=4, processors=8, ramsize=RAM, window=1, host_threads=8, scan_slots=2, no_compress=True)  # (-n: nothing but the scan)
     want, _ = B.compress_buffer(data, **kw)
     src = tmp_path / "zeros.bin"
     src.write_bytes(data)

@@ -97,7 +97,7 @@ def test_early_release_rollback(B, O, monkeypatch):
     # the copy starts d bytes before the boundary; a roll-back needs those d positions to hold no candidate
     # (tag mask 1: one position in two is one), so small d and a few seeds
     for trial, d in enumerate((1, 2, 1, 3, 2, 1, 2, 3)):
-        filler = datagen.random_bytes((4 << 20) + 1 - d - len(a), seed=60 + trial)
+        filler = datagen.random_bytes((4 << 20) - d - len(a), seed=60 + trial)  # (segments start on multiples of 16 since round 6)
         data = a + filler + a[:1 << 20] + datagen.random_bytes(2 << 20, seed=70 + trial)
         L.lrzgpu_profile_reset()
         _both(B, O, data, level=7, threads=2, processors=8)
@@ -107,11 +107,11 @@ def test_early_release_rollback(B, O, monkeypatch):
     assert rollbacks >= 1  # at least one of the offsets puts the first candidate behind the boundary
 
     # the same after literal blocks have already gone to the back end: they are cancelled and redone
-    monkeypatch.setenv("LRZGPU_SEG_BYTES", str(4 << 20))  # segment boundaries at 1 + k * 4 MiB
+    monkeypatch.setenv("LRZGPU_SEG_BYTES", str(4 << 20))  # segment boundaries at k * 4 MiB
     base = datagen.random_bytes(4 << 20, seed=81)
     parts, pos = [base], len(base)
     for k in range(14, 18):  # copies of base[0:64 KiB] starting 1 or 2 bytes before the boundaries 56 .. 68 MiB
-        start = k * (4 << 20) + 1 - (1 + k % 2)
+        start = k * (4 << 20) - (1 + k % 2)
         parts.append(datagen.random_bytes(start - pos, seed=100 + k))
         parts.append(base[:65536])
         pos = start + 65536

@@ -118,7 +118,7 @@ def test_rollback_of_blocks_started_early(B, O, forced):
     base = datagen.random_bytes(4 << 20, seed=81)
     parts, pos = [base], len(base)
     for k in range(14, 18):
-        start = k * (4 << 20) + 1 - (1 + k % 2)
+        start = k * (4 << 20) - (1 + k % 2)
         parts.append(datagen.text_like(start - pos, seed=100 + k))
         parts.append(base[:65536])
         pos = start + 65536
