@@ -308,13 +308,6 @@ int lrzgpu_lz4_compress_default_size(const uint8_t *src, int src_size, int dst_c
  * stop_below" is certain (what is left costs at most rest + rest/255 + 16 bytes) -- an upper bound of
  * the size that is itself below stop_below. */
 int lrzgpu_lz4_size_stop_below(const uint8_t *src, int src_size, int dst_capacity, int stop_below, int device);
-/* The same answers with the first 4 MiB of a block of 16 MiB or more parsed by sixteen wavefronts at once, each checked
- * against its predecessor's state (what the pipeline's gate does; csrc/lz4_gate.hip): with stop_below = 0 the exact size,
- * with stop_below > 0 SOME bound below stop_below when "compressible" is certain (the verdict is the same as
- * lrzgpu_lz4_size_stop_below's, the bound may be another).  *valid_segs = how many of the sixteen segments held;
- * seg_bytes / warm_bytes = 0: the pipeline's 256 KiB / 128 KiB (tests shrink them until segments fail). */
-int lrzgpu_lz4_size_speculative(const uint8_t *src, int src_size, int dst_capacity, int stop_below, unsigned seg_bytes,
-				unsigned warm_bytes, int *valid_segs, int device);
 
 /* ---- LZMA backend -----------------------------------------------------------------------------
  * LzmaCompress() -- src/lzma/include/LzmaLib.h:95-112, same arguments and SRes codes

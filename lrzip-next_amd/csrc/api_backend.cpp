@@ -181,36 +181,6 @@ static int lz4_size_host(const uint8_t *src, int src_size, int dst_capacity, int
 	return lz4_size_dev(tb.block.p, src_size, dst_capacity, stop_below);
 }
 
-// The same size (stop_below = 0) or early verdict with the first part of the block parsed by sixteen wavefronts at once
-// and checked (lz4_gate.hip, what the pipeline's gate launches do for blocks of 16 MiB or more); *valid_segs = how many of
-// the sixteen speculative segments held.  seg_bytes / warm_bytes: 0 = the pipeline's (256 KiB after 128 KiB of warm-up).
-extern "C" int lrzgpu_lz4_size_speculative(const uint8_t *src, int src_size, int dst_capacity, int stop_below, unsigned seg_bytes,
-					   unsigned warm_bytes, int *valid_segs, int device)
-{
-	int rc = select_device(device);
-	if (rc)
-		return rc;
-	if (src_size < 0 || (!src && src_size))
-		return LRZGPU_E_PARAM;
-	ThreadBuffers &tb = thread_buffers();
-	if (!tb.ensure(device, (size_t)src_size + 64))
-		return LRZGPU_E_NOMEM;
-	DevBuf scratch;
-	if (!scratch.alloc(lz4_spec_bytes(1) + 64, device))
-		return LRZGPU_E_NOMEM;
-	Lz4Job job{tb.block.p, src_size, dst_capacity, stop_below > 0 ? stop_below : 0}, *d_job = (Lz4Job *)tb.small.p;
-	int *d_res = (int *)(tb.small.p + 64), *d_valid = (int *)(scratch.p + lz4_spec_bytes(1)), res[1] = {-1}, valid = 0;
-	if ((src_size && hipMemcpyAsync(tb.block.p, src, (size_t)src_size, hipMemcpyHostToDevice, tb.s) != hipSuccess) ||
-	    hipMemcpyAsync(d_job, &job, sizeof(job), hipMemcpyHostToDevice, tb.s) != hipSuccess ||
-	    lz4_sizes_device(d_job, 1, d_res, tb.s, scratch.p, d_valid, seg_bytes, warm_bytes) != 0 ||
-	    hipMemcpyAsync(res, d_res, sizeof(int), hipMemcpyDeviceToHost, tb.s) != hipSuccess ||
-	    hipMemcpyAsync(&valid, d_valid, sizeof(int), hipMemcpyDeviceToHost, tb.s) != hipSuccess || stream_wait(tb.s) != hipSuccess)
-		return LRZGPU_E_HIP;
-	if (valid_segs)
-		*valid_segs = valid;
-	return res[0];
-}
-
 // ---- LZMA: src/lzma/include/LzmaLib.h:95-112 --------------------------------------------------
 
 static int64_t match_lists_impl(const uint8_t *src, size_t n, uint32_t dictSize, unsigned fb, unsigned cutValue,

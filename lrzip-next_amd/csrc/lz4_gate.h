@@ -17,13 +17,7 @@ struct Lz4Job {
 };
 
 // results[j] = liblz4 1.9.3 LZ4_compress_default(src, dst, src_size, dst_capacity) return value.
-// d_spec != nullptr (lz4_spec_bytes(njobs) bytes of device scratch, alive until the launches are through): the first
-// 4 MiB of every block of 16 MiB or more are parsed by sixteen wavefronts at once and checked (lz4_gate.hip); the
-// results are the same.  d_valid_segs (optional, njobs ints): how many of the sixteen segments held.  seg_bytes /
-// warm_bytes: 0 = the defaults (tests shrink them to see segments fail).
-size_t lz4_spec_bytes(int njobs);
-int lz4_sizes_device(const Lz4Job *d_jobs, int njobs, int *d_results, hipStream_t s, void *d_spec = nullptr, int *d_valid_segs = nullptr,
-		     uint32_t seg_bytes = 0, uint32_t warm_bytes = 0);
+int lz4_sizes_device(const Lz4Job *d_jobs, int njobs, int *d_results, hipStream_t s);
 
 // reference src/stream.c:2325-2380 decision from a size oracle; size_fn(in_len, d_len) must
 // return the LZ4 size of the first in_len bytes of the block.

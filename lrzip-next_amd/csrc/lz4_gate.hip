@@ -119,53 +119,32 @@ struct Win {
 	}
 };
 
-// ---- the automaton of one wavefront ------------------------------------------------------------------------------
-// Where a run begins: mode 0 at the start of the input like LZ4_compress_generic itself; mode 1 at the top of the
-// match-search loop with a given position, anchor, output count and hash table (a run taken over from another one);
-// mode 2 there too, but cold: empty table, anchor = ip -- the speculative run of a segment (k_lz4_spec).
-struct Lz4Start {
-	int mode;
-	uint32_t ip, anchor;
-	long long op;
-	const uint32_t *table; // mode 1: 4096 words in device memory
-};
-// what a speculative run reports at the first match search at or behind each of its two boundaries
-struct Lz4Mark {
-	uint32_t ip, anchor;
-	long long op; // bytes put out since the run's first mark (the second mark), 0 (the first)
-	int ok;       // 0: the run ended some other way (it met the end of the input or the output limit)
-	int pad;
-};
-struct Lz4SegOut {
-	Lz4Mark first, second;
-};
-
-// SPEC = false: returns the size (or 0, or the early verdict's bound) like LZ4_compress_default.
-// SPEC = true: runs until the first match search at or behind b_hi; at the first one at or behind b_lo it copies its
-// state out (mark `first`, table tab_out[0..4096)), at the end again (`second`, tab_out[4096..8192)); returns -1.
-template <bool SPEC>
-__device__ __forceinline__ int lz4_wave(const Lz4Job &job, const Lz4Start &st0, uint8_t *smem, const int lane, const uint32_t b_lo,
-					 const uint32_t b_hi, Lz4SegOut *seg_out, uint32_t *tab_out)
+// grid.x = number of jobs, block = 64 threads (one wavefront per job); dynamic LDS = RING + TABLE_BYTES + OWNER_BYTES
+__global__ void __launch_bounds__(64) k_lz4_size(const Lz4Job *__restrict__ jobs, int *__restrict__ results)
 {
+	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 	uint8_t *ring = smem;
 	uint32_t *table32 = reinterpret_cast<uint32_t *>(smem + RING);
 	uint16_t *table16 = reinterpret_cast<uint16_t *>(smem + RING);
 	uint8_t *owner = smem + RING + TABLE_BYTES;
+	const int lane = threadIdx.x;
+	const Lz4Job job = jobs[blockIdx.x];
 	const uint8_t *src = job.src;
 	const int src_size = job.src_size;
 	const long long olimit = job.dst_capacity;
 
-	if ((uint32_t)src_size > LZ4_MAX_INPUT_SIZE)
-		return 0;
-	if (src_size == 0)
-		return job.dst_capacity > 0 ? 1 : 0;
-	if (st0.mode == 1) {
-		for (int k = lane; k < (int)(TABLE_BYTES / 4); k += 64)
-			table32[k] = st0.table[k];
-	} else {
-		for (int k = lane; k < (int)(TABLE_BYTES / 4); k += 64)
-			table32[k] = 0;
+	if ((uint32_t)src_size > LZ4_MAX_INPUT_SIZE) {
+		if (lane == 0)
+			results[blockIdx.x] = 0;
+		return;
 	}
+	if (src_size == 0) {
+		if (lane == 0)
+			results[blockIdx.x] = job.dst_capacity > 0 ? 1 : 0;
+		return;
+	}
+	for (int k = lane; k < (int)(TABLE_BYTES / 4); k += 64)
+		table32[k] = 0;
 
 	const bool limited = job.dst_capacity < (long long)src_size + src_size / 255 + 16;
 	const bool by_u16 = src_size < LZ4_64KLIMIT;
@@ -219,53 +198,21 @@ __device__ __forceinline__ int lz4_wave(const Lz4Job &job, const Lz4Start &st0, 
 
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-	ensure(st0.mode == 0 ? 0 : st0.ip);
+	ensure(0);
 
 	// wave-uniform automaton state (positions are offsets from src)
 	uint32_t ip = 0, anchor = 0, match = 0;
 	long long op = 0;
 	int result = -1;
-	bool marked = false; // (SPEC) the first mark is out
-	long long op_mark = 0;
-	auto mark = [&](Lz4Mark *m, uint32_t *tab, long long op_rel, int ok) {
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-		for (int k = lane; k < (int)(TABLE_BYTES / 4); k += 64)
-			tab[k] = table32[k];
-		if (lane == 0) {
-			m->ip = ip;
-			m->anchor = anchor;
-			m->op = op_rel;
-			m->ok = ok;
-		}
-	};
 
-	if (st0.mode != 0) {
-		ip = st0.ip;
-		anchor = st0.anchor;
-		op = st0.op;
-	} else {
-		if (src_size < LZ4_MINLENGTH)
-			goto last_literals;
+	if (src_size < LZ4_MINLENGTH)
+		goto last_literals;
 
-		if (lane == 0)
-			tset(W.hash(0, by_u16), 0);
-		ip = 1;
-	}
+	if (lane == 0)
+		tset(W.hash(0, by_u16), 0);
+	ip = 1;
 
 	for (;;) {
-		if constexpr (SPEC) {
-			// the top of a match search: the one state two runs over the same bytes can be compared in
-			if (!marked && ip >= b_lo) {
-				mark(&seg_out->first, tab_out, 0, 1);
-				marked = true;
-				op_mark = op;
-			}
-			if (ip >= b_hi) {
-				mark(&seg_out->second, tab_out + TABLE_BYTES / 4, op - op_mark, marked ? 1 : 0);
-				return -1;
-			}
-		}
 		// ---- find a match: 64 probes of the greedy scan per round, one per lane ----
 		// The skip acceleration is a pure function of the probe count, so the position of every
 		// probe of a search is known in closed form.  Every lane hashes its position and
@@ -393,7 +340,7 @@ __device__ __forceinline__ int lz4_wave(const Lz4Job &job, const Lz4Start &st0, 
 				op += (mc - ML_MASK) / 255 + 1;
 		}
 		anchor = ip;
-		if (!SPEC && job.stop_below > 0) { // (a speculative run's count is relative: k_lz4_chain looks at the bound)
+		if (job.stop_below > 0) {
 			const long long rest = (long long)iend - (long long)anchor;
 			const long long ub = op + rest + rest / 255 + 16;
 			if (ub < (long long)job.stop_below) {
@@ -442,172 +389,19 @@ last_literals:
 		result = (int)op;
 	}
 done:
-	if constexpr (SPEC) {
-		// (a speculative run is never given a segment near the end of the input or of the output room: not reached)
-		if (!marked)
-			mark(&seg_out->first, tab_out, 0, 0);
-		mark(&seg_out->second, tab_out + TABLE_BYTES / 4, 0, 0);
-		return -1;
-	}
-	return result;
-}
-
-// grid.x = number of jobs, block = 64 threads (one wavefront per job); dynamic LDS = RING + TABLE_BYTES + OWNER_BYTES.
-// starts == nullptr: every job from the start of its input.  Otherwise starts[j].mode: 0 from the start, 1 taken over
-// from the speculative runs (k_lz4_chain), 3: the verdict is already in results[j]
-__global__ void __launch_bounds__(64) k_lz4_size(const Lz4Job *__restrict__ jobs, int *__restrict__ results, const Lz4Start *__restrict__ starts)
-{
-	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-	const int lane = threadIdx.x;
-	const Lz4Job job = jobs[blockIdx.x];
-	Lz4Start st;
-	st.mode = 0;
-	st.ip = st.anchor = 0;
-	st.op = 0;
-	st.table = nullptr;
-	if (starts) {
-		st = starts[blockIdx.x];
-		if (st.mode == 3)
-			return;
-	}
-	const int r = lz4_wave<false>(job, st, smem, lane, 0, 0, nullptr, nullptr);
 	if (lane == 0)
-		results[blockIdx.x] = r;
+		results[blockIdx.x] = result;
 }
 
-// ---- the first part of a large block on several wavefronts ---------------------------------------------------------
-// The greedy parse of LZ4_compress_generic is one automaton per block, but its state at the top of a match search is
-// small -- the position, the anchor and the 4096 table words, of which only those within 64 KiB of the position can ever
-// matter again -- and a run that starts cold some way in front of a point soon parses like the real one (its own
-// inserts replace what it did not see; what it never saw ages out of reach).  So the first SPEC_SEGS * SPEC_SEG bytes
-// of a block are parsed by SPEC_SEGS wavefronts at once, wavefront k from SPEC_WARM bytes in front of k * SPEC_SEG with
-// an empty table; each notes its state at its first match search at or behind its segment's start and again at or
-// behind its end.  k_lz4_chain then checks, segment by segment, that run k's first note IS run k - 1's second one
-// (same position, same anchor, tables equal word by word where a word is still within reach): then run k was the real
-// parse from there on and its output count is the real one.  The first segment whose note differs, and everything
-// behind it, is parsed again by the one wavefront that takes over (k_lz4_size with a start state) -- speculation decides
-// how long the gate takes, never what it says.
-constexpr uint32_t SPEC_SEG = 256u << 10, SPEC_WARM = 128u << 10;
-constexpr int SPEC_SEGS = 16;
-constexpr int SPEC_MIN_BLOCK = 16 << 20; // blocks below this are parsed by one wavefront as before
-
-__global__ void __launch_bounds__(64) k_lz4_spec(const Lz4Job *__restrict__ jobs, Lz4SegOut *__restrict__ segs, uint32_t *__restrict__ tables,
-						 uint32_t seg_bytes, uint32_t warm_bytes)
-{
-	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-	const int lane = threadIdx.x, j = blockIdx.x / SPEC_SEGS, k = blockIdx.x % SPEC_SEGS;
-	const Lz4Job job = jobs[j];
-	Lz4SegOut *out = segs + (size_t)blockIdx.x;
-	uint32_t *tab = tables + (size_t)blockIdx.x * 2 * (TABLE_BYTES / 4);
-	if ((int64_t)job.src_size < (int64_t)SPEC_MIN_BLOCK) {
-		if (lane == 0)
-			out->first.ok = out->second.ok = 0;
-		return;
-	}
-	Lz4Start st;
-	st.mode = k == 0 ? 0 : 2;
-	st.ip = st.anchor = k == 0 ? 0 : (uint32_t)k * seg_bytes - warm_bytes;
-	st.op = 0;
-	st.table = nullptr;
-	(void)lz4_wave<true>(job, st, smem, lane, (uint32_t)k * seg_bytes, (uint32_t)(k + 1) * seg_bytes, out, tab);
-}
-
-// one wavefront per job: how far the speculative runs were the real parse, the verdict if that is far enough, else the
-// state the one wavefront of k_lz4_size goes on from
-__global__ void __launch_bounds__(64) k_lz4_chain(const Lz4Job *__restrict__ jobs, const Lz4SegOut *__restrict__ segs, const uint32_t *__restrict__ tables,
-						  int *__restrict__ results, Lz4Start *__restrict__ starts, int *__restrict__ valid_segs)
-{
-	const int lane = threadIdx.x, j = blockIdx.x;
-	const Lz4Job job = jobs[j];
-	const Lz4SegOut *S = segs + (size_t)j * SPEC_SEGS;
-	const uint32_t *T = tables + (size_t)j * SPEC_SEGS * 2 * (TABLE_BYTES / 4);
-	Lz4Start st;
-	st.mode = 0;
-	st.ip = st.anchor = 0;
-	st.op = 0;
-	st.table = nullptr;
-	int good = 0; // segments whose run was the real parse
-	if ((int64_t)job.src_size >= (int64_t)SPEC_MIN_BLOCK && S[0].first.ok && S[0].second.ok) {
-		good = 1;
-		long long op = S[0].second.op;
-		for (int k = 1; k < SPEC_SEGS; k++) {
-			const Lz4Mark a = S[k - 1].second, b = S[k].first;
-			bool same = b.ok && S[k].second.ok && a.ip == b.ip && a.anchor == b.anchor;
-			if (same) {
-				// word by word: equal, or both out of reach for good (a match candidate must lie within 65535 of the
-				// position, and positions only grow)
-				const uint32_t *ta = T + ((size_t)(k - 1) * 2 + 1) * (TABLE_BYTES / 4), *tb = T + ((size_t)k * 2) * (TABLE_BYTES / 4);
-				bool diff = false;
-				for (int q = lane; q < (int)(TABLE_BYTES / 4); q += 64) {
-					const uint32_t x = ta[q], y = tb[q];
-					if (x != y && ((uint64_t)x + LZ4_DISTANCE_MAX >= a.ip || (uint64_t)y + LZ4_DISTANCE_MAX >= a.ip))
-						diff = true;
-				}
-				same = __ballot(diff) == 0;
-			}
-			if (!same)
-				break;
-			op += S[k].second.op;
-			good = k + 1;
-		}
-		const Lz4Mark e = S[good - 1].second;
-		st.mode = 1;
-		st.ip = e.ip;
-		st.anchor = e.anchor;
-		st.op = op;
-		st.table = T + ((size_t)(good - 1) * 2 + 1) * (TABLE_BYTES / 4);
-		if (job.stop_below > 0) {
-			const long long rest = (long long)job.src_size - (long long)e.anchor;
-			const long long ub = op + rest + rest / 255 + 16;
-			if (ub < (long long)job.stop_below) {
-				st.mode = 3;
-				if (lane == 0)
-					results[j] = (int)ub;
-			}
-		}
-	}
-	if (lane == 0) {
-		starts[j] = st;
-		if (valid_segs)
-			valid_segs[j] = good;
-	}
-}
-
-size_t lz4_spec_bytes(int njobs)
-{
-	const size_t per_job = (size_t)SPEC_SEGS * (sizeof(Lz4SegOut) + 2 * TABLE_BYTES) + sizeof(Lz4Start) + sizeof(int);
-	return ((size_t)(njobs > 0 ? njobs : 0) * per_job + 511) & ~(size_t)255;
-}
-
-int lz4_sizes_device(const Lz4Job *d_jobs, int njobs, int *d_results, hipStream_t s, void *d_spec, int *d_valid_segs, uint32_t seg_bytes, uint32_t warm_bytes)
+int lz4_sizes_device(const Lz4Job *d_jobs, int njobs, int *d_results, hipStream_t s)
 {
 	if (njobs <= 0)
 		return 0;
 	const size_t lds = (size_t)RING + TABLE_BYTES + OWNER_BYTES;
-	static int attr_rc = (int)hipFuncSetAttribute((const void *)k_lz4_size, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) |
-			     (int)hipFuncSetAttribute((const void *)k_lz4_spec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	static int attr_rc = (int)hipFuncSetAttribute((const void *)k_lz4_size, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	if (attr_rc != (int)hipSuccess)
 		return -1;
-	const Lz4Start *starts = nullptr;
-	if (d_spec) {
-		// scratch layout: tables | segment notes | start states
-		uint8_t *p = (uint8_t *)d_spec;
-		uint32_t *tables = (uint32_t *)p;
-		p += (size_t)njobs * SPEC_SEGS * 2 * TABLE_BYTES;
-		Lz4SegOut *segs = (Lz4SegOut *)p;
-		p += (size_t)njobs * SPEC_SEGS * sizeof(Lz4SegOut);
-		Lz4Start *st = (Lz4Start *)p;
-		if (!seg_bytes)
-			seg_bytes = SPEC_SEG;
-		if (!warm_bytes)
-			warm_bytes = SPEC_WARM;
-		if (warm_bytes > seg_bytes)
-			warm_bytes = seg_bytes;
-		hipLaunchKernelGGL(k_lz4_spec, dim3(njobs * SPEC_SEGS), dim3(64), lds, s, d_jobs, segs, tables, seg_bytes, warm_bytes);
-		hipLaunchKernelGGL(k_lz4_chain, dim3(njobs), dim3(64), 0, s, d_jobs, (const Lz4SegOut *)segs, (const uint32_t *)tables, d_results, st, d_valid_segs);
-		starts = st;
-	}
-	hipLaunchKernelGGL(k_lz4_size, dim3(njobs), dim3(64), lds, s, d_jobs, d_results, starts);
+	hipLaunchKernelGGL(k_lz4_size, dim3(njobs), dim3(64), lds, s, d_jobs, d_results);
 	return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -206,7 +206,6 @@ struct Lz4Batch {
 	std::vector<Job *> jobs;
 	EventTimer *timer = nullptr;
 	int64_t bytes = 0;
-	int spec_slot = -1, spec_n = 0; // the scratch of the speculative first part (Feeder::spec), as slots [spec_slot, + spec_n)
 };
 
 struct Pipeline {
@@ -521,36 +520,8 @@ struct Feeder {
 	// it would synchronise the whole device (and with it the multi-second gate launches)
 	DevBuf arena;
 	size_t arena_cap = 0, arena_used = 0;
-	// scratch of the gate's speculative first part (lz4_gate.hip: sixteen wavefronts on the first 4 MiB of a block):
-	// kSpecSlots job-sized slots, handed out to launches and taken back when their results are collected; a launch that
-	// finds too few free runs on one wavefront per block as before
-	static constexpr int kSpecSlots = 48;
-	DevBuf spec;
-	std::vector<char> spec_busy;
 
 	explicit Feeder(Pipeline &p) : P(p) {}
-	int spec_take(int n) // first of n consecutive free slots, -1 if there are none (or no scratch)
-	{
-		if (!spec.p || n <= 0 || n > kSpecSlots)
-			return -1;
-		for (int at = 0; at + n <= kSpecSlots; at++) {
-			int k = 0;
-			while (k < n && !spec_busy[(size_t)(at + k)])
-				k++;
-			if (k == n) {
-				for (k = 0; k < n; k++)
-					spec_busy[(size_t)(at + k)] = 1;
-				return at;
-			}
-			at += k;
-		}
-		return -1;
-	}
-	void spec_give(int at, int n)
-	{
-		for (int k = 0; at >= 0 && k < n; k++)
-			spec_busy[(size_t)(at + k)] = 0;
-	}
 
 	int reserve(size_t descriptors)
 	{
@@ -563,11 +534,6 @@ struct Feeder {
 		arena_used = 0;
 		if (!arena.alloc(arena_cap * (sizeof(Lz4Job) + sizeof(int)) + 64, P.device))
 			return LRZGPU_E_NOMEM;
-		if (!spec.p && P.sz.lz4_test && !P.sz.no_compress && P.sz.stream_bufsize >= ((int64_t)16 << 20)) {
-			const char *e = getenv("LRZGPU_GATE_SPEC"); // 0: one wavefront per block (A/B, tests)
-			if ((!e || strcmp(e, "0")) && spec.alloc(lz4_spec_bytes(1) * kSpecSlots, P.device))
-				spec_busy.assign((size_t)kSpecSlots, 0);
-		}
 		return 0;
 	}
 
@@ -623,9 +589,7 @@ struct Feeder {
 			return LRZGPU_E_HIP;
 		hipStream_t ls = gate_streams[gate_rr++ % gate_streams.size()];
 		b.timer = new EventTimer(ls);
-		b.spec_n = (int)lj.size();
-		b.spec_slot = spec_take(b.spec_n);
-		int lr = lz4_sizes_device(b.d_jobs, (int)lj.size(), b.d_res, ls, b.spec_slot >= 0 ? spec.p + (size_t)b.spec_slot * lz4_spec_bytes(1) : nullptr);
+		int lr = lz4_sizes_device(b.d_jobs, (int)lj.size(), b.d_res, ls);
 		b.timer->stop();
 		if (lr != 0 || hipEventCreateWithFlags(&b.ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(b.ev, ls) != hipSuccess) {
 			delete b.timer;
@@ -675,7 +639,6 @@ struct Feeder {
 			}
 			delete b.timer;
 			(void)hipEventDestroy(b.ev);
-			spec_give(b.spec_slot, b.spec_n);
 			batches.erase(batches.begin() + (long)k);
 		}
 		return 0;
@@ -698,8 +661,6 @@ struct Feeder {
 		ms = nullptr;
 		gate_streams.clear();
 		arena.release();
-		spec.release();
-		spec_busy.clear();
 	}
 };
 

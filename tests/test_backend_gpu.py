@@ -157,41 +157,6 @@ def test_lz4_early_verdict_equals_oracle(B, O):
                 assert got == want, (kind, n, bound, got, want, flag.value)
 
 
-@pytest.mark.parametrize("kind", ["text", "random", "few", "phrases"])
-def test_lz4_gate_on_sixteen_wavefronts_says_the_same(B, O, kind):
-    """Blocks of 16 MiB or more: the first 4 MiB are parsed by sixteen wavefronts at once, wavefront k from 128 KiB in
-    front of its 256 KiB segment with an empty hash table, and a segment only counts if its run met its predecessor's
-    state exactly (position, anchor, every table word still within LZ4's 64 KiB reach) -- csrc/lz4_gate.hip.  The exact
-    size must be the one-wavefront kernel's (= liblz4 1.9.3's, tests above), the early verdict the same verdict; with
-    segments and warm-up shrunk until most segments FAIL their check the answers must not move either."""
-    L = B.lib()
-    L.lrzgpu_lz4_size_speculative.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_uint, C.POINTER(C.c_int), C.c_int]
-    L.lrzgpu_lz4_size_stop_below.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
-    n = (16 << 20) + 4321
-    data = datagen.KINDS[kind](n, seed=37)
-    exact = L.lrzgpu_lz4_compress_default_size(data, n, n + 1, 0)
-    bounds = (n, n // 2)
-    one = {b: L.lrzgpu_lz4_size_stop_below(data, n, n + 1, b, 0) for b in bounds}
-    held = {}
-    for seg, warm in ((0, 0), (65536, 4096), (20000, 64)):
-        v = C.c_int(-1)
-        assert L.lrzgpu_lz4_size_speculative(data, n, n + 1, 0, seg, warm, C.byref(v), 0) == exact, (kind, seg, warm)
-        assert 0 <= v.value <= 16
-        held[(seg, warm)] = v.value
-        for b in bounds:
-            got = L.lrzgpu_lz4_size_speculative(data, n, n + 1, b, seg, warm, C.byref(v), 0)
-            assert (0 < one[b] < b) == (0 < got < b), (kind, seg, warm, b, one[b], got)
-            if not (0 < one[b] < b):
-                assert got == one[b]  # (no early verdict: both ran the block out)
-    if kind in ("text", "phrases"):
-        assert held[(0, 0)] >= 12, held  # the real settings hold on ordinary data (or the gate is no faster than before)
-    # a block below 16 MiB takes the one wavefront
-    v = C.c_int(-1)
-    small = data[: 3 << 20]
-    assert L.lrzgpu_lz4_size_speculative(small, len(small), len(small) + 1, 0, 0, 0, C.byref(v), 0) == L.lrzgpu_lz4_compress_default_size(small, len(small), len(small) + 1, 0)
-    assert v.value == 0
-
-
 def test_mf_stream_in_btbuf_format(B, O):
     """lrzgpu_lzma_mf_open / next_block / close: the BT thread's block format (LzFindMt.c:571-729).  Re-reading the
     blocks must give, position by position, the oracle's lists without their h2/h3 front (lengths 2 and 3 belong to
