@@ -48,8 +48,8 @@ def test_rounds_and_exact_stretches_are_one_automaton(B, O, kind, verdict, dense
     kernel hands over to the dense variant instead, which takes its own stretches under 'always'."""
     monkeypatch.setenv("LRZGPU_RESOLVE_POOR", verdict)
     monkeypatch.setenv("LRZGPU_RESOLVE_DENSE", dense)
-    if dense == "1" and verdict == "never":
-        pytest.skip("rounds only: the hand-over is never asked for, same run as with 0")
+    if dense == "1" and (verdict == "never" or kind in ("longrange", "random")):
+        pytest.skip("rounds only: the hand-over is never asked for, same run as with 0 (and three kinds are enough for it)")
     degenerate = kind in ("few", "phrases")
     n = ((96 << 10) if verdict == "never" else (1 << 20)) + 99 if degenerate else 1048576 + 777
     for level in ((7, 9) if degenerate and verdict == "always" else (7,)):
@@ -152,6 +152,16 @@ def test_table_fill_and_clean_sweeps(B, O):
     # small table (level 1): many mask generations on a few MiB
     st = _check(B, O, datagen.random_bytes(6 * 1048576, seed=22), level=1)
     assert st.minimum_tag_mask > 15
+
+
+def test_dense_resolver_through_a_full_table(B, O, monkeypatch):
+    """The dense variant on every launch of a scan whose L7 table fills and is swept (continuous cleaning, tightening
+    masks, lookup-only candidates, displacement chains), then 24 MiB with a 12 MiB copy (the long extent leaves through
+    k_long_compare and comes back into the variant)."""
+    monkeypatch.setenv("LRZGPU_RESOLVE_DENSE", "always")
+    st = _check(B, O, datagen.text_like(32 * 1048576 + 5, seed=21), level=7)
+    assert st.minimum_tag_mask > 1
+    _check(B, O, datagen.long_range(24 * 1048576, seed=5, base_frac=0.5, mutate_every=70001), level=7)
 
 
 def test_long_range_copy(B, O):
