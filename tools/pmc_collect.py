@@ -21,7 +21,11 @@ STREAMING = {"k_crc32_tiles", "k_long_compare", "k_gather_runs", "k_tag_scan"}
 def short(name):
     m = re.match(r"(?:void )?(?:lrzgpu::)?([A-Za-z_0-9]+)", name.strip('"'))
     n = m.group(1) if m else name
-    return "rocprim_sort/scan/select" if n.startswith("rocprim") or "rocprim" in name[:40] else n
+    if n.startswith("rocprim") or "rocprim" in name[:40]:
+        # rocPRIM's kernels by their own names (round 5's summaries had them under one label: hard to audit)
+        r = re.search(r"rocprim::(?:detail::)?([A-Za-z_0-9]+)", name)
+        return "rocprim::" + (r.group(1) if r else "kernel")
+    return n
 
 
 RAW = "/tmp/lrzgpu_prof_raw"  # raw rocprofv3 output is hundreds of MiB: it never goes under gpurun_out/
