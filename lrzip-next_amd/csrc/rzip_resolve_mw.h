@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 	// when its rounds stop paying (leave = 4), the dense variant gives back when fewer than one in eight of DENSE_WINDOW rounds had a
 	// use for what it adds (leave = 5); the kernel ends with ScanState::error = leave and p_skip in front of the first
 	// candidate it has not examined
-	constexpr int DENSE_WINDOW = 512;
+	constexpr int DENSE_WINDOW = 256;
 	int leave = 0, dense_rounds = 0, dense_used = 0;
 	__syncthreads();
 	for (;;) {

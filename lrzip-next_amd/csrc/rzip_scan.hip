@@ -1958,7 +1958,12 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 	// phrases over and over.  LRZGPU_RESOLVE_DENSE=0: never (exact stretches instead, rounds 1 to 5); =always: every
 	// launch is the dense one (tests: every data kind through it)
 	bool dense = false;
-	{
+	// a hand-over that did not pay (the dense variant gave back: seven rounds in eight had no use for it) is not asked for
+	// again for 1, 2, 4 ... 64 segments: data whose rounds are poor for other reasons -- a match of 64 KiB after every
+	// mutated byte, as in the headline file's later chunks -- would otherwise go back and forth every few hundred rounds,
+	// each time with a new K1 pass over the rest of the segment
+	int dense_ban = 0, dense_ban_next = 1;
+	const int batch_mode_base = [&] {
 		const char *e = getenv("LRZGPU_RESOLVE_DENSE");
 		if ((!e || strcmp(e, "0")) && chain <= (unsigned)MAX_EQS)
 			batch_mode |= 16; // (level 9's chains of 128 equal tags are beyond what a lane of the variant holds: exact stretches there)
@@ -1966,7 +1971,8 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 			batch_mode |= 32;
 			dense = true;
 		}
-	}
+		return batch_mode;
+	}();
 	const auto wall0 = std::chrono::steady_clock::now();
 	const int64_t end = h.end;
 	int64_t p_skip = 0;
@@ -2035,13 +2041,13 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 		if (dense)
 			hipLaunchKernelGGL((k_resolve_mw<1, DENSE_HITS, MAX_EQS, true>), dim3(1), dim3(64), 0, s, d_chunk, (Slot *)w->table, w->state, (i64)seg_lo,
 					   ntiles, (const uint32_t *)w->cand_rel, (const u64 *)w->cand_tag, (const uint32_t *)w->tile_count, w->records,
-					   batch_mode, (const uint32_t *)w->tile_base, (const uint32_t *)w->comp_rel, (const u64 *)w->comp_tag,
+					   batch_mode_base, (const uint32_t *)w->tile_base, (const uint32_t *)w->comp_rel, (const u64 *)w->comp_tag,
 					   (uint32_t)w->comp_cap, w->rank_bytes, w->fp_bytes);
 		else
 			hipLaunchKernelGGL((k_resolve_mw<4, MAX_HITS, MAX_EQS>), dim3(1), dim3(256), 0, s, d_chunk, (Slot *)w->table, w->state, (i64)seg_lo,
 					   ntiles, (const uint32_t *)w->cand_rel, (const u64 *)w->cand_tag, (const uint32_t *)w->tile_count, w->records,
-					   batch_mode, (const uint32_t *)w->tile_base, (const uint32_t *)w->comp_rel, (const u64 *)w->comp_tag,
-					   (uint32_t)w->comp_cap, w->rank_bytes, w->fp_bytes);
+					   dense_ban > 0 ? (batch_mode_base & ~16) : batch_mode_base, (const uint32_t *)w->tile_base, (const uint32_t *)w->comp_rel,
+					   (const u64 *)w->comp_tag, (uint32_t)w->comp_cap, w->rank_bytes, w->fp_bytes);
 		t2.stop();
 		HIPCHK(d2h_pageable(&h, w->state, sizeof(h), s)); // (sleeps while the resolver runs)
 		if (getenv("LRZGPU_TRACE"))
@@ -2098,6 +2104,10 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 			if (getenv("LRZGPU_TRACE"))
 				fprintf(stderr, "lrzgpu scan: the %s resolver takes over at %lld\n", h.error == 4 ? "dense" : "four-wavefront", (long long)h.p_skip + 1);
 			dense = h.error == 4;
+			if (h.error == 5) {
+				dense_ban = dense_ban_next;
+				dense_ban_next = dense_ban_next < 64 ? 2 * dense_ban_next : 64;
+			}
 			h.error = 0;
 			HIPCHK(hipMemcpyAsync(w->state, &h, sizeof(h), hipMemcpyHostToDevice, s));
 			p_skip = h.p_skip;
@@ -2111,6 +2121,10 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 		}
 		if (h.error)
 			return h.error == 1 ? -4 : -5;
+		if (dense)
+			dense_ban_next = 1; // (the variant saw a segment out: it is where it belongs)
+		else if (dense_ban > 0)
+			dense_ban--;
 		p_skip = h.p_skip > seg_hi - 1 ? h.p_skip : seg_hi - 1;
 		min_mask = h.min_mask;
 		if (progress) {
