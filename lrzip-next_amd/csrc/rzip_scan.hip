@@ -136,7 +136,10 @@ __global__ void __launch_bounds__(256) k_tag_scan(const uint8_t *__restrict__ bu
 						  uint32_t *__restrict__ tile_count)
 {
 	__shared__ u64 hx[256];
-	__shared__ u64 xs[PER_THREAD][256 + 2]; // xs[j][t] = X(16 t + j); columns 256, 257: the 32 positions behind the tile
+	// xs[j & 7][t] = X(16 t + j), in two halves (j < 8, then j >= 8: 16.5 KB instead of 33 -- with 35 KB a workgroup did not
+	// fit beside the finder's walk workgroups on a CU and waited for one to drain: 8 ms a launch inside the pipeline
+	// against 0.3 ms alone); columns 256, 257: the 32 positions behind the tile
+	__shared__ u64 xs[PER_THREAD / 2][256 + 2];
 	__shared__ u64 wave_x[4];
 	__shared__ uint32_t wave_tot[4];
 
@@ -181,9 +184,7 @@ __global__ void __launch_bounds__(256) k_tag_scan(const uint8_t *__restrict__ bu
 	u64 excl = inc ^ acc; // everything in front of my first byte
 	for (int q = 0; q < wv; q++)
 		excl ^= wave_x[q];
-#pragma unroll
-	for (int j = 0; j < PER_THREAD; j++)
-		xs[j][tid] = j ? excl ^ x[j - 1] : excl;
+	u64 xh[PER_THREAD]; // the 32 positions behind the tile (threads 0 and 1)
 	if (tid < 2) {
 		u64 a = wave_x[0] ^ wave_x[1] ^ wave_x[2] ^ wave_x[3]; // X(4096)
 		if (tid == 1) {
@@ -194,23 +195,38 @@ __global__ void __launch_bounds__(256) k_tag_scan(const uint8_t *__restrict__ bu
 		const uint4 mine = tid ? h1 : h0;
 #pragma unroll
 		for (int j = 0; j < PER_THREAD; j++) {
-			xs[j][256 + tid] = a;
+			xh[j] = a;
 			a ^= hx[byte_of(mine, j)];
 		}
 	}
-	__syncthreads();
-
-	// tags of my 16 positions: X(i + 31) ^ X(i), i = 16 tid + k; X(i + 31) sits in column tid + 1 (k = 0) or tid + 2
+	// tags of my 16 positions: X(i + 31) ^ X(i), i = 16 tid + k; X(i + 31) = X(16 (tid + 1) + 15) for k = 0, else
+	// X(16 (tid + 2) + k - 1): the half with j < 8 serves k = 1 .. 8, the half with j >= 8 serves k = 9 .. 15 and k = 0
 	const int l0 = tid * PER_THREAD;
 	u64 tags[PER_THREAD];
 	uint32_t bits = 0;
 #pragma unroll
-	for (int k = 0; k < PER_THREAD; k++) {
-		const u64 xi = k ? excl ^ x[k - 1] : excl;
-		const u64 t = xs[(k + 15) & 15][tid + 1 + ((k + 15) >> 4)] ^ xi;
-		tags[k] = t;
-		if (l0 + k < need && (t & min_mask) == min_mask)
-			bits |= 1u << k;
+	for (int half = 0; half < 2; half++) {
+		if (half)
+			__syncthreads(); // (the first half has been read)
+#pragma unroll
+		for (int j = 0; j < PER_THREAD / 2; j++) {
+			const int jj = 8 * half + j;
+			xs[j][tid] = jj ? excl ^ x[jj - 1] : excl;
+			if (tid < 2)
+				xs[j][256 + tid] = xh[jj];
+		}
+		__syncthreads();
+#pragma unroll
+		for (int k = 0; k < PER_THREAD; k++) {
+			const int jn = (k + 15) & 15; // X(i + 31) is entry jn of column tid + 1 + ((k + 15) >> 4)
+			if ((jn >> 3) != half)
+				continue;
+			const u64 xi = k ? excl ^ x[k - 1] : excl;
+			const u64 t = xs[jn & 7][tid + 1 + ((k + 15) >> 4)] ^ xi;
+			tags[k] = t;
+			if (l0 + k < need && (t & min_mask) == min_mask)
+				bits |= 1u << k;
+		}
 	}
 	// workgroup exclusive scan of popcounts
 	uint32_t cnt = __popc(bits);
