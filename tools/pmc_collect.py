@@ -23,7 +23,7 @@ def short(name):
     n = m.group(1) if m else name
     if n.startswith("rocprim") or "rocprim" in name[:40]:
         # rocPRIM's kernels by their own names (round 5's summaries had them under one label: hard to audit)
-        r = re.search(r"rocprim::(?:detail::)?([A-Za-z_0-9]+)", name)
+        r = re.search(r"rocprim::(?:ROCPRIM_[0-9]+_NS::)?(?:detail::)?([A-Za-z_0-9]+)", name)
         return "rocprim::" + (r.group(1) if r else "kernel")
     return n
 
