@@ -38,6 +38,25 @@ def test_single_chunk_l7(B, O, kind):
         assert fs.blocks_lzma <= 1  # lz4 gate rejects the literal blocks -> stored; only the tiny token stream compresses
 
 
+_MIXED = {}
+
+
+@pytest.mark.parametrize("dense", ["always", "1"])
+def test_mixed_file_with_the_dense_resolver(B, O, dense, monkeypatch):
+    """Whole images with the resolver's dense variant on every launch / handing over by itself: a file that is text, then
+    phrases, then four letters, then a copy of its own start, in 100 MiB chunks of which the second starts inside the
+    degenerate part (multi-chunk layout, early block release, the lz4 gate, LZMA: everything downstream of the scan)."""
+    if not _MIXED:
+        head = datagen.text_like(88 << 20, seed=31)
+        data = head + datagen.phrase_mix(9 << 20, seed=32) + datagen.few_symbols(7 << 20, seed=33) + head[: 8 << 20] + datagen.phrase_mix((1 << 20) + 77, seed=34)
+        want, fs = O.compress_buffer(data, compression_level=7, threads=8, processors=8, ramsize=RAM, window=1, workers=16)
+        assert fs.n_chunks == 2
+        _MIXED.update(data=data, want=want)
+    monkeypatch.setenv("LRZGPU_RESOLVE_DENSE", dense)
+    got, _ = B.compress_buffer(_MIXED["data"], level=7, threads=8, processors=8, ramsize=RAM, window=1, host_threads=16)
+    assert got == _MIXED["want"]
+
+
 def test_levels_and_threads(B, O):
     data = datagen.long_range(6 * 1048576, seed=12, base_frac=0.6, mutate_every=50021)
     for level in (5, 6, 8, 9):

@@ -84,7 +84,7 @@ def test_degenerate_inputs_hand_over_to_the_dense_resolver(B, O, kind):
     candidates (a four-letter alphabet: every candidate's insert lands in its neighbours' probe run; phrases: a match
     every few candidates), the dense one gives back when seven rounds in eight had no use for it.  4 MiB each (the
     reference's one core needs about 2 s for these; rounds 1 to 5 of this library needed 8 to 13 s for FIVE MiB)."""
-    n = (4 << 20) + 123
+    n = ((16 << 20) if kind == "few" else (4 << 20)) + 123  # (16 MiB of four letters: about 4 s here, 3.5 s for the oracle's one core)
     if kind == "dna":
         # four letters with repeats: a genome-like input (every 40 KB a copy of an earlier 1-3 KB stretch, lightly mutated)
         import numpy as np
