@@ -48,12 +48,18 @@ def test_cfg3_reduced_concurrent_chunks(B, O, cfg3_small):
     # (one scanner -- the chunks strictly one after the other -- is test_victim_round_chain_rescans' configuration)
 
 
+_VICTIM_DATA = []
+
+
 def _moving_victim_data(O):
-    """Three -w1 chunks whose victim_round does not come back to 0 (checked with the oracle's own scan)."""
-    data = datagen.victim_mover(2 * 104857600 + 20 * 1048576, O.hash_index(), seed=3, every=32768)
-    vr = O.rzip_chunk(data[:104857600], level=7)[4]
-    assert vr != 0, "generator no longer moves victim_round: pick another seed"
-    return data
+    """Three -w1 chunks whose victim_round does not come back to 0 (checked with the oracle's own scan; made once per run:
+    four tests use it)."""
+    if not _VICTIM_DATA:
+        data = datagen.victim_mover(2 * 104857600 + 20 * 1048576, O.hash_index(), seed=3, every=32768)
+        vr = O.rzip_chunk(data[:104857600], level=7)[4]
+        assert vr != 0, "generator no longer moves victim_round: pick another seed"
+        _VICTIM_DATA.append(data)
+    return _VICTIM_DATA[0]
 
 
 def test_victim_round_chain_rescans(B, O):

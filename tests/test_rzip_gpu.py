@@ -66,7 +66,7 @@ def test_dense_resolver_equals_oracle(B, O, kind, level, monkeypatch):
     monkeypatch.setenv("LRZGPU_RESOLVE_DENSE", "always")
     n = (2 if kind in ("phrases", "few") else 3) * 1048576 + 777
     if level == 9 and kind in ("phrases", "few"):
-        n = 393216 + 777  # (chains of 128 equal tags are beyond a lane of the variant: exact steps, kept small)
+        n = 1048576 + 777  # (chains of 128 equal tags: the variant's deep instantiation, 132 hits per lookup)
     _check(B, O, datagen.KINDS[kind](n, seed=level + 11), level=level)
 
 
@@ -159,9 +159,9 @@ def test_dense_resolver_through_a_full_table(B, O, monkeypatch):
     masks, lookup-only candidates, displacement chains), then 24 MiB with a 12 MiB copy (the long extent leaves through
     k_long_compare and comes back into the variant)."""
     monkeypatch.setenv("LRZGPU_RESOLVE_DENSE", "always")
-    st = _check(B, O, datagen.text_like(32 * 1048576 + 5, seed=21), level=7)
+    st = _check(B, O, datagen.text_like(24 * 1048576 + 5, seed=21), level=7)
     assert st.minimum_tag_mask > 1
-    _check(B, O, datagen.long_range(24 * 1048576, seed=5, base_frac=0.5, mutate_every=70001), level=7)
+    _check(B, O, datagen.long_range(16 * 1048576, seed=5, base_frac=0.5, mutate_every=70001), level=7)
 
 
 def test_long_range_copy(B, O):
