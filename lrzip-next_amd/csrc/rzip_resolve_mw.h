@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 	constexpr int RINGN = NW >= 8 ? 2 * W : 4 * W;
 	static_assert(!DENSE || NW == 1, "the dense variant is one wavefront");
 	constexpr int PWB = DENSE ? 64 : 16; // suspects per wave that get the exact test
-	constexpr int CFB = CF_BITS + (NW >= 4 ? 1 : 0) - (DENSE ? 2 : 0); // four times the writes per round: twice the counters (dense: 64 lanes, soft writes not counted)
+	constexpr int CFB = CF_BITS + (NW >= 4 ? 1 : 0); // four times the writes per round: twice the counters
 	constexpr int CFW = (1 << CFB) / 2;
 	__shared__ i64 ring_pos[RINGN];
 	__shared__ u64 ring_tag[RINGN];
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 	// ---- the dense variant (see "dense" below) ----
 	constexpr int DH = DENSE ? MAXH * 64 : 1, DEM = 16;
 	__shared__ uint32_t hit_fr[DH];                          // measured extents of the tag hits, beside hit_all
-	__shared__ u64 q_cache[DENSE ? (MAXH > 64 ? 16 : 32) * 64 : 1]; // a walk step's 4th .. 19th (deep: 11th) fingerprint match (tag, offset), per lane
+	__shared__ u64 q_cache[DENSE ? 32 * 64 : 1];             // a walk step's 4th .. 19th fingerprint match (tag, offset), per lane
 	__shared__ i64 em_p[DEM], em_ofs[DEM], em_len[DEM];      // matches emitted inside the round, in order
 	__shared__ int em_lane[DEM];
 	static_assert(sizeof(i64) * MAXH * 64 * NW >= (size_t)W * 128, "staging area");

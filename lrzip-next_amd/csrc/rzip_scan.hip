@@ -63,7 +63,6 @@ constexpr int A1_MAX_STEPS = 8192; // slots a speculative walk may cover (longer
 constexpr int MAX_EQS = 32;  // round-robin eviction handled in the batch up to this max_chain_len
 constexpr int MAX_HITS = 24; // tag hits one speculative lookup may verify (more -> serial path)
 constexpr int DENSE_HITS = 40; // ... in the dense variant (one wavefront: its hits and their measured extents have the LDS to themselves)
-constexpr int DENSE_HITS_DEEP = 132, DENSE_EQS_DEEP = 128; // ... and its instantiation for level 9 (max_chain_len 128)
 // the 8-wavefront resolver trades both for window: 160 KB of LDS hold 512 candidates with these (levels <= 7 only)
 constexpr int CF_BITS = 13; // conflict filter: 16-bit write counters per hashed 8-slot granule (<= 320 writes per round)
 
@@ -1042,89 +1041,86 @@ __device__ __forceinline__ void measure_hits(const uint8_t *buf, const i64 P, co
 		pf[c] = *reinterpret_cast<const U128u *>(buf + P + 16 * c);
 		pb[c] = *reinterpret_cast<const U128u *>(buf + P - 16 - 16 * c);
 	}
-	for (int base = 0; base < n; base += 64) { // (a lane of the deep instantiation holds up to 132 hits)
-		const int nb = n - base < 64 ? n - base : 64;
-		u64 open = 0; // hits (of this block of 64) with a direction that ran through its first 32 bytes
-		for (int k0 = base; k0 < base + nb; k0 += 4) {
-			i64 op[4];
-			U128u f[4][2], b[4][2];
-			bool fast[4];
+	u64 open = 0; // hits with a direction that ran through its first 32 bytes
+	for (int k0 = 0; k0 < n; k0 += 4) {
+		i64 op[4];
+		U128u f[4][2], b[4][2];
+		bool fast[4];
 #pragma unroll
-			for (int j = 0; j < 4; j++) {
-				op[j] = k0 + j < base + nb ? hit_lds[(k0 + j) * 64 + lane] : P;
-				fast[j] = op[j] >= 64 && op[j] < P;
-				if (fast[j]) {
+		for (int j = 0; j < 4; j++) {
+			op[j] = k0 + j < n ? hit_lds[(k0 + j) * 64 + lane] : P;
+			fast[j] = op[j] >= 64 && op[j] < P;
+			if (fast[j]) {
 #pragma unroll
-					for (int c = 0; c < 2; c++) {
-						f[j][c] = *reinterpret_cast<const U128u *>(buf + op[j] + 16 * c);
-						b[j][c] = *reinterpret_cast<const U128u *>(buf + op[j] - 16 - 16 * c);
-					}
-				}
-			}
-#pragma unroll
-			for (int j = 0; j < 4; j++) {
-				if (k0 + j >= base + nb)
-					continue;
-				if (op[j] >= P)
-					note(k0 + j, 0);
-				else if (!fast[j])
-					slow(k0 + j, op[j]);
-				else {
-					int fw = lead16(pf[0], f[j][0]), bk = trail16(pb[0], b[j][0]);
-					if (fw == 16)
-						fw += lead16(pf[1], f[j][1]);
-					if (bk == 16)
-						bk += trail16(pb[1], b[j][1]);
-					if (fw == 32 || bk == 32) {
-						open |= 1ull << (k0 + j - base);
-						hit_fr[(k0 + j) * 64 + lane] = (uint32_t)fw | (uint32_t)bk << 16; // (so far)
-					} else
-						note(k0 + j, (uint32_t)fw | (uint32_t)bk << 16);
+				for (int c = 0; c < 2; c++) {
+					f[j][c] = *reinterpret_cast<const U128u *>(buf + op[j] + 16 * c);
+					b[j][c] = *reinterpret_cast<const U128u *>(buf + op[j] - 16 - 16 * c);
 				}
 			}
 		}
-		while (open) {
-			int kk[4];
-			i64 op[4];
-			int fw[4], bk[4];
-			U128u f[4][2], b[4][2];
 #pragma unroll
-			for (int j = 0; j < 4; j++) {
-				kk[j] = open ? base + __ffsll((long long)open) - 1 : -1;
-				if (kk[j] >= 0) {
-					open &= open - 1;
-					op[j] = hit_lds[kk[j] * 64 + lane];
-					const uint32_t fr = hit_fr[kk[j] * 64 + lane];
-					fw[j] = (int)(fr & 0xFFFFu);
-					bk[j] = (int)(fr >> 16);
+		for (int j = 0; j < 4; j++) {
+			if (k0 + j >= n)
+				continue;
+			if (op[j] >= P)
+				note(k0 + j, 0);
+			else if (!fast[j])
+				slow(k0 + j, op[j]);
+			else {
+				int fw = lead16(pf[0], f[j][0]), bk = trail16(pb[0], b[j][0]);
+				if (fw == 16)
+					fw += lead16(pf[1], f[j][1]);
+				if (bk == 16)
+					bk += trail16(pb[1], b[j][1]);
+				if (fw == 32 || bk == 32) {
+					open |= 1ull << (k0 + j);
+					hit_fr[(k0 + j) * 64 + lane] = (uint32_t)fw | (uint32_t)bk << 16; // (so far)
+				} else
+					note(k0 + j, (uint32_t)fw | (uint32_t)bk << 16);
+			}
+		}
+	}
+	while (open) {
+		int kk[4];
+		i64 op[4];
+		int fw[4], bk[4];
+		U128u f[4][2], b[4][2];
 #pragma unroll
-					for (int c = 0; c < 2; c++) {
-						if (fw[j] == 32)
-							f[j][c] = *reinterpret_cast<const U128u *>(buf + op[j] + 32 + 16 * c);
-						if (bk[j] == 32)
-							b[j][c] = *reinterpret_cast<const U128u *>(buf + op[j] - 48 - 16 * c);
-					}
+		for (int j = 0; j < 4; j++) {
+			kk[j] = open ? __ffsll((long long)open) - 1 : -1;
+			if (kk[j] >= 0) {
+				open &= open - 1;
+				op[j] = hit_lds[kk[j] * 64 + lane];
+				const uint32_t fr = hit_fr[kk[j] * 64 + lane];
+				fw[j] = (int)(fr & 0xFFFFu);
+				bk[j] = (int)(fr >> 16);
+#pragma unroll
+				for (int c = 0; c < 2; c++) {
+					if (fw[j] == 32)
+						f[j][c] = *reinterpret_cast<const U128u *>(buf + op[j] + 32 + 16 * c);
+					if (bk[j] == 32)
+						b[j][c] = *reinterpret_cast<const U128u *>(buf + op[j] - 48 - 16 * c);
 				}
 			}
+		}
 #pragma unroll
-			for (int j = 0; j < 4; j++) {
-				if (kk[j] < 0)
-					continue;
-				if (fw[j] == 32) {
-					fw[j] += lead16(pf[2], f[j][0]);
-					if (fw[j] == 48)
-						fw[j] += lead16(pf[3], f[j][1]);
-				}
-				if (bk[j] == 32) {
-					bk[j] += trail16(pb[2], b[j][0]);
-					if (bk[j] == 48)
-						bk[j] += trail16(pb[3], b[j][1]);
-				}
-				if (fw[j] == 64 || bk[j] == 64)
-					note(kk[j], measure_hit(buf, P, op[j], end)); // longer than 64 one way: byte-wise from the start
-				else
-					note(kk[j], (uint32_t)fw[j] | (uint32_t)bk[j] << 16);
+		for (int j = 0; j < 4; j++) {
+			if (kk[j] < 0)
+				continue;
+			if (fw[j] == 32) {
+				fw[j] += lead16(pf[2], f[j][0]);
+				if (fw[j] == 48)
+					fw[j] += lead16(pf[3], f[j][1]);
 			}
+			if (bk[j] == 32) {
+				bk[j] += trail16(pb[2], b[j][0]);
+				if (bk[j] == 48)
+					bk[j] += trail16(pb[3], b[j][1]);
+			}
+			if (fw[j] == 64 || bk[j] == 64)
+				note(kk[j], measure_hit(buf, P, op[j], end)); // longer than 64 one way: byte-wise from the start
+			else
+				note(kk[j], (uint32_t)fw[j] | (uint32_t)bk[j] << 16);
 		}
 	}
 }
@@ -1141,7 +1137,6 @@ __device__ __forceinline__ void simulate_lanes(const Resolver &R, const Slot *__
 					       const i64 w_pos, const int w_ticket, i64 *hit_lds, uint32_t *eqs_lds, const int eqs_stride, LaneSim &L, LapF lap,
 					       uint32_t *hit_fr = nullptr, u64 *q_cache = nullptr)
 {
-		constexpr int QC = MAXH > 64 ? 8 : 16; // fingerprint matches of a walk step parked in LDS (dense; the deep instantiation has less room)
 		const u64 T = w_tag;
 		const i64 P = w_pos;
 		const int my_rank = bitness_rank(T);
@@ -1250,10 +1245,10 @@ __device__ __forceinline__ void simulate_lanes(const Resolver &R, const Slot *__
 								// of the step are fetched together as well -- unconditional loads, so that they are all on
 								// their way before the first is waited for -- and parked in LDS (q_cache[2 j], [2 j + 1])
 								if (__ballot(Qp != 0)) {
-									Slot c[QC];
+									Slot c[16];
 									int ql = q2 < 0 ? 0 : q2;
 #pragma unroll
-									for (int j = 0; j < QC; j++) {
+									for (int j = 0; j < 16; j++) {
 										if (Qp) {
 											ql = __ffsll((long long)Qp) - 1;
 											Qp &= Qp - 1;
@@ -1261,7 +1256,7 @@ __device__ __forceinline__ void simulate_lanes(const Resolver &R, const Slot *__
 										c[j] = tbl[idx + ql];
 									}
 #pragma unroll
-									for (int j = 0; j < QC; j++) {
+									for (int j = 0; j < 16; j++) {
 										q_cache[(2 * j) * 64 + lane] = c[j].t;
 										q_cache[(2 * j + 1) * 64 + lane] = (u64)c[j].offset;
 									}
@@ -1271,7 +1266,7 @@ __device__ __forceinline__ void simulate_lanes(const Resolver &R, const Slot *__
 						auto slot_at = [&](int q, int word) -> u64 {
 							if constexpr (DENSE) {
 								const int ord = __popcll(Q & low_mask(q)) - 3; // (the first three are in registers)
-								if (ord < QC)
+								if (ord < 16)
 									return q_cache[(2 * ord + word) * 64 + lane];
 							}
 							return word ? (u64)tbl[idx + q].offset : tbl[idx + q].t;
@@ -1986,8 +1981,8 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 	int dense_ban = 0, dense_ban_next = 1;
 	const int batch_mode_base = [&] {
 		const char *e = getenv("LRZGPU_RESOLVE_DENSE");
-		if ((!e || strcmp(e, "0")) && chain <= (unsigned)DENSE_EQS_DEEP)
-			batch_mode |= 16;
+		if ((!e || strcmp(e, "0")) && chain <= (unsigned)MAX_EQS)
+			batch_mode |= 16; // (level 9's chains of 128 equal tags are beyond what a lane of the variant holds: exact stretches there)
 		if (e && !strcmp(e, "always")) {
 			batch_mode |= 32;
 			dense = true;
@@ -2059,13 +2054,7 @@ int scan_chunk_device(ScanWorkspace *w, const uint8_t *d_chunk, int64_t chunk_si
 				   (u64 *)w->comp_tag);
 		t1.stop();
 		EventTimer t2(s);
-		if (dense && chain > (unsigned)MAX_EQS)
-			// (level 9: chains of 128 equal tags -- the same kernel with room for them: 132 hits and 128 chain slots per lane)
-			hipLaunchKernelGGL((k_resolve_mw<1, DENSE_HITS_DEEP, DENSE_EQS_DEEP, true>), dim3(1), dim3(64), 0, s, d_chunk, (Slot *)w->table, w->state, (i64)seg_lo,
-					   ntiles, (const uint32_t *)w->cand_rel, (const u64 *)w->cand_tag, (const uint32_t *)w->tile_count, w->records,
-					   batch_mode_base, (const uint32_t *)w->tile_base, (const uint32_t *)w->comp_rel, (const u64 *)w->comp_tag,
-					   (uint32_t)w->comp_cap, w->rank_bytes, w->fp_bytes);
-		else if (dense)
+		if (dense)
 			hipLaunchKernelGGL((k_resolve_mw<1, DENSE_HITS, MAX_EQS, true>), dim3(1), dim3(64), 0, s, d_chunk, (Slot *)w->table, w->state, (i64)seg_lo,
 					   ntiles, (const uint32_t *)w->cand_rel, (const u64 *)w->cand_tag, (const uint32_t *)w->tile_count, w->records,
 					   batch_mode_base, (const uint32_t *)w->tile_base, (const uint32_t *)w->comp_rel, (const u64 *)w->comp_tag,
