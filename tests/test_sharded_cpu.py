@@ -91,7 +91,13 @@ def _worker(rank, world, port, q):
             q.put(("result", got == want, len(ranges), fs.n_chunks, redone))
         else:
             assert got is None
-        q.put(("calls", rank, calls))
+        # where this rank's seconds went (lrzgpu_profile.shard_s, what bench.py --gpus N prints as critical_path)
+        import ctypes as C
+        bench = _load("lrz_bench_mod", "bench.py")
+        prof = bench.Profile()
+        B.lib().lrzgpu_profile_get.argtypes = [C.POINTER(bench.Profile)]
+        B.lib().lrzgpu_profile_get(C.byref(prof))
+        q.put(("calls", rank, calls, list(prof.shard_s)))
     finally:
         dist.destroy_process_group()
 
@@ -113,6 +119,11 @@ def test_two_ranks_chunk_sharding_and_victim_round_protocol():
     assert res[2] == res[3] >= 5
     assert res[4] >= 1, "the data was meant to break the victim_round prediction at least once"
     calls = {m[1]: m[2] for m in msgs if m[0] == "calls"}
+    stage_s = {m[1]: m[3] for m in msgs if m[0] == "calls"}
+    for r in (0, 1):  # own chunks, chain check, redone, hand-off, (hash), protocol wall -- seconds of that rank
+        own, check, redo, handoff, _, wall = stage_s[r]
+        assert wall > 0 and own > 0 and handoff >= 0 and wall >= own and wall + 1e-6 >= own + check + redo + handoff
+    assert max(stage_s[0][2], stage_s[1][2]) > 0  # somebody redid a chunk, and it shows
     k0 = {c[0] for c in calls[0]}
     k1 = {c[0] for c in calls[1]}
     assert k0 and k1 and not (k0 & k1)  # both ranks did work, on disjoint chunk sets
