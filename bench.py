@@ -666,6 +666,23 @@ def main():
         file_leg = None
         if world == 1 and not args.no_file_leg:
             file_leg = file_to_file_leg(B, buf, n_bytes, fresh_ctl, max(1, args.file_passes))
+        # the one kernel of the path that north_star expects at HBM speed, alone on the GPU (inside the step it runs on
+        # a CU-masked scan stream beside everything else: per_kernel_GBps above): k_tag_scan over the first 2 GiB of the
+        # same buffer at the mask the bench's scans mostly run under, through lrzgpu_tag_candidates_dev
+        tag_scan_alone = None
+        if world == 1:
+            try:
+                n_k1 = min(n_bytes, 2 << 30)
+                cnt, _, ms1 = B.tag_candidates_dev(buf.data_ptr(), n_k1, min_mask=0x1ff, reps=5, only_tags=True, device=local_dev)
+                _, _, ms3 = B.tag_candidates_dev(buf.data_ptr(), n_k1, min_mask=0x1ff, reps=5, only_tags=False, device=local_dev)
+                tag_scan_alone = {"kernel": "k_tag_scan", "bound": "hbm", "bytes": n_k1, "min_mask": "0x1ff", "candidates": int(cnt),
+                                  "ms_per_pass": round(ms1, 3), "achieved": round(n_k1 / ms1 / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
+                                  "frac": round(n_k1 / ms1 / 1e6 / 8000.0, 4),
+                                  "with_list_kernels_GBps": round(n_k1 / ms3 / 1e6, 1),
+                                  "what": "1 B read per position (SURVEY 8d): positions per second of k_tag_scan alone on the idle GPU, "
+                                          "average of 4 passes after the first; with k_tile_scan + k_compact_cands beside it"}
+            except Exception as e:  # (never in the way of the line)
+                tag_scan_alone = {"unavailable": repr(e)[:120]}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             sample = n_bytes if args.cpu_sample_chunks <= 0 else min(n_bytes, args.cpu_sample_chunks * chunk_size)
@@ -690,7 +707,7 @@ def main():
                            [("everything else (committer, Python, HIP runtime threads)", round((cpu_s - sum(role_cpu)) / steps, 1))]),
                        "parallelism": ("%d chunks scanned concurrently on 1 GPU" % n_chunks) if world == 1 else
                                       ("chunk k -> GPU k mod %d, chunk images handed to rank 0 over %s send/recv" % (world, ("RCCL (C transport, csrc/shard_rccl.cpp)" if transport == "rccl-c" else "RCCL via torch.distributed") if backend == "nccl" else backend))},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_k_tag_scan_alone": tag_scan_alone, "cpu_baseline": cpu,
             "critical_path": critical_path,
             "value_file_to_file": file_leg,
             "value_note": "`value` = the K timed steps with the input ALREADY RESIDENT in HBM -- what this run's measurement contract "

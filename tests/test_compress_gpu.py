@@ -48,8 +48,8 @@ def test_mixed_file_with_the_dense_resolver(B, O, dense, monkeypatch):
     degenerate part (multi-chunk layout, early block release, the lz4 gate, LZMA: everything downstream of the scan)."""
     if not _MIXED:
         base = datagen.text_like(6 << 20, seed=31)
-        head = base * 15  # (90 MiB of which rzip leaves 6: the oracle's LZMA is what this test costs)
-        data = head + datagen.phrase_mix(9 << 20, seed=32) + datagen.few_symbols(7 << 20, seed=33) + head[: 8 << 20] + datagen.phrase_mix((1 << 20) + 77, seed=34)
+        head = base * 16  # (96 MiB of which rzip leaves 6: LZMA -- the oracle's and, on four letters, the product's parser -- is what this test costs)
+        data = head + datagen.phrase_mix(3 << 20, seed=32) + datagen.few_symbols(2 << 20, seed=33) + head[: 8 << 20] + datagen.phrase_mix((1 << 20) + 77, seed=34)
         want, fs = O.compress_buffer(data, compression_level=7, threads=8, processors=8, ramsize=RAM, window=1, workers=16)
         assert fs.n_chunks == 2
         _MIXED.update(data=data, want=want)
