@@ -28,6 +28,19 @@ def test_serial_stretches_replace_rounds_that_do_not_pay(B, O, kind):
     assert rounds < 2500 or committed > 0.9 * st.lookups, (rounds, committed, exact)
 
 
+@pytest.mark.parametrize("kind,limit_s", [("few", 4.0), ("phrases", 5.0)])
+def test_degenerate_inputs_are_off_their_cliff(B, kind, limit_s):
+    """5 MiB of a four-letter alphabet / of 50 random phrases through the scan at level 7: 1.4 / 2.4 s of k_resolve since
+    the dense variant of the resolver (5.0 / 6.1 s in round 5, when every candidate was a 2 - 4 us exact
+    step).  The limits leave a slow box twice the measured time and would still catch the old path."""
+    data = datagen.KINDS[kind]((5 << 20) + 123, seed=9)
+    B.hash_search(data[: 1 << 20], level=7)  # (workspaces, code objects)
+    t0 = time.time()
+    B.hash_search(data, level=7)
+    dt = time.time() - t0
+    assert dt < limit_s, (kind, dt)
+
+
 def test_block_above_the_ceiling_is_refused_at_once(B):
     """LRZGPU_E_BLOCK_TOO_LARGE comes before anything is scanned: in seconds, not minutes into the run
     (the refusal itself is asserted in test_configs_gpu.py)."""
