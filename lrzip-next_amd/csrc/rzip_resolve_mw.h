@@ -71,6 +71,11 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 	constexpr int DH = DENSE ? MAXH * 64 : 1, DEM = 16;
 	__shared__ uint32_t hit_fr[DH];                          // measured extents of the tag hits, beside hit_all
 	__shared__ u64 q_cache[DENSE ? 32 * 64 : 1];             // a walk step's 4th .. 19th fingerprint match (tag, offset), per lane
+	// the soft writers of a round by slot, by tag, by (tag, bytes after), by (tag, bytes before): exact-key tables of 128
+	// entries (open addressing, at most 64 keys), every entry a mask of the lanes that wrote the key
+	constexpr int SPN = DENSE ? 128 : 1;
+	__shared__ uint32_t sp_skey[SPN];
+	__shared__ u64 sp_smask[SPN], sp_tkey[SPN], sp_tmask[SPN], sp_tnofb[SPN], sp_fkey[SPN], sp_fmask[SPN], sp_bkey[SPN], sp_bmask[SPN];
 	__shared__ i64 em_p[DEM], em_ofs[DEM], em_len[DEM];      // matches emitted inside the round, in order
 	__shared__ int em_lane[DEM];
 	static_assert(sizeof(i64) * MAXH * 64 * NW >= (size_t)W * 128, "staging area");
@@ -111,6 +116,12 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 	R.ext_p = R.ext_op = R.ext_done = 0;
 	for (int k = threadIdx.x; k < CFW; k += W)
 		cf_bits[k] = 0;
+	if constexpr (DENSE)
+		for (int k = threadIdx.x; k < SPN; k += W) {
+			sp_skey[k] = 0xFFFFFFFFu;
+			sp_tkey[k] = sp_fkey[k] = sp_bkey[k] = ~0ull;
+			sp_smask[k] = sp_tmask[k] = sp_tnofb[k] = sp_fmask[k] = sp_bmask[k] = 0;
+		}
 	if (threadIdx.x == 0)
 		x_miss = 0;
 
@@ -852,31 +863,129 @@ __global__ void __launch_bounds__(64 * NW) k_resolve_mw(const uint8_t *__restric
 			// its bytes and mine differ within 8 both ways (fwd < 8, back < 8: single_match_len() = 0 under any
 			// last_match); anything else is a conflict like a hard write.  One pass over the soft writers, every later
 			// lane against the writer's tag, slot and bytes -- no interval, no filter: a lookup always covers its own chain.
-			// (32-bit folds stand for the 64-bit values: different folds prove different values, equal folds are taken for
-			// equal values -- the cautious side of each test; a lane without its bytes gets folds nothing differs from)
-			// (multiplicative folds: the bytes of a four-letter input XOR-fold onto a few hundred values)
+			// (32-bit folds stand for the 64-bit byte strings: different folds prove different values, equal folds are taken
+			// for equal values -- the cautious side of each test; multiplicative folds: the bytes of a four-letter input
+			// XOR-fold onto a few hundred values.)  Rounds 6a walked the soft writers one by one, every later lane against
+			// each (64 iterations of ~90 instructions on four-letter data: a third of the round); now every soft writer
+			// enters four exact-key tables in LDS -- its slot, its tag, (tag, bytes after), (tag, bytes before) -- with
+			// its lane bit, and every lane looks its own keys up: the masks in front of its own bit are the writers it
+			// has to answer to, the first bit behind it in its slot's mask is the store that stands instead of its own.
 			const uint32_t th = (uint32_t)(w_tag ^ (w_tag >> 32));
 			const uint32_t fah = (uint32_t)((d_fa * 0x9E3779B97F4A7C15ull) >> 32), bah = (uint32_t)((d_ba * 0x9E3779B97F4A7C15ull) >> 32);
+			const u64 kf = (((u64)th << 32) | fah) & 0x7FFFFFFFFFFFFFFFull, kb = (((u64)th << 32) | bah) & 0x7FFFFFFFFFFFFFFFull;
 			const bool passable = L.nw <= 1 && !cleans && !L.pot && d_fb_ok && live && !L.complex_;
 			const bool multi = live && (wr[1] != 0xFFFFFFFFu || wr[4] != 0xFFFFFFFFu); // (more write slots than wr[0])
 			const bool looks = live && !L.complex_;
-			for (u64 sw = __ballot(soft_w); sw; sw &= sw - 1) {
-				const int w = __ffsll((long long)sw) - 1;
-				const uint32_t th_w = (uint32_t)__builtin_amdgcn_readlane((int)th, w), fah_w = (uint32_t)__builtin_amdgcn_readlane((int)fah, w);
-				const uint32_t bah_w = (uint32_t)__builtin_amdgcn_readlane((int)bah, w), w0_w = (uint32_t)__builtin_amdgcn_readlane((int)wr[0], w);
-				const bool fb_w = __builtin_amdgcn_readlane((int)d_fb_ok, w) != 0;
-				const bool later = looks && gi > w;
-				const bool writes_it = wr[0] == w0_w || (multi && (wr[1] == w0_w || wr[2] == w0_w || wr[3] == w0_w || wr[4] == w0_w));
-				const bool same_tag = th == th_w;
-				const bool passes = same_tag && passable && fb_w && fah != fah_w && bah != bah_w;
-				const bool conf = later && (same_tag ? !passes : writes_it);
-				if (later && passes)
-					soft_me = true;
-				if (conf && w < first_conf)
-					first_conf = w;
-				const u64 sm = __ballot(later && passes && writes_it);
-				if (lane == w && sm && __ffsll((long long)sm) - 1 < sup_by)
-					sup_by = __ffsll((long long)sm) - 1;
+			auto ins32 = [&](uint32_t key) -> int {
+				uint32_t h = (key * 2654435761u) >> 25;
+				for (;;) {
+					const uint32_t old = atomicCAS(&sp_skey[h], 0xFFFFFFFFu, key);
+					if (old == 0xFFFFFFFFu || old == key)
+						return (int)h;
+					h = (h + 1) & (SPN - 1);
+				}
+			};
+			auto find32 = [&](uint32_t key) -> int {
+				uint32_t h = (key * 2654435761u) >> 25;
+				for (;;) {
+					const uint32_t v = sp_skey[h];
+					if (v == key)
+						return (int)h;
+					if (v == 0xFFFFFFFFu)
+						return -1;
+					h = (h + 1) & (SPN - 1);
+				}
+			};
+			auto ins64 = [&](u64 *keys, u64 key) -> int {
+				uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 57);
+				for (;;) {
+					const u64 old = atomicCAS((unsigned long long *)&keys[h], ~0ull, (unsigned long long)key);
+					if (old == ~0ull || old == key)
+						return (int)h;
+					h = (h + 1) & (SPN - 1);
+				}
+			};
+			auto find64 = [&](const u64 *keys, u64 key) -> int {
+				uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 57);
+				for (;;) {
+					const u64 v = keys[h];
+					if (v == key)
+						return (int)h;
+					if (v == ~0ull)
+						return -1;
+					h = (h + 1) & (SPN - 1);
+				}
+			};
+			int hs = -1, ht = -1, hf = -1, hb = -1;
+			if (__ballot(soft_w)) {
+				if (soft_w) {
+					hs = ins32(wr[0]);
+					atomicOr((unsigned long long *)&sp_smask[hs], (unsigned long long)lane_bit);
+					ht = ins64(sp_tkey, w_tag);
+					atomicOr((unsigned long long *)&sp_tmask[ht], (unsigned long long)lane_bit);
+					if (!d_fb_ok)
+						atomicOr((unsigned long long *)&sp_tnofb[ht], (unsigned long long)lane_bit);
+					hf = ins64(sp_fkey, kf);
+					atomicOr((unsigned long long *)&sp_fmask[hf], (unsigned long long)lane_bit);
+					hb = ins64(sp_bkey, kb);
+					atomicOr((unsigned long long *)&sp_bmask[hb], (unsigned long long)lane_bit);
+				}
+				__syncthreads(); // (one wavefront: its LDS operations are in order; this is the compiler's fence)
+				u64 conf_m = 0;
+				if (looks) {
+					u64 cls = 0;
+					const int t = find64(sp_tkey, w_tag);
+					if (t >= 0)
+						cls = sp_tmask[t];
+					const u64 ecls = cls & lanes_below; // soft writers of my tag in front of me
+					if (ecls) {
+						if (!passable)
+							conf_m |= ecls;
+						else {
+							u64 d = sp_tnofb[t];
+							const int f2 = find64(sp_fkey, kf), b2 = find64(sp_bkey, kb);
+							if (f2 >= 0)
+								d |= sp_fmask[f2];
+							if (b2 >= 0)
+								d |= sp_bmask[b2];
+							d &= lanes_below;
+							if (d)
+								conf_m |= d; // one of them has my bytes within 8, or none to show
+							else
+								soft_me = true;
+						}
+					}
+#pragma unroll
+					for (int q = 0; q < 5; q++) {
+						if (wr[q] == 0xFFFFFFFFu || (q > 0 && !multi))
+							continue;
+						const int s2 = find32(wr[q]);
+						if (s2 < 0)
+							continue;
+						const u64 m = sp_smask[s2];
+						// a soft writer of another tag in front of me on a slot I write (of any tag, if I write several)
+						conf_m |= m & lanes_below & (multi ? ~0ull : ~cls);
+						if (q == 0 && soft_w) {
+							const u64 later = m & ~lanes_below & ~lane_bit;
+							if (later)
+								sup_by = __ffsll((long long)later) - 1; // the next store into my slot: it stands if it commits
+						}
+					}
+				}
+				if (conf_m && __ffsll((long long)conf_m) - 1 < first_conf)
+					first_conf = __ffsll((long long)conf_m) - 1;
+				__syncthreads();
+				if (soft_w) { // the tables go back empty (several lanes may clear one entry)
+					sp_skey[hs] = 0xFFFFFFFFu;
+					sp_smask[hs] = 0;
+					sp_tkey[ht] = ~0ull;
+					sp_tmask[ht] = 0;
+					sp_tnofb[ht] = 0;
+					sp_fkey[hf] = ~0ull;
+					sp_fmask[hf] = 0;
+					sp_bkey[hb] = ~0ull;
+					sp_bmask[hb] = 0;
+				}
 			}
 		}
 #pragma unroll
