@@ -673,14 +673,14 @@ def main():
         if world == 1:
             try:
                 n_k1 = min(n_bytes, 2 << 30)
-                cnt, _, ms1 = B.tag_candidates_dev(buf.data_ptr(), n_k1, min_mask=0x1ff, reps=5, only_tags=True, device=local_dev)
-                _, _, ms3 = B.tag_candidates_dev(buf.data_ptr(), n_k1, min_mask=0x1ff, reps=5, only_tags=False, device=local_dev)
+                cnt, _, ms1 = B.tag_candidates_dev(buf.data_ptr(), n_k1, min_mask=0x1ff, reps=40, only_tags=True, device=local_dev)  # (enough passes for the clocks of an idle GPU to come up)
+                _, _, ms3 = B.tag_candidates_dev(buf.data_ptr(), n_k1, min_mask=0x1ff, reps=20, only_tags=False, device=local_dev)
                 tag_scan_alone = {"kernel": "k_tag_scan", "bound": "hbm", "bytes": n_k1, "min_mask": "0x1ff", "candidates": int(cnt),
                                   "ms_per_pass": round(ms1, 3), "achieved": round(n_k1 / ms1 / 1e6, 1), "peak": 8000.0, "unit": "GB/s",
                                   "frac": round(n_k1 / ms1 / 1e6 / 8000.0, 4),
                                   "with_list_kernels_GBps": round(n_k1 / ms3 / 1e6, 1),
                                   "what": "1 B read per position (SURVEY 8d): positions per second of k_tag_scan alone on the idle GPU, "
-                                          "average of 4 passes after the first; with k_tile_scan + k_compact_cands beside it"}
+                                          "average of the passes after the first; with k_tile_scan + k_compact_cands beside it"}
             except Exception as e:  # (never in the way of the line)
                 tag_scan_alone = {"unavailable": repr(e)[:120]}
         cpu = None
