@@ -1,4 +1,4 @@
-"""Assertions about ROUND COUNTS and SECONDS -- not about bytes.  They live here, collected after every parity test
+"""Assertions about ROUND COUNTS (and printed seconds) -- not about bytes.  They live here, collected after every parity test
 (the file name sorts last and conftest.py moves anything marked `perf` to the end), so that under `pytest -x` a
 performance regression can never again keep parity tests from running (one such assertion inside
 test_rzip_gpu.py hid 83 tests)."""
@@ -28,26 +28,37 @@ def test_serial_stretches_replace_rounds_that_do_not_pay(B, O, kind):
     assert rounds < 2500 or committed > 0.9 * st.lookups, (rounds, committed, exact)
 
 
-@pytest.mark.parametrize("kind,limit_s", [("few", 4.0), ("phrases", 5.0)])
-def test_degenerate_inputs_are_off_their_cliff(B, kind, limit_s):
-    """5 MiB of a four-letter alphabet / of 50 random phrases through the scan at level 7: 1.4 / 2.4 s of k_resolve since
+@pytest.mark.parametrize("kind", ["few", "phrases"])
+def test_degenerate_inputs_are_off_their_cliff(B, kind):
+    """5 MiB of a four-letter alphabet / of 50 random phrases through the scan at level 7: 1.1 / 2.2 s of k_resolve since
     the dense variant of the resolver (5.0 / 6.1 s in round 5, when every candidate was a 2 - 4 us exact
-    step).  The limits leave a slow box twice the measured time and would still catch the old path."""
+    step).  What is ASSERTED is a count -- at most one candidate in ten takes the exact step -- because seconds depend on
+    the box and on what the process did before (behind 410 other tests the same call once took 5.0 s instead of 2.9:
+    workspaces allocated beside 100 GB of parked pools); the seconds are printed."""
+    from test_chunks_gpu import _bench, _profile
     data = datagen.KINDS[kind]((5 << 20) + 123, seed=9)
     B.hash_search(data[: 1 << 20], level=7)  # (workspaces, code objects)
+    B.lib().lrzgpu_profile_reset()
     t0 = time.time()
-    B.hash_search(data, level=7)
+    _, _, st, _, _ = B.hash_search(data, level=7)
     dt = time.time() - t0
-    assert dt < limit_s, (kind, dt)
+    p = _profile(B, _bench())
+    rounds, committed, exact = (int(v) for v in p.resolve_dbg[:3])
+    print("%s: %.2f s (k_resolve %.0f ms), %d rounds, %d committed, %d exact steps of %d lookups" % (kind, dt, p.resolve_ms, rounds, committed, exact, st.lookups))
+    assert exact < 0.1 * st.lookups and committed > 0.9 * st.lookups, (rounds, committed, exact, st.lookups)
 
 
 def test_block_above_the_ceiling_is_refused_at_once(B):
-    """LRZGPU_E_BLOCK_TOO_LARGE comes before anything is scanned: in seconds, not minutes into the run
-    (the refusal itself is asserted in test_configs_gpu.py)."""
+    """LRZGPU_E_BLOCK_TOO_LARGE comes before anything is scanned (the refusal itself is asserted in
+    test_configs_gpu.py): no kernel of the scan has run when the call returns -- a count, not a stopwatch."""
     import torch
+    from test_chunks_gpu import _bench, _profile
     n = 3 << 30
     buf = torch.zeros(n + 256, dtype=torch.uint8, device="cuda")
+    B.lib().lrzgpu_profile_reset()
     t0 = time.time()
     with pytest.raises(RuntimeError, match="rc=-108"):
         B.compress_device(buf.data_ptr(), n, level=7, threads=1, processors=1, ramsize=64 << 30, host_threads=4)
-    assert time.time() - t0 < 5.0
+    p = _profile(B, _bench())
+    print("refused after %.2f s" % (time.time() - t0))
+    assert p.tag_scan_launches == 0 and p.resolve_launches == 0 and p.mf_launches == 0
