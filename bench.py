@@ -30,8 +30,9 @@ import sys
 import resource
 import time
 
-# one hardware queue per stream (chunk scanners, gate, finder workers): must be set before HIP initialises
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+# eight hardware queues for the streams of the chunk scanners, the gate and the finder workers (32 oversubscribes the
+# GPU's resident queues and halves every kernel, see bindings.py): must be set before HIP initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))

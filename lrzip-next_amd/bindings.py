@@ -6,8 +6,11 @@ CPU fallback here: if the library is missing, loading raises.
 import ctypes as C
 import os
 
-# scan, gate and finder streams should not share hardware queues (effective only if HIP is not yet initialised)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+# Eight hardware queues for the scan, gate and finder streams (effective only if HIP is not yet initialised).  More is
+# worse: with 32 the runtime holds more queues than the GPU keeps resident, the scheduler rotates them, and EVERY
+# kernel of the process runs at about half its speed from the first step on (measured, round 6: k_resolve 392 ->
+# 192 ms per launch, k_tag_scan alone 0.63 -> 1.10 TB/s, the step 21.9 -> 20.7 s); with 4 the streams queue up.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liblrzgpu.so")
